@@ -1,0 +1,6 @@
+"""mesh_to_sdf_amd — MI355X-native hot path of Azkellas/mesh_to_sdf (generate_sdf / generate_grid_sdf).
+
+The compute lives in csrc/ (hand-written HIP for gfx950 behind the C ABI of include/m2s.h);
+this package is the thin host-side mirror of the reference's public interface
+(mesh_to_sdf/src/lib.rs:146-311, generate/grid.rs:265-270, grid.rs:30-141).
+"""

@@ -1,0 +1,331 @@
+"""Pins the CPU oracle (oracle/m2s_oracle.cpp) on every known-answer test the reference's own
+test-suite holds for the hot path.  Citations: /root/reference/mesh_to_sdf/src/<file>:<lines>.
+CPU only (no GPU needed)."""
+import numpy as np
+import pytest
+
+import oracle as orc
+
+F = np.float32
+
+
+# ---- doc-test known answers -----------------------------------------------------------
+def test_lib_doctest_rtree_bvh():
+    # lib.rs:13-31,58: tri [[.5,1.5,.5],[1,2,3],[1,3,7]], query [.5,.5,.5], default accel => [1.0]
+    v = [[0.5, 1.5, 0.5], [1.0, 2.0, 3.0], [1.0, 3.0, 7.0]]
+    out = orc.generate_sdf(v, [0, 1, 2], [[0.5, 0.5, 0.5]], accel=orc.ACCEL["RtreeBvh"])
+    assert out.tolist() == [1.0]
+
+
+def test_lib_doctest_generate_sdf():
+    # lib.rs:269-289: tri [[0,1,0],[1,2,3],[1,3,4]], query origin, RtreeBvh => vec![1.0]
+    v = [[0.0, 1.0, 0.0], [1.0, 2.0, 3.0], [1.0, 3.0, 4.0]]
+    for accel in range(4):
+        for sign in range(2):
+            out = orc.generate_sdf(v, [0, 1, 2], [[0.0, 0.0, 0.0]], accel=accel, sign=sign)
+            assert abs(out[0]) == 1.0
+    out = orc.generate_sdf(v, [0, 1, 2], [[0.0, 0.0, 0.0]], accel=3)
+    assert out.tolist() == [1.0]
+
+
+@pytest.mark.parametrize("sem", [orc.EXACT, orc.PROPAGATE, orc.EXACT_BVH])
+def test_grid_doctest(sem):
+    # generate/grid.rs:207-231: grid [0,10]^3, 10^3 cells, Raycast => sdf[0] == 1.0
+    v = [[0.5, 1.5, 0.5], [1.0, 2.0, 3.0], [1.0, 3.0, 4.0]]
+    first, size, cnt = orc.grid_from_bounding_box([0, 0, 0], [10, 10, 10], [10, 10, 10])
+    sdf = orc.generate_grid_sdf(v, [0, 1, 2], first, size, cnt, sign=0, semantics=sem)
+    assert sdf[0] == 1.0
+    # lib.rs:33-58 uses the [.5,1.5,.5],[1,2,3],[1,3,7] triangle on the same grid
+    v2 = [[0.5, 1.5, 0.5], [1.0, 2.0, 3.0], [1.0, 3.0, 7.0]]
+    sdf2 = orc.generate_grid_sdf(v2, [0, 1, 2], first, size, cnt, sign=0, semantics=sem)
+    assert sdf2[0] == 1.0
+
+
+# ---- grid == brute force, exact (generate/grid.rs:693-724) ----------------------------
+@pytest.mark.parametrize("sem", [orc.EXACT, orc.PROPAGATE, orc.EXACT_BVH])
+def test_generate_grid_equals_generate_sdf(sem):
+    v = [[0.0, 1.0, 0.0], [1.0, 2.0, 3.0], [1.0, 3.0, 4.0], [2.0, 0.0, 0.0]]
+    idx = [0, 1, 2, 1, 2, 3]
+    first, size, cnt = orc.grid_from_bounding_box([0, 0, 0], [5, 5, 5], [5, 5, 5])
+    q = [orc.grid_cell_center(first, size, cnt, [x, y, z]) for x in range(5) for y in range(5) for z in range(5)]
+    sdf = orc.generate_sdf(v, idx, np.array(q), accel=orc.ACCEL["None"], sign=orc.SIGN["Raycast"])
+    grid = orc.generate_grid_sdf(v, idx, first, size, cnt, sign=0, semantics=sem)
+    assert sdf.shape == grid.shape == (125,)
+    assert np.array_equal(sdf.view(np.uint32), grid.view(np.uint32))  # assert_eq! on f32
+    # values recorded in SURVEY.md appendix A (independent float32 restatement)
+    assert [float(x) for x in grid[:5]] == [float(F(x)) for x in (0.73854893, 0.9534626, 1.2677314, 1.6366342, 2.1794496)]
+
+
+# ---- grid.rs unit tests ---------------------------------------------------------------
+def test_grid_from_bounding_box():
+    # grid.rs:201-211
+    first, size, cnt = orc.grid_from_bounding_box([-1.0, 0.0, 1.0], [0.0, 2.0, 5.0], [2, 2, 2])
+    assert first.tolist() == [-0.75, 0.5, 2.0]
+    assert size.tolist() == [0.5, 1.0, 2.0]
+    mn, mx = orc.grid_bounding_box(first, size, cnt)
+    assert mn.tolist() == [-1.0, 0.0, 1.0] and mx.tolist() == [0.0, 2.0, 5.0]
+
+
+def test_grid_snap():
+    # grid.rs:213-239
+    first, size, cnt = orc.grid_from_bounding_box([0, 0, 0], [1, 1, 1], [2, 2, 2])
+    assert orc.grid_snap(first, size, cnt, [0.4, 0.8, 0.1]) == (True, [0, 1, 0])
+    assert orc.grid_snap(first, size, cnt, [-0.5, 0.8, 0.8]) == (False, [0, 1, 1])
+    assert orc.grid_snap(first, size, cnt, [0.8, 0.8, 0.8]) == (True, [1, 1, 1])
+    assert orc.grid_snap(first, size, cnt, [0.8, 1.5, 0.8]) == (False, [1, 1, 1])
+
+
+def test_grid_cell_idx():
+    # grid.rs:241-256
+    cnt = [2, 3, 4]
+    expect = {(0, 0, 0): 0, (0, 0, 1): 1, (0, 1, 0): 4, (0, 1, 1): 5, (1, 0, 0): 12, (1, 0, 1): 13, (1, 1, 0): 16, (1, 1, 1): 17}
+    for cell, idx in expect.items():
+        assert orc.grid_cell_idx(cnt, list(cell)) == idx
+
+
+def test_grid_integer_coordinates_roundtrip():
+    # grid.rs:258-280
+    cnt = [5, 10, 15]
+    for i in range(0, 750, 7):
+        assert orc.grid_cell_idx(cnt, orc.grid_cell_coords(cnt, i)) == i
+    for x in range(5):
+        for y in range(0, 10, 3):
+            for z in range(0, 15, 4):
+                assert orc.grid_cell_coords(cnt, orc.grid_cell_idx(cnt, [x, y, z])) == [x, y, z]
+
+
+def test_grid_cell_center():
+    # grid.rs:282-297
+    first, size, cnt = orc.grid_from_bounding_box([0, 0, 0], [1, 1, 1], [2, 2, 2])
+    for x in range(2):
+        for y in range(2):
+            for z in range(2):
+                c = orc.grid_cell_center(first, size, cnt, [x, y, z])
+                assert c.tolist() == [0.25 + 0.5 * x, 0.25 + 0.5 * y, 0.25 + 0.5 * z]
+
+
+# ---- geo.rs unit tests ----------------------------------------------------------------
+def test_closest_point_segment():
+    # geo.rs:311-323
+    a, b = [0.0, 0.0, 0.0], [1.0, 0.0, 0.0]
+    assert orc.closest_point_segment([0.3, 1.0, 0.0], a, b).tolist() == [float(F(0.3)), 0.0, 0.0]
+    assert orc.closest_point_segment([10.3, 1.0, 10.0], a, b).tolist() == [1.0, 0.0, 0.0]
+
+
+def test_point_array_ops():
+    # point/impl_array.rs tests: length([1,2,3]) == 3.7416575, dist([1,2,3],[4,5,6]) == 5.196152
+    assert orc.length([1.0, 2.0, 3.0]) == F(3.7416575)
+    assert orc.dist([1.0, 2.0, 3.0], [4.0, 5.0, 6.0]) == F(5.196152)
+
+
+def _baseline_point_triangle_distance(x0, x1, x2, x3):
+    """SDFGen-style baseline the reference's proptest compares against (geo.rs:325-370),
+    re-derived in float64: distance from x0 to triangle x1-x2-x3."""
+    x0, x1, x2, x3 = (np.asarray(v, np.float64) for v in (x0, x1, x2, x3))
+
+    def seg(p, a, b):
+        d = b - a
+        t = np.clip(np.dot(p - a, d) / np.dot(d, d), 0.0, 1.0)
+        return np.linalg.norm(p - (a + t * d))
+
+    x13, x23, x03 = x1 - x3, x2 - x3, x0 - x3
+    m13, m23, d = x13 @ x13, x23 @ x23, x13 @ x23
+    invdet = 1.0 / max(m13 * m23 - d * d, 1e-30)
+    a, b = x13 @ x03, x23 @ x03
+    w23 = invdet * (m23 * a - d * b)
+    w31 = invdet * (m13 * b - d * a)
+    w12 = 1 - w23 - w31
+    if w23 >= 0 and w31 >= 0 and w12 >= 0:
+        return np.linalg.norm(x0 - (w23 * x1 + w31 * x2 + w12 * x3))
+    if w23 > 0:
+        return min(seg(x0, x1, x2), seg(x0, x1, x3))
+    if w31 > 0:
+        return min(seg(x0, x1, x2), seg(x0, x2, x3))
+    return min(seg(x0, x1, x3), seg(x0, x2, x3))
+
+
+def _cmp_any(a, b):
+    return any(orc.approx_eq(a[i], b[i], 5, 1e-3) for i in range(3))
+
+
+def test_proptest_regression_seeds():
+    # proptest-regressions/geo.txt:7-8 — the two saved failure cases must now pass the property
+    cases = [
+        ([0.0, -8.055119, 1.1846914], [0.0, 0.0, 0.0], [0.0, 0.0, 8.367966], [-7.806354, 9.330519, 0.0]),
+        ([0.0, -5.8359632, 4.405388], [0.0, 0.9572999, 9.758267], [6.9999175, -4.739112, 7.5462694], [0.0, -9.673183, 0.52112055]),
+    ]
+    for p, a, b, c in cases:
+        d = orc.point_triangle_distance(p, a, b, c)
+        assert not np.isnan(d)
+        base = _baseline_point_triangle_distance(p, a, b, c)
+        assert orc.approx_eq(d, F(base), 5, 1e-3), (d, base)
+        # aligned ray vs generic Möller–Trumbore (geo.rs:258-287)
+        for axis, dirv in enumerate(np.eye(3)):
+            h, g = orc.ray_triangle_intersection_aligned(p, a, b, c, axis), _moller(p, dirv, a, b, c)
+            if (h is None) != (g is None):
+                # the first seed puts the +Y ray exactly on edge a-b: geo.rs:203 is strict, so a miss
+                assert h is None and _edge_margin(p, a, b, c, axis) < 1e-6
+
+
+def _moller(o, d, a, b, c):
+    """Generic ray/triangle (the reference's test-only ray_triangle_intersection_generic,
+    geo.rs:372-420), in float64."""
+    o, d, a, b, c = (np.asarray(v, np.float64) for v in (o, d, a, b, c))
+    e1, e2 = b - a, c - a
+    h = np.cross(d, e2)
+    det = e1 @ h
+    if abs(det) < 1e-12:
+        return None
+    f = 1.0 / det
+    s = o - a
+    u = f * (s @ h)
+    if u < 0 or u > 1:
+        return None
+    q = np.cross(s, e1)
+    v = f * (d @ q)
+    if v < 0 or u + v > 1:
+        return None
+    t = f * (e2 @ q)
+    return t if t > 1e-12 else None
+
+
+def test_proptest_closest_point_triangle():
+    # geo.rs:225-256 re-expressed with a fixed seed: 1000 cases, ulps 5 / eps 1e-3
+    rng = np.random.default_rng(20241008)
+    n = 0
+    while n < 1000:
+        p, a, b, c = (rng.uniform(-10, 10, 3).astype(F) for _ in range(4))
+        if _cmp_any(a, b) or _cmp_any(a, c) or _cmp_any(b, c):
+            continue
+        n += 1
+        d = orc.point_triangle_distance(p, a, b, c)
+        base = F(_baseline_point_triangle_distance(p, a, b, c))
+        assert not np.isnan(d)
+        assert orc.approx_eq(d, base, 5, 1e-3), (p, a, b, c, d, base)
+
+
+def test_proptest_ray_triangle():
+    # geo.rs:258-287 re-expressed with a fixed seed
+    rng = np.random.default_rng(7)
+    for _ in range(1000):
+        p, a, b, c = (rng.uniform(-10, 10, 3).astype(F) for _ in range(4))
+        for axis, dirv in enumerate(np.eye(3)):
+            g = _moller(p, dirv, a, b, c)
+            h = orc.ray_triangle_intersection_aligned(p, a, b, c, axis)
+            if g is None or h is None:
+                if (g is None) != (h is None):
+                    # only tolerated on the boundary (strict vs non-strict edge rule)
+                    w = _edge_margin(p, a, b, c, axis)
+                    assert w < 1e-4, (p, a, b, c, axis, g, h)
+                continue
+            assert orc.approx_eq(F(g), h, 5, 1e-3), (g, h)
+
+
+def _edge_margin(p, a, b, c, axis):
+    u, w = [(1, 2), (2, 0), (0, 1)][axis]
+    P = np.array([p[u], p[w]], np.float64)
+    T = [np.array([v[u], v[w]], np.float64) for v in (a, b, c)]
+    m = 1e30
+    for i in range(3):
+        e = T[(i + 1) % 3] - T[i]
+        d = P - T[i]
+        m = min(m, abs(e[0] * d[1] - e[1] * d[0]) / max(np.linalg.norm(e), 1e-30))
+    return m
+
+
+# ---- compare_distances (lib.rs:242-259) -----------------------------------------------
+def test_compare_distances_rules():
+    assert orc.compare_distances(1.0, 2.0) == -1
+    assert orc.compare_distances(-1.0, 2.0) == -1
+    assert orc.compare_distances(2.0, -1.0) == 1
+    # approx-equal magnitudes: positive beats negative
+    assert orc.compare_distances(1.0, -1.0) == -1
+    assert orc.compare_distances(-1.0, 1.0) == 1
+    assert orc.compare_distances(1.0 + 5e-7, -1.0) == -1   # within epsilon 1e-6
+    assert orc.compare_distances(-1.0, 1.0 + 5e-7) == 1
+    assert orc.compare_distances(-1.0, 1.0 + 3e-6) == -1   # outside: smaller magnitude wins
+    assert orc.compare_distances(1.0, 1.0) == 0
+    # 2 ulps at large magnitude (epsilon no longer covers it)
+    big = F(1000.0)
+    big2 = np.nextafter(np.nextafter(big, F(2000)), F(2000))
+    big3 = np.nextafter(big2, F(2000))
+    assert orc.compare_distances(-big, big2) == 1
+    assert orc.compare_distances(-big, big3) == -1
+    assert orc.compare_distances(float("nan"), 1.0) == -2
+    assert orc.compare_distances(1.0, np.finfo(F).max) == -1
+
+
+# ---- suzanne cross-checks (generic/*.rs tests) ----------------------------------------
+SUZ_QUERIES = [[0.01, 0.01, 0.5], [1.0, 1.0, 1.0], [0.1, 0.2, 0.2], [1.1, 2.2, 5.2], [-0.1, 0.2, -0.2], [0.0, 0.0, 0.0]]
+# min distance (f32) and signs from an independent float32 restatement
+SUZ_DIST = [0.21291672, 0.6953796, 0.45411023, 4.7007284, 0.48913327, 0.4095722]
+SUZ_SIGN = {  # columns: Bvh(Raycast)/RtreeBvh, None(Raycast), None/Bvh(Normal), Rtree
+    "best3": [-1, 1, -1, 1, -1, 1],
+    "xonly": [-1, 1, -1, 1, -1, -1],
+    "normal": [1, 1, -1, 1, -1, -1],
+    "rtree": [1, 1, -1, 1, -1, -1],
+}
+
+
+def test_suzanne_queries(suzanne):
+    v, idx = suzanne
+    q = np.array(SUZ_QUERIES, F)
+    ref = np.array(SUZ_DIST, F)
+    res = {
+        "best3": orc.generate_sdf(v, idx, q, accel=1, sign=0),
+        "rtreebvh": orc.generate_sdf(v, idx, q, accel=3),
+        "xonly": orc.generate_sdf(v, idx, q, accel=0, sign=0),
+        "normal": orc.generate_sdf(v, idx, q, accel=0, sign=1),
+        "normal_bvh": orc.generate_sdf(v, idx, q, accel=1, sign=1),
+        "rtree": orc.generate_sdf(v, idx, q, accel=2),
+    }
+    for k, out in res.items():
+        assert np.array_equal(np.abs(out), ref), (k, out)
+    assert np.array_equal(res["best3"], res["rtreebvh"])
+    assert np.array_equal(res["normal"], res["normal_bvh"])
+    for k in SUZ_SIGN:
+        assert np.sign(res[k]).astype(int).tolist() == SUZ_SIGN[k], k
+
+
+def test_suzanne_external_baseline(suzanne):
+    # generic/default.rs:83-109 + tests/generate_python_baseline.py: Normal sign,
+    # queries (0,0,0),(1,1,1),(.1,.2,.2) ~ [-0.42, 0.69, -0.46] within 0.1;
+    # pysdf's third value is 0.45411023 (opposite sign convention).
+    v, idx = suzanne
+    q = np.array([[0, 0, 0], [1, 1, 1], [0.1, 0.2, 0.2]], F)
+    out = orc.generate_sdf(v, idx, q, accel=0, sign=1)
+    base = [-0.40961263, 0.6929414, -0.46345082]
+    for o, b in zip(out, base):
+        assert abs(o - b) < 0.1
+    assert abs(out[2]) == F(0.45411023)
+
+
+def test_cross_method_tolerance(suzanne):
+    # generic/bvh.rs:192-249, :252-310; rtree.rs:172-242; rtree_bvh.rs:220-274 — grid vs generic
+    # within 0.01 (the reference accepts this much because its grid path PROPAGATES labels).
+    v, idx = suzanne
+    bmin, bmax = v.min(0), v.max(0)
+    first, size, cnt = orc.grid_from_bounding_box(bmin, bmax, [16, 16, 16])
+    q = np.array([orc.grid_cell_center(first, size, cnt, [x, y, z]) for x in range(16) for y in range(16) for z in range(16)])
+    gen = orc.generate_sdf(v, idx, q, accel=1, sign=1)
+    grid_p = orc.generate_grid_sdf(v, idx, first, size, cnt, sign=1, semantics=orc.PROPAGATE)
+    grid_e = orc.generate_grid_sdf(v, idx, first, size, cnt, sign=1, semantics=orc.EXACT)
+    assert np.array_equal(gen, grid_e)
+    assert np.max(np.abs(np.abs(gen) - np.abs(grid_p))) < 0.01
+    assert np.all(np.abs(grid_p) >= np.abs(grid_e))  # propagation never undershoots the exact minimum
+
+
+# ---- topology (generate/grid.rs:847-904, lib.rs:175-193) ------------------------------
+def test_topology_equivalence():
+    first, size, cnt = orc.grid_from_bounding_box([0, 0, 0], [5, 5, 5], [25, 25, 25])
+    v0, v1, v2, v3 = [0.0, 1.0, 0.0], [1.0, 2.0, 3.0], [1.0, 3.0, 4.0], [2.0, 0.0, 0.0]
+    a = orc.generate_grid_sdf([v0, v1, v2, v3], [0, 1, 2, 1, 2, 3, 2, 3, 0], first, size, cnt, sign=1, topology=0)
+    b = orc.generate_grid_sdf([v0, v1, v2, v1, v2, v3, v2, v3, v0], None, first, size, cnt, sign=1, topology=0)
+    c = orc.generate_grid_sdf([v0, v1, v2, v3], [0, 1, 2, 3, 0], first, size, cnt, sign=1, topology=1)
+    d = orc.generate_grid_sdf([v0, v1, v2, v3, v0], None, first, size, cnt, sign=1, topology=1)
+    for other in (b, c, d):
+        assert np.array_equal(a, other)
+    assert orc.get_triangles(4, [0, 1, 2, 3, 0], 1).tolist() == [[0, 1, 2], [1, 2, 3], [2, 3, 0]]  # no winding flip
+    assert orc.get_triangles(7, None, 0).tolist() == [[0, 1, 2], [3, 4, 5]]  # tuples() drops the partial
+    with pytest.raises(orc.OracleError):
+        orc.get_triangles(3, [0, 1, 3], 0)
