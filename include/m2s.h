@@ -1,0 +1,146 @@
+/* m2s.h — C ABI of the MI355X-native hot path of Azkellas/mesh_to_sdf.
+ *
+ * Drop-in boundary.  The reference has no FFI layer of its own; its public surface for this
+ * path is two generic Rust functions (paths relative to /root/reference/mesh_to_sdf/src):
+ *
+ *   pub fn generate_sdf<V: Point, I: Copy + Into<u32> + Sync + Send>(
+ *       vertices: &[V], indices: Topology<I>, query_points: &[V],
+ *       acceleration_method: AccelerationMethod) -> Vec<f32>              lib.rs:291-300
+ *   pub fn generate_grid_sdf<V: Point + Sync + Send, I: ...>(
+ *       vertices: &[V], indices: Topology<I>, grid: &Grid<V>,
+ *       sign_method: SignMethod) -> Vec<f32>                              generate/grid.rs:265-274
+ *
+ * The entry points below are exactly what a Rust `extern "C"` block bound behind those two
+ * signatures needs (see INTEGRATION.md for the shim): plain pointers and sizes, packed
+ * xyz float triples (`[f32; 3]` is zero-copy), u16 or u32 indices, enums as ints.
+ *
+ * Semantics.  Distances are the reference's f32 arithmetic (geo.rs:70-138 closest point,
+ * point.rs:99-126 operation order, no FMA contraction) minimised over ALL triangles, i.e. what
+ * generate_sdf(AccelerationMethod::None(..)) returns and what the reference's own test
+ * generate/grid.rs:693-724 asserts the grid path to equal.  (The reference's grid path is a
+ * heap-ordered label propagation whose result depends on the thread count and is >= this
+ * minimum on <0.5% of cells; see DESIGN.md "Exact vs propagation".)
+ *
+ * Threading: synchronous and re-entrant; calls on one device are serialised internally.
+ */
+#ifndef M2S_H
+#define M2S_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define M2S_VERSION_MAJOR 0
+#define M2S_VERSION_MINOR 1
+
+/* Return codes.  The reference panics where this ABI returns a negative code; the Rust shim
+ * turns a negative code back into panic!(m2s_last_error()). */
+#define M2S_OK 0
+#define M2S_ERR_BAD_ARG (-1)     /* null pointer / bad enum / vertex index out of range (reference: index panic) */
+#define M2S_ERR_NAN (-2)         /* "NaN distance" — lib.rs:257 expect(), Normal sign only */
+#define M2S_ERR_EMPTY_MESH (-3)  /* AccelerationMethod::Rtree on a mesh with no triangle — generic/rtree.rs:117 unwrap() */
+#define M2S_ERR_HIP (-4)         /* HIP runtime failure, or no HIP device / kernels not loadable */
+
+/* Topology — lib.rs:151-167.  List: consecutive triples, a trailing partial triple is dropped
+ * (itertools::tuples).  Strip: sliding window, NO winding flip on odd triangles (lib.rs:188-191).
+ * indices == NULL means 0..n_vertices (Topology::*(None)). */
+enum m2s_topology { M2S_TRIANGLE_LIST = 0, M2S_TRIANGLE_STRIP = 1 };
+
+/* SignMethod — lib.rs:204-216 (default Raycast). */
+enum m2s_sign_method { M2S_SIGN_RAYCAST = 0, M2S_SIGN_NORMAL = 1 };
+
+/* AccelerationMethod — lib.rs:224-239 (default RtreeBvh).  It selects the SIGN RULE, which is
+ * observable, not just a speed path:
+ *   NONE  + Raycast: parity of +X hits over all triangles          generic/default.rs:32-38,65-72
+ *   NONE  + Normal : compare_distances fold over all triangles     generic/default.rs:40-59
+ *   BVH   + Raycast: best of three +X/+Y/+Z rays from the query    generic/bvh.rs:106-141
+ *   BVH   + Normal : compare_distances fold                        generic/bvh.rs:82-94
+ *   RTREE          : normal sign of the single nearest triangle    generic/rtree.rs:113-125 (sign_method ignored)
+ *   RTREE_BVH      : nearest distance + best of three rays         generic/rtree_bvh.rs:123-173 (sign_method ignored)
+ */
+enum m2s_accel { M2S_ACCEL_NONE = 0, M2S_ACCEL_BVH = 1, M2S_ACCEL_RTREE = 2, M2S_ACCEL_RTREE_BVH = 3 };
+
+/* Grid<V> — grid.rs:30-37: centre of the first cell, cell size (may differ per axis, may be
+ * negative), cell count.  Output index of cell (x,y,z) is z + y*nz + x*ny*nz (grid.rs:122-124). */
+typedef struct m2s_grid {
+  float first_cell[3];
+  float cell_size[3];
+  uint64_t cell_count[3];
+} m2s_grid;
+
+/* Where the data pointers of a call live. */
+enum m2s_mem_kind {
+  M2S_MEM_HOST = 0,   /* vertices/indices/queries/out are host pointers (the drop-in case; H2D/D2H inside the call) */
+  M2S_MEM_DEVICE = 1  /* all four are device pointers on `device`; nothing crosses PCIe */
+};
+
+/* Phase timings of the last call, milliseconds, measured with HIP events on the call's stream
+ * (the reference logs the same three phases, generate/grid.rs:303-307,342-346,369-373). */
+typedef struct m2s_timings {
+  float accel_build_ms;  /* topology flatten + triangle records + LBVH */
+  float sign_ms;         /* grid-line ray parity planes (Raycast grid path) */
+  float distance_ms;     /* nearest-triangle search (+ fused sign resolve) — the dominant kernel */
+  float total_ms;        /* first kernel to last kernel, device side */
+  uint64_t n_triangles;
+  uint64_t n_units;      /* voxels or queries produced by this call */
+  uint32_t distance_launches;  /* number of launches of the dominant kernel in this call */
+  uint32_t reserved;
+} m2s_timings;
+
+/* Optional per-call options; pass NULL for defaults.  Set struct_size = sizeof(m2s_opts). */
+typedef struct m2s_opts {
+  uint32_t struct_size;
+  int32_t device;       /* HIP device ordinal; -1 = current device */
+  void* stream;         /* hipStream_t to enqueue on; NULL = the library's own stream for that device */
+  int32_t mem_kind;     /* enum m2s_mem_kind */
+  int32_t algorithm;    /* 0 = default (LBVH); 1 = brute force over all triangles (validation / AccelerationMethod::None) */
+  /* Grid path only: compute the x-slab [x_begin, x_end) of cells (cell axis 0 is the slowest
+   * axis, so a slab is one contiguous range of the output).  x_end == 0 means the whole grid.
+   * `out` always addresses the WHOLE grid; only the slab's range is written. */
+  uint64_t x_begin;
+  uint64_t x_end;
+  m2s_timings* timings; /* filled when non-NULL (forces a stream sync before returning) */
+  int32_t synchronous;  /* device-memory calls: 1 (default when opts==NULL) = sync before return; 0 = leave work enqueued */
+  int32_t reserved;
+} m2s_opts;
+
+/* generate_sdf — lib.rs:291-311.
+ * vertices: n_vertices packed xyz f32.  indices: n_indices values of index_bytes (2 or 4) each, or NULL.
+ * queries: n_queries packed xyz.  out: n_queries f32.  *n_out (optional) receives the number of
+ * distances written: n_queries, or 0 for RTREE_BVH on a mesh without triangles (the reference
+ * returns an empty Vec there, generic/rtree_bvh.rs:104-106). */
+int m2s_generate_sdf(const float* vertices, size_t n_vertices, const void* indices, size_t n_indices, int index_bytes,
+                     int topology, const float* queries, size_t n_queries, int accel, int sign_method, float* out,
+                     size_t* n_out, const m2s_opts* opts);
+
+/* generate_grid_sdf — generate/grid.rs:265-378.  out: cell_count[0]*[1]*[2] f32, caller owned. */
+int m2s_generate_grid_sdf(const float* vertices, size_t n_vertices, const void* indices, size_t n_indices,
+                          int index_bytes, int topology, const m2s_grid* grid, int sign_method, float* out,
+                          const m2s_opts* opts);
+
+/* Grid helpers with the reference's exact f32 arithmetic (so callers need not re-derive it).
+ * m2s_grid_from_bounding_box — Grid::from_bounding_box, grid.rs:59-74.
+ * m2s_grid_cell_center      — Grid::get_cell_center,   grid.rs:135-141.
+ * m2s_grid_cell_idx         — Grid::get_cell_idx,      grid.rs:122-124. */
+void m2s_grid_from_bounding_box(const float bbox_min[3], const float bbox_max[3], const uint64_t cell_count[3],
+                                m2s_grid* grid);
+void m2s_grid_cell_center(const m2s_grid* grid, const uint64_t cell[3], float out[3]);
+uint64_t m2s_grid_cell_idx(const m2s_grid* grid, const uint64_t cell[3]);
+
+/* Number of triangles Topology::get_triangles (lib.rs:175-193) yields for these arguments. */
+size_t m2s_triangle_count(size_t n_vertices, size_t n_indices, int has_indices, int topology);
+
+/* Library / device introspection. */
+int m2s_version(void);               /* major*1000 + minor */
+int m2s_device_count(void);          /* HIP devices visible; 0 if none (every compute call then fails with M2S_ERR_HIP) */
+const char* m2s_last_error(void);    /* thread-local message of the last failing call on this thread */
+/* Drops the cached per-device workspace (device memory is otherwise kept between calls). */
+void m2s_release_workspace(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* M2S_H */

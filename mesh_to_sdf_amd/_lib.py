@@ -1,0 +1,111 @@
+"""Loader for the gfx950 kernel library (mesh_to_sdf_amd/libm2s_hip.so, C ABI of include/m2s.h).
+
+There is deliberately NO fallback: if the HIP library is missing or cannot be loaded, every
+compute entry point raises.  The CPU oracle under oracle/ is test infrastructure and is never
+imported from here.
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "libm2s_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+M2S_OK = 0
+ERR_BAD_ARG, ERR_NAN, ERR_EMPTY_MESH, ERR_HIP = -1, -2, -3, -4
+MEM_HOST, MEM_DEVICE = 0, 1
+
+
+class M2SGrid(C.Structure):
+    _fields_ = [("first_cell", C.c_float * 3), ("cell_size", C.c_float * 3), ("cell_count", C.c_uint64 * 3)]
+
+
+class M2STimings(C.Structure):
+    _fields_ = [
+        ("accel_build_ms", C.c_float),
+        ("sign_ms", C.c_float),
+        ("distance_ms", C.c_float),
+        ("total_ms", C.c_float),
+        ("n_triangles", C.c_uint64),
+        ("n_units", C.c_uint64),
+        ("distance_launches", C.c_uint32),
+        ("reserved", C.c_uint32),
+    ]
+
+
+class M2SOpts(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32),
+        ("device", C.c_int32),
+        ("stream", C.c_void_p),
+        ("mem_kind", C.c_int32),
+        ("algorithm", C.c_int32),
+        ("x_begin", C.c_uint64),
+        ("x_end", C.c_uint64),
+        ("timings", C.POINTER(M2STimings)),
+        ("synchronous", C.c_int32),
+        ("reserved", C.c_int32),
+    ]
+
+
+# every symbol include/m2s.h declares
+EXPORTS = [
+    "m2s_generate_sdf",
+    "m2s_generate_grid_sdf",
+    "m2s_grid_from_bounding_box",
+    "m2s_grid_cell_center",
+    "m2s_grid_cell_idx",
+    "m2s_triangle_count",
+    "m2s_version",
+    "m2s_device_count",
+    "m2s_last_error",
+    "m2s_release_workspace",
+]
+
+
+def build(force=False):
+    """Compile the HIP sources in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+    args = ["make", "-C", CSRC, "-j4"]
+    if force:
+        args.append("-B")
+    subprocess.check_call(args)
+    return SO_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise RuntimeError(
+                f"{SO_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(mesh_to_sdf_amd has no CPU fallback)"
+            )
+        L = C.CDLL(SO_PATH)
+        L.m2s_generate_sdf.restype = C.c_int
+        L.m2s_generate_sdf.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p,
+                                       C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(M2SOpts)]
+        L.m2s_generate_grid_sdf.restype = C.c_int
+        L.m2s_generate_grid_sdf.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_int,
+                                            C.POINTER(M2SGrid), C.c_int, C.c_void_p, C.POINTER(M2SOpts)]
+        L.m2s_grid_from_bounding_box.restype = None
+        L.m2s_grid_from_bounding_box.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_uint64), C.POINTER(M2SGrid)]
+        L.m2s_grid_cell_center.restype = None
+        L.m2s_grid_cell_center.argtypes = [C.POINTER(M2SGrid), C.POINTER(C.c_uint64), C.POINTER(C.c_float)]
+        L.m2s_grid_cell_idx.restype = C.c_uint64
+        L.m2s_grid_cell_idx.argtypes = [C.POINTER(M2SGrid), C.POINTER(C.c_uint64)]
+        L.m2s_triangle_count.restype = C.c_size_t
+        L.m2s_triangle_count.argtypes = [C.c_size_t, C.c_size_t, C.c_int, C.c_int]
+        L.m2s_version.restype = C.c_int
+        L.m2s_device_count.restype = C.c_int
+        L.m2s_last_error.restype = C.c_char_p
+        L.m2s_release_workspace.restype = None
+        _lib = L
+    return _lib
+
+
+def last_error():
+    return lib().m2s_last_error().decode("utf-8", "replace")

@@ -1,0 +1,287 @@
+"""Host-side mirror of the reference's public interface for the hot path, over the C ABI.
+
+Same names, argument meaning and error behaviour as mesh_to_sdf 0.4.0
+(/root/reference/mesh_to_sdf/src/lib.rs:151-311, generate/grid.rs:265-274, grid.rs:30-170), so
+the parity tests read like the reference's own tests:
+
+    sdf = generate_sdf(vertices, Topology.TriangleList(indices), query_points, AccelerationMethod.RtreeBvh)
+    grid = Grid.from_bounding_box(bbox_min, bbox_max, [nx, ny, nz])
+    sdf = generate_grid_sdf(vertices, Topology.TriangleList(indices), grid, SignMethod.Raycast)
+
+numpy in -> numpy out (host pointers through the ABI: the drop-in case, H2D/D2H inside the call);
+torch CUDA tensors in -> torch CUDA tensor out (device pointers, enqueued on torch's current
+stream, nothing crosses PCIe).  Where the reference panics this raises M2SPanic.
+"""
+import ctypes as C
+import enum
+from dataclasses import dataclass
+from typing import Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+from ._lib import M2SGrid, M2SOpts, M2STimings
+
+
+class M2SError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"m2s error {code}: {msg}")
+        self.code = code
+
+
+class M2SPanic(M2SError):
+    """The reference would have panicked here (index out of range, NaN distance, empty R-tree)."""
+
+
+class SignMethod(enum.IntEnum):
+    """lib.rs:204-216 (default Raycast)."""
+    Raycast = 0
+    Normal = 1
+
+
+@dataclass(frozen=True)
+class AccelerationMethod:
+    """lib.rs:224-239: None(SignMethod) | Bvh(SignMethod) | Rtree | RtreeBvh (default)."""
+    kind: int
+    sign: SignMethod = SignMethod.Raycast
+
+    @staticmethod
+    def None_(sign: SignMethod = SignMethod.Raycast):
+        return AccelerationMethod(0, SignMethod(sign))
+
+    @staticmethod
+    def Bvh(sign: SignMethod = SignMethod.Raycast):
+        return AccelerationMethod(1, SignMethod(sign))
+
+
+AccelerationMethod.Rtree = AccelerationMethod(2, SignMethod.Normal)
+AccelerationMethod.RtreeBvh = AccelerationMethod(3, SignMethod.Raycast)
+
+
+@dataclass(frozen=True)
+class Topology:
+    """lib.rs:151-167.  indices=None means 0..len(vertices)."""
+    kind: int
+    indices: Optional[object] = None
+
+    @staticmethod
+    def TriangleList(indices=None):
+        return Topology(0, indices)
+
+    @staticmethod
+    def TriangleStrip(indices=None):
+        return Topology(1, indices)
+
+
+class Grid:
+    """grid.rs:30-170.  All arithmetic is the reference's f32 arithmetic (through the C ABI helpers)."""
+
+    def __init__(self, first_cell, cell_size, cell_count):  # Grid::new, grid.rs:43-49
+        self._g = M2SGrid()
+        for k in range(3):
+            self._g.first_cell[k] = float(np.float32(first_cell[k]))
+            self._g.cell_size[k] = float(np.float32(cell_size[k]))
+            self._g.cell_count[k] = int(cell_count[k])
+
+    new = classmethod(lambda cls, first_cell, cell_size, cell_count: cls(first_cell, cell_size, cell_count))
+
+    @classmethod
+    def from_bounding_box(cls, bbox_min, bbox_max, cell_count):  # grid.rs:59-74
+        g = cls.__new__(cls)
+        g._g = M2SGrid()
+        mn = (C.c_float * 3)(*[float(np.float32(v)) for v in bbox_min])
+        mx = (C.c_float * 3)(*[float(np.float32(v)) for v in bbox_max])
+        cnt = (C.c_uint64 * 3)(*[int(v) for v in cell_count])
+        _lib.lib().m2s_grid_from_bounding_box(mn, mx, cnt, C.byref(g._g))
+        return g
+
+    def get_first_cell(self):
+        return np.array(list(self._g.first_cell), np.float32)
+
+    def get_cell_size(self):
+        return np.array(list(self._g.cell_size), np.float32)
+
+    def get_cell_count(self):
+        return [int(v) for v in self._g.cell_count]
+
+    def get_total_cell_count(self):
+        c = self.get_cell_count()
+        return c[0] * c[1] * c[2]
+
+    def get_last_cell(self):  # grid.rs:82-88 (first + count * size, as written in the reference)
+        f, s, c = self.get_first_cell(), self.get_cell_size(), self.get_cell_count()
+        return (f + np.array(c, np.float32) * s).astype(np.float32)
+
+    def get_bounding_box(self):  # grid.rs:110-119
+        f, s, c = self.get_first_cell(), self.get_cell_size(), self.get_cell_count()
+        mn = (f - s * np.float32(0.5)).astype(np.float32)
+        mx = (mn + np.array(c, np.float32) * s).astype(np.float32)
+        return mn, mx
+
+    def get_cell_idx(self, cell):  # grid.rs:122-124
+        return int(_lib.lib().m2s_grid_cell_idx(C.byref(self._g), (C.c_uint64 * 3)(*[int(v) for v in cell])))
+
+    def get_cell_integer_coordinates(self, cell_idx):  # grid.rs:127-132
+        c = self.get_cell_count()
+        return [cell_idx // (c[1] * c[2]), (cell_idx // c[2]) % c[1], cell_idx % c[2]]
+
+    def get_cell_center(self, cell):  # grid.rs:135-141
+        out = (C.c_float * 3)()
+        _lib.lib().m2s_grid_cell_center(C.byref(self._g), (C.c_uint64 * 3)(*[int(v) for v in cell]), out)
+        return np.array(list(out), np.float32)
+
+    def snap_point_to_grid(self, point):  # grid.rs:145-170 -> ("Inside"|"Outside", [x, y, z])
+        mn, _ = self.get_bounding_box()
+        s, c = self.get_cell_size(), self.get_cell_count()
+        with np.errstate(all="ignore"):
+            cell = np.floor((np.asarray(point, np.float32) - mn) / s)
+        cell = [0 if not np.isfinite(v) and np.isnan(v) else int(np.clip(v, -2.0**62, 2.0**62)) for v in cell]
+        res = [min(max(cell[k], 0), c[k] - 1) for k in range(3)]
+        return ("Inside" if res == cell else "Outside"), res
+
+    def __eq__(self, other):
+        return isinstance(other, Grid) and bytes(self._g) == bytes(other._g)
+
+
+def _raise(rc):
+    msg = _lib.last_error()
+    if rc in (_lib.ERR_BAD_ARG, _lib.ERR_NAN, _lib.ERR_EMPTY_MESH):
+        raise M2SPanic(rc, msg)
+    raise M2SError(rc, msg)
+
+
+def _is_torch(x):
+    return type(x).__module__.startswith("torch")
+
+
+class _Args:
+    """Normalises (vertices, topology[, queries]) to raw pointers for one call."""
+
+    def __init__(self, vertices, topology: Topology, queries=None):
+        self.keep = []
+        self.device = _is_torch(vertices) and vertices.is_cuda
+        if self.device:
+            import torch
+
+            self.torch = torch
+            self.dev = vertices.device
+            v = vertices.detach().to(torch.float32).contiguous().reshape(-1, 3)
+            self.n_verts = v.shape[0]
+            self.p_verts = v.data_ptr() if v.numel() else None
+            self.keep.append(v)
+            idx = topology.indices
+            self.index_bytes = 4
+            if idx is None:
+                self.p_idx, self.n_idx = None, 0
+            else:
+                if not _is_torch(idx):
+                    idx = torch.as_tensor(np.ascontiguousarray(idx).astype(np.int64), device=self.dev)
+                idx = idx.to(device=self.dev, dtype=torch.int32).contiguous().reshape(-1)  # bit pattern == u32
+                self.n_idx = idx.numel()
+                self.p_idx = idx.data_ptr() if idx.numel() else _dummy_device_ptr(torch, self.dev, self.keep)
+                self.keep.append(idx)
+            if queries is not None:
+                q = queries if _is_torch(queries) else torch.as_tensor(np.asarray(queries, np.float32), device=self.dev)
+                q = q.detach().to(device=self.dev, dtype=torch.float32).contiguous().reshape(-1, 3)
+                self.n_q = q.shape[0]
+                self.p_q = q.data_ptr() if q.numel() else None
+                self.keep.append(q)
+        else:
+            v = np.ascontiguousarray(np.asarray(vertices, np.float32)).reshape(-1, 3)
+            self.n_verts = v.shape[0]
+            self.p_verts = v.ctypes.data if v.size else None
+            self.keep.append(v)
+            idx = topology.indices
+            if idx is None:
+                self.p_idx, self.n_idx, self.index_bytes = None, 0, 4
+            else:
+                idx = np.asarray(idx)
+                if idx.dtype == np.uint16:
+                    idx = np.ascontiguousarray(idx).reshape(-1)
+                    self.index_bytes = 2
+                else:
+                    if idx.size and (idx.min() < 0 or idx.max() > 0xFFFFFFFF):
+                        raise M2SPanic(_lib.ERR_BAD_ARG, "index does not fit u32")
+                    idx = np.ascontiguousarray(idx.astype(np.uint32)).reshape(-1)
+                    self.index_bytes = 4
+                self.n_idx = idx.size
+                self._empty = np.zeros(4, np.uint32)
+                self.p_idx = idx.ctypes.data if idx.size else self._empty.ctypes.data
+                self.keep.append(idx)
+            if queries is not None:
+                q = np.ascontiguousarray(np.asarray(queries, np.float32)).reshape(-1, 3)
+                self.n_q = q.shape[0]
+                self.p_q = q.ctypes.data if q.size else None
+                self.keep.append(q)
+        self.topology = topology.kind
+
+    def opts(self, timings=None, algorithm=0, x_begin=0, x_end=0):
+        o = M2SOpts()
+        o.struct_size = C.sizeof(M2SOpts)
+        o.algorithm = int(algorithm)
+        o.x_begin, o.x_end = int(x_begin), int(x_end)
+        o.synchronous = 1
+        if timings is not None:
+            o.timings = C.pointer(timings)
+        if self.device:
+            o.device = self.dev.index if self.dev.index is not None else self.torch.cuda.current_device()
+            o.stream = self.torch.cuda.current_stream(self.dev).cuda_stream
+            o.mem_kind = _lib.MEM_DEVICE
+        else:
+            o.device = -1
+            o.mem_kind = _lib.MEM_HOST
+        return o
+
+
+def _dummy_device_ptr(torch, dev, keep):
+    t = torch.zeros(4, dtype=torch.int32, device=dev)
+    keep.append(t)
+    return t.data_ptr()
+
+
+def generate_sdf(vertices, indices: Topology, query_points, acceleration_method: AccelerationMethod = None, *,
+                 timings: M2STimings = None, algorithm: int = 0):
+    """lib.rs:291-311."""
+    am = acceleration_method if acceleration_method is not None else AccelerationMethod.RtreeBvh
+    a = _Args(vertices, indices, query_points)
+    n_out = C.c_size_t(0)
+    if a.device:
+        out = a.torch.empty(a.n_q, dtype=a.torch.float32, device=a.dev)
+        p_out = out.data_ptr() if a.n_q else None
+    else:
+        out = np.empty(a.n_q, np.float32)
+        p_out = out.ctypes.data if a.n_q else None
+    o = a.opts(timings, algorithm)
+    rc = _lib.lib().m2s_generate_sdf(a.p_verts, a.n_verts, a.p_idx, a.n_idx, a.index_bytes, a.topology, a.p_q, a.n_q,
+                                     int(am.kind), int(am.sign), p_out, C.byref(n_out), C.byref(o))
+    if rc != _lib.M2S_OK:
+        _raise(rc)
+    return out[: n_out.value]
+
+
+def generate_grid_sdf(vertices, indices: Topology, grid: Grid, sign_method: SignMethod = SignMethod.Raycast, *,
+                      timings: M2STimings = None, algorithm: int = 0, x_slab: Sequence[int] = None, out=None):
+    """generate/grid.rs:265-378.  `x_slab=(x0, x1)` computes only cells with x0 <= x < x1 (the rest
+    of `out` is left untouched); used by the multi-GPU driver in distributed.py."""
+    a = _Args(vertices, indices)
+    total = grid.get_total_cell_count()
+    if out is None:
+        if a.device:
+            out = a.torch.empty(total, dtype=a.torch.float32, device=a.dev)
+        else:
+            out = np.empty(total, np.float32)
+    if a.device:
+        assert out.is_cuda and out.dtype == a.torch.float32 and out.numel() == total and out.is_contiguous()
+        p_out = out.data_ptr() if total else None
+    else:
+        assert out.dtype == np.float32 and out.size == total and out.flags["C_CONTIGUOUS"]
+        p_out = out.ctypes.data if total else None
+    xb, xe = (0, 0) if x_slab is None else (int(x_slab[0]), int(x_slab[1]))
+    if x_slab is not None and xb == xe:
+        return out
+    o = a.opts(timings, algorithm, xb, xe)
+    rc = _lib.lib().m2s_generate_grid_sdf(a.p_verts, a.n_verts, a.p_idx, a.n_idx, a.index_bytes, a.topology,
+                                          C.byref(grid._g), int(sign_method), p_out, C.byref(o))
+    if rc != _lib.M2S_OK:
+        _raise(rc)
+    return out

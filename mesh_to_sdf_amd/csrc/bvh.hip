@@ -1,0 +1,327 @@
+// bvh.hip — topology flatten + triangle records + LBVH in stackless pre-order layout (gfx950).
+//
+// Replaces, as behaviour, Topology::get_triangles (lib.rs:175-193) and the acceleration
+// structures the reference builds inside every call (bvh 0.10 Bvh::build_par at
+// generate/grid.rs:95-111, generic/bvh.rs:74; rstar bulk_load at generic/rtree.rs:111): they
+// only select candidates, the kernels in distance.hip take the exact minimum.
+//
+// Pipeline (all on the call's stream, no host round trip):
+//   k_tri_setup   : indices -> (a,b,c), degeneracy class, padded box (geo.rs:4-22), scene bounds
+//   k_morton      : 63-bit Morton key of the box centre
+//   rocprim radix sort (key,value)            — library sort, not on the parity path
+//   k_karras      : Karras 2012 hierarchy over the sorted keys (ranges, children, parents)
+//   k_seg_level   : segment tree of leaf boxes, one launch per level (fence-free refit)
+//   k_emit        : node boxes by range query, pre-order index = 2*first + #left-turns, skip links
+#include <cstring>
+
+#include <rocprim/rocprim.hpp>
+
+#include "common.h"
+#include "geo.hip.h"
+
+namespace m2s {
+
+namespace {
+
+struct Box {
+  float mnx, mny, mnz, mxx, mxy, mxz;
+};
+
+__device__ __forceinline__ int ord(float f) {
+  int i = __float_as_int(f);
+  return i >= 0 ? i : i ^ 0x7fffffff;
+}
+__host__ __device__ __forceinline__ float unord(int i) {
+  int b = i >= 0 ? i : i ^ 0x7fffffff;
+#ifdef __HIP_DEVICE_COMPILE__
+  return __int_as_float(b);
+#else
+  float f;
+  memcpy(&f, &b, 4);
+  return f;
+#endif
+}
+
+__device__ __forceinline__ uint32_t load_index(const void* idx, int index_bytes, size_t i) {
+  if (idx == nullptr) return (uint32_t)i;
+  return index_bytes == 2 ? (uint32_t)((const uint16_t*)idx)[i] : ((const uint32_t*)idx)[i];
+}
+
+// One thread per triangle of Topology::get_triangles (lib.rs:175-193).
+__global__ __launch_bounds__(256) void k_tri_setup(const float* __restrict__ verts, uint32_t n_verts,
+                                                   const void* __restrict__ indices, int index_bytes, int topology,
+                                                   uint32_t n_tris, TriRec* __restrict__ raw, Box* __restrict__ boxes,
+                                                   int* __restrict__ scene /*6 ordered ints*/, int* __restrict__ err) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  int lo[3] = {INT32_MAX, INT32_MAX, INT32_MAX}, hi[3] = {INT32_MIN, INT32_MIN, INT32_MIN};
+  if (t < n_tris) {
+    const size_t base = topology == 0 ? (size_t)t * 3 : (size_t)t;  // list: tuples(); strip: tuple_windows()
+    uint32_t i0 = load_index(indices, index_bytes, base), i1 = load_index(indices, index_bytes, base + 1),
+             i2 = load_index(indices, index_bytes, base + 2);
+    if (i0 >= n_verts || i1 >= n_verts || i2 >= n_verts) {
+      atomicOr(err, ERRF_INDEX_OOB);  // the reference panics on vertices[i]
+      i0 = i1 = i2 = 0;
+    }
+    f3 a = {0, 0, 0}, b = {0, 0, 0}, c = {0, 0, 0};
+    if (n_verts) {
+      a = mk3(verts[3 * (size_t)i0], verts[3 * (size_t)i0 + 1], verts[3 * (size_t)i0 + 2]);
+      b = mk3(verts[3 * (size_t)i1], verts[3 * (size_t)i1 + 1], verts[3 * (size_t)i1 + 2]);
+      c = mk3(verts[3 * (size_t)i2], verts[3 * (size_t)i2 + 1], verts[3 * (size_t)i2 + 2]);
+    }
+    f3 mn, mx;
+    triangle_bounding_box(a, b, c, &mn, &mx);
+    TriRec r;
+    r.ax = a.x; r.ay = a.y; r.az = a.z; r.cls = tri_class(a, b, c);
+    r.bx = b.x; r.by = b.y; r.bz = b.z; r.index = t;
+    r.cx = c.x; r.cy = c.y; r.cz = c.z; r.pad0 = 0.0f;
+    // bounding sphere about the box centre; radius rounded outwards
+    const float sx = 0.5f * (mn.x + mx.x), sy = 0.5f * (mn.y + mx.y), sz = 0.5f * (mn.z + mx.z);
+    auto d2 = [&](f3 p) { float dx = p.x - sx, dy = p.y - sy, dz = p.z - sz; return dx * dx + dy * dy + dz * dz; };
+    const float r2 = fmaxf(d2(a), fmaxf(d2(b), d2(c)));
+    r.sx = sx; r.sy = sy; r.sz = sz;
+    r.sr = sqrtf(r2) * 1.000001f + 1e-30f;
+    raw[t] = r;
+    boxes[t] = {mn.x, mn.y, mn.z, mx.x, mx.y, mx.z};
+    const float cen[3] = {sx, sy, sz};
+    for (int k = 0; k < 3; ++k)
+      if (cen[k] == cen[k] && fabsf(cen[k]) < 3.0e38f) { lo[k] = ord(cen[k]); hi[k] = lo[k]; }
+  }
+  // wave reduce, one atomic per wave and bound
+  for (int k = 0; k < 3; ++k) {
+    int l = lo[k], h = hi[k];
+    for (int off = 32; off > 0; off >>= 1) {
+      l = min(l, __shfl_xor(l, off));
+      h = max(h, __shfl_xor(h, off));
+    }
+    if ((threadIdx.x & 63) == 0) {
+      if (l != INT32_MAX) atomicMin(&scene[k], l);
+      if (h != INT32_MIN) atomicMax(&scene[3 + k], h);
+    }
+  }
+}
+
+__device__ __forceinline__ uint64_t expand21(uint32_t v) {
+  uint64_t x = v & 0x1fffffu;
+  x = (x | x << 32) & 0x1f00000000ffffull;
+  x = (x | x << 16) & 0x1f0000ff0000ffull;
+  x = (x | x << 8) & 0x100f00f00f00f00full;
+  x = (x | x << 4) & 0x10c30c30c30c30c3ull;
+  x = (x | x << 2) & 0x1249249249249249ull;
+  return x;
+}
+
+__global__ __launch_bounds__(256) void k_morton(const TriRec* __restrict__ raw, uint32_t n_tris,
+                                                const int* __restrict__ scene, uint64_t* __restrict__ keys,
+                                                uint32_t* __restrict__ vals) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_tris) return;
+  const float c[3] = {raw[t].sx, raw[t].sy, raw[t].sz};
+  uint32_t q[3];
+  for (int k = 0; k < 3; ++k) {
+    const float lo = unord(scene[k]), hi = unord(scene[3 + k]);
+    float u = (c[k] - lo) / (hi - lo);
+    u = (u == u) ? fminf(fmaxf(u, 0.0f), 1.0f) : 0.0f;
+    q[k] = min((uint32_t)(u * 2097152.0f), 2097151u);
+  }
+  keys[t] = (expand21(q[0]) << 2) | (expand21(q[1]) << 1) | expand21(q[2]);
+  vals[t] = t;
+}
+
+// Karras 2012.  Keys may repeat; ties are broken by position, which keeps the tree well formed.
+__device__ __forceinline__ int delta(const uint64_t* __restrict__ keys, int n, int i, int j) {
+  if (j < 0 || j >= n) return -1;
+  const uint64_t a = keys[i], b = keys[j];
+  if (a == b) return 64 + __clz((uint32_t)i ^ (uint32_t)j);
+  return __clzll((long long)(a ^ b));
+}
+
+// Node ids: internal i in [0, n-2], leaf k -> (n-1) + k.
+__global__ __launch_bounds__(256) void k_karras(const uint64_t* __restrict__ keys, int n, int2* __restrict__ range,
+                                                int2* __restrict__ child, int* __restrict__ parent) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n - 1) return;
+  const int d = (delta(keys, n, i, i + 1) - delta(keys, n, i, i - 1)) >= 0 ? 1 : -1;
+  const int dmin = delta(keys, n, i, i - d);
+  int lmax = 2;
+  while (delta(keys, n, i, i + lmax * d) > dmin) lmax <<= 1;
+  int l = 0;
+  for (int t = lmax >> 1; t >= 1; t >>= 1)
+    if (delta(keys, n, i, i + (l + t) * d) > dmin) l += t;
+  const int j = i + l * d;
+  const int dnode = delta(keys, n, i, j);
+  int s = 0;
+  for (int t = (l + 1) >> 1;; t = (t + 1) >> 1) {
+    if (delta(keys, n, i, i + (s + t) * d) > dnode) s += t;
+    if (t <= 1) break;
+  }
+  const int gamma = i + s * d + min(d, 0);
+  const int first = min(i, j), last = max(i, j);
+  const int left = (first == gamma) ? (n - 1) + gamma : gamma;
+  const int right = (last == gamma + 1) ? (n - 1) + gamma + 1 : gamma + 1;
+  range[i] = make_int2(first, last);
+  child[i] = make_int2(left, right);
+  parent[left] = i;
+  parent[right] = -i - 2;  // negative: "I am a right child of i"  (root keeps its initial marker)
+}
+
+__device__ __forceinline__ Box box_union(Box a, Box b) {
+  return {fminf(a.mnx, b.mnx), fminf(a.mny, b.mny), fminf(a.mnz, b.mnz),
+          fmaxf(a.mxx, b.mxx), fmaxf(a.mxy, b.mxy), fmaxf(a.mxz, b.mxz)};
+}
+
+// Level 0 of the segment tree: leaf boxes in sorted order.
+__global__ __launch_bounds__(256) void k_seg_level0(const Box* __restrict__ boxes, const uint32_t* __restrict__ order,
+                                                    int n, Box* __restrict__ seg) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < n) seg[k] = boxes[order[k]];
+}
+__global__ __launch_bounds__(256) void k_seg_level(const Box* __restrict__ below, int n_below, Box* __restrict__ here,
+                                                   int n_here) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n_here) return;
+  Box b = below[2 * j];
+  if (2 * j + 1 < n_below) b = box_union(b, below[2 * j + 1]);
+  here[j] = b;
+}
+
+struct SegLevels {
+  uint32_t off[34];
+  uint32_t cnt[34];
+  int levels;
+};
+
+__device__ __forceinline__ Box seg_query(const Box* __restrict__ seg, const SegLevels& lv, int first, int last) {
+  const float inf = __builtin_inff();
+  Box acc = {inf, inf, inf, -inf, -inf, -inf};
+  uint32_t lo = (uint32_t)first, hi = (uint32_t)last + 1u;
+  int level = 0;
+  while (lo < hi) {
+    if (lo & 1u) { acc = box_union(acc, seg[lv.off[level] + lo]); ++lo; }
+    if (hi & 1u) { --hi; acc = box_union(acc, seg[lv.off[level] + hi]); }
+    lo >>= 1; hi >>= 1; ++level;
+  }
+  return acc;
+}
+
+// One thread per node (internal 0..n-2, leaves n-1..2n-2): pre-order slot, box, skip link,
+// and for leaves the sorted triangle record.
+__global__ __launch_bounds__(256) void k_emit(int n, const int2* __restrict__ range, const int* __restrict__ parent,
+                                              const Box* __restrict__ seg, SegLevels lv,
+                                              const uint32_t* __restrict__ order, const TriRec* __restrict__ raw,
+                                              NodeRec* __restrict__ nodes, TriRec* __restrict__ tris) {
+  const int id = blockIdx.x * blockDim.x + threadIdx.x;
+  if (id >= 2 * n - 1) return;
+  const bool leaf = id >= n - 1;
+  int first, last;
+  if (leaf) { first = last = id - (n - 1); }
+  else { int2 r = range[id]; first = r.x; last = r.y; }
+  // number of left turns on the root -> node path
+  int lefts = 0, cur = id;
+  while (true) {
+    const int p = parent[cur];
+    if (p == INT32_MIN) break;          // root marker
+    if (p >= 0) { ++lefts; cur = p; }   // cur is a left child of p
+    else cur = -p - 2;                  // right child
+  }
+  const uint32_t slot = 2u * (uint32_t)first + (uint32_t)lefts;
+  const uint32_t cnt = (uint32_t)(last - first + 1);
+  Box b = leaf ? seg[first] : seg_query(seg, lv, first, last);
+  NodeRec nr;
+  nr.mnx = b.mnx; nr.mny = b.mny; nr.mnz = b.mnz;
+  nr.skip = slot + 2u * cnt - 1u;
+  nr.mxx = b.mxx; nr.mxy = b.mxy; nr.mxz = b.mxz;
+  nr.tri = leaf ? first : -1;
+  nodes[slot] = nr;
+  if (leaf) tris[first] = raw[order[first]];
+}
+
+__global__ void k_init_scene(int* scene, int* parent, int n_nodes) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < 3) scene[i] = INT32_MAX;
+  else if (i < 6) scene[i] = INT32_MIN;
+  if (i < n_nodes) parent[i] = INT32_MIN;
+}
+
+inline unsigned cdiv(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }
+
+}  // namespace
+
+size_t bvh_workspace_bytes(size_t n_tris) {
+  const size_t n = n_tris ? n_tris : 1;
+  size_t sort_tmp = 0;
+  (void)rocprim::radix_sort_pairs(nullptr, sort_tmp, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr,
+                            (uint32_t*)nullptr, n, 0, 64, (hipStream_t)0);
+  size_t b = 0;
+  b += n * sizeof(TriRec) * 2 + n * sizeof(Box) * 3 + n * (8 + 4) * 2 + sort_tmp;
+  b += n * (sizeof(int2) * 2) + 2 * n * sizeof(int) + 2 * n * sizeof(NodeRec);
+  return b + 64 * 256 + 4096;
+}
+
+int build_device_mesh(Arena& ws, hipStream_t st, const float* d_verts, size_t n_verts, const void* d_indices,
+                      size_t n_indices, int index_bytes, int topology, size_t n_tris, int* d_err, DeviceMesh* out) {
+  (void)n_indices;
+  out->tris = nullptr;
+  out->nodes = nullptr;
+  out->scene = nullptr;
+  out->n_tris = (uint32_t)n_tris;
+  out->n_nodes = n_tris ? (uint32_t)(2 * n_tris - 1) : 0;
+  if (n_tris == 0) return 0;
+  const int n = (int)n_tris;
+
+  TriRec* raw = ws.take<TriRec>(n_tris);
+  TriRec* tris = ws.take<TriRec>(n_tris);
+  Box* boxes = ws.take<Box>(n_tris);
+  Box* seg = ws.take<Box>(2 * n_tris + 64);
+  uint64_t* keys = ws.take<uint64_t>(n_tris);
+  uint64_t* keys2 = ws.take<uint64_t>(n_tris);
+  uint32_t* vals = ws.take<uint32_t>(n_tris);
+  uint32_t* order = ws.take<uint32_t>(n_tris);
+  int2* range = ws.take<int2>(n_tris);
+  int2* child = ws.take<int2>(n_tris);
+  int* parent = ws.take<int>(2 * n_tris);
+  NodeRec* nodes = ws.take<NodeRec>(2 * n_tris);
+  int* scene = ws.take<int>(8);
+  size_t sort_tmp = 0;
+  (void)rocprim::radix_sort_pairs(nullptr, sort_tmp, keys, keys2, vals, order, n_tris, 0, 64, st);
+  void* tmp = ws.take<char>(sort_tmp ? sort_tmp : 1);
+  if (!raw || !tris || !boxes || !seg || !keys || !keys2 || !vals || !order || !range || !child || !parent || !nodes ||
+      !scene || !tmp) {
+    set_error("internal: BVH workspace too small");
+    return M2S_ERR_HIP_INTERNAL;
+  }
+
+  const unsigned B = 256;
+  hipLaunchKernelGGL(k_init_scene, dim3(cdiv(2 * n_tris, B)), dim3(B), 0, st, scene, parent, 2 * n - 1);
+  hipLaunchKernelGGL(k_tri_setup, dim3(cdiv(n_tris, B)), dim3(B), 0, st, d_verts, (uint32_t)n_verts, d_indices,
+                     index_bytes, topology, (uint32_t)n_tris, raw, boxes, scene, d_err);
+  hipLaunchKernelGGL(k_morton, dim3(cdiv(n_tris, B)), dim3(B), 0, st, raw, (uint32_t)n_tris, scene, keys, vals);
+  M2S_HIP_CHECK(rocprim::radix_sort_pairs(tmp, sort_tmp, keys, keys2, vals, order, n_tris, 0, 64, st));
+  if (n > 1) hipLaunchKernelGGL(k_karras, dim3(cdiv(n_tris - 1, B)), dim3(B), 0, st, keys2, n, range, child, parent);
+
+  SegLevels lv;
+  lv.levels = 0;
+  {
+    uint32_t off = 0, cnt = (uint32_t)n_tris;
+    while (true) {
+      lv.off[lv.levels] = off;
+      lv.cnt[lv.levels] = cnt;
+      ++lv.levels;
+      if (cnt == 1) break;
+      off += cnt;
+      cnt = (cnt + 1) / 2;
+    }
+  }
+  hipLaunchKernelGGL(k_seg_level0, dim3(cdiv(n_tris, B)), dim3(B), 0, st, boxes, order, n, seg);
+  for (int l = 1; l < lv.levels; ++l)
+    hipLaunchKernelGGL(k_seg_level, dim3(cdiv(lv.cnt[l], B)), dim3(B), 0, st, seg + lv.off[l - 1], (int)lv.cnt[l - 1],
+                       seg + lv.off[l], (int)lv.cnt[l]);
+  hipLaunchKernelGGL(k_emit, dim3(cdiv(2 * n_tris - 1, B)), dim3(B), 0, st, n, range, parent, seg, lv, order, raw,
+                     nodes, tris);
+  M2S_HIP_CHECK(hipGetLastError());
+  out->tris = tris;
+  out->nodes = nodes;
+  out->scene = scene;
+  return 0;
+}
+
+}  // namespace m2s

@@ -1,0 +1,129 @@
+// common.h — records shared by the host orchestration and the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace m2s {
+
+// ---- HBM layout --------------------------------------------------------------------------
+// Triangle record, 64 B, 64-B aligned, stored in Morton (= BVH leaf) order.  Every lane of a
+// wave tests the SAME triangle, so a record is fetched with wave-uniform (scalar) loads:
+// one s_load_dwordx16 per triangle; the record is therefore packed per triangle, while
+// everything that is read lane-parallel (queries, outputs, bit planes) is SoA / linear.
+struct alignas(64) TriRec {
+  float ax, ay, az;
+  uint32_t cls;        // geo.hip.h tri_class (degeneracy class of geo.rs:73-88)
+  float bx, by, bz;
+  uint32_t index;      // triangle index in Topology::get_triangles order (tie-break for Rtree)
+  float cx, cy, cz;
+  float pad0;
+  float sx, sy, sz;    // bounding sphere of the triangle: centre ...
+  float sr;            // ... and radius (conservative), for the cheap per-lane reject
+};
+static_assert(sizeof(TriRec) == 64, "TriRec must be 64 bytes");
+
+// Stackless BVH node, 32 B, pre-order (depth-first) layout:
+//   the left child of node i is i+1; `skip` is the next node once the subtree of i is done
+//   (== node count at the right spine), so traversal is   i = hit && !leaf ? i + 1 : skip.
+// Leaves hold one triangle: the padded box of geo.rs:4-22 (1e-4), internal nodes the union.
+struct alignas(32) NodeRec {
+  float mnx, mny, mnz;
+  uint32_t skip;
+  float mxx, mxy, mxz;
+  int32_t tri;         // >= 0: leaf, index into the TriRec array; -1: internal
+};
+static_assert(sizeof(NodeRec) == 32, "NodeRec must be 32 bytes");
+
+struct DeviceMesh {
+  const TriRec* tris;   // n_tris records, Morton order
+  const NodeRec* nodes; // n_nodes = 2*n_tris - 1 (0 if n_tris == 0)
+  uint32_t n_tris;
+  uint32_t n_nodes;
+  const int* scene;     // 6 order-encoded ints: min xyz / max xyz of the triangle box centres (see bvh.hip)
+};
+
+// Largest |coordinate| of the mesh (from the order-encoded centre bounds); feeds the pruning slack.
+__device__ __forceinline__ float mesh_scale(const DeviceMesh& m) {
+  float s = 0.0f;
+  for (int k = 0; k < 6; ++k) {
+    int i = m.scene[k];
+    int b = i >= 0 ? i : i ^ 0x7fffffff;
+    float f = __int_as_float(b);
+    if (f == f && fabsf(f) < 3.0e38f) s = fmaxf(s, fabsf(f));
+  }
+  return s;
+}
+
+struct GridParams {
+  float first[3];
+  float size[3];
+  uint32_t n[3];
+  uint32_t xb, xe;   // x-slab [xb, xe)
+  uint32_t nzw;      // 32-bit words per (x,y) row of a bit plane = ceil(nz / 32)
+  uint64_t out_off;  // subtracted from the whole-grid cell index when writing (slab staging buffers)
+};
+
+// Device-side error flags (OR-ed into one int by kernels).
+enum : int { ERRF_INDEX_OOB = 1, ERRF_NAN = 2 };
+
+// Result modes of the nearest search.
+enum : int {
+  MODE_UNSIGNED = 0,      // min unsigned distance (Raycast magnitude)                       default.rs:44-51
+  MODE_NORMAL_FOLD = 1,   // compare_distances fold (None/Bvh + Normal, grid Normal)         default.rs:52-59
+  MODE_NEAREST_NORMAL = 2 // sign of the single nearest triangle (Rtree)                     rtree.rs:113-125
+};
+// Sign sources for MODE_UNSIGNED.
+enum : int {
+  SIGN_NONE = 0,
+  SIGN_GRID_PLANE = 1,  // grid path: majority bit plane from sign.hip
+  SIGN_RAYS3 = 2,       // generic: best of three axis rays from the query, BVH candidate rule
+  SIGN_XRAY_ALL = 3     // generic None(Raycast): +X ray against ALL triangles (brute force only)
+};
+
+#define M2S_HIP_CHECK(expr)                                                   \
+  do {                                                                        \
+    hipError_t _e = (expr);                                                   \
+    if (_e != hipSuccess) {                                                   \
+      ::m2s::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+      return M2S_ERR_HIP_INTERNAL;                                            \
+    }                                                                         \
+  } while (0)
+
+constexpr int M2S_ERR_HIP_INTERNAL = -4;
+void set_error(const char* fmt, ...);
+
+// Bump allocator over one device block per device (kept between calls; see capi.hip).
+struct Arena {
+  char* base = nullptr;
+  size_t cap = 0;
+  size_t off = 0;
+  template <class T>
+  T* take(size_t count, size_t align = 256) {
+    size_t o = (off + align - 1) / align * align;
+    size_t bytes = count * sizeof(T);
+    if (o + bytes > cap) return nullptr;
+    off = o + bytes;
+    return reinterpret_cast<T*>(base + o);
+  }
+};
+
+// ---- host launchers implemented in the .hip files ------------------------------------------
+// bvh.hip: flatten topology, build triangle records + LBVH in pre-order layout.
+size_t bvh_workspace_bytes(size_t n_tris);
+int build_device_mesh(Arena& ws, hipStream_t st, const float* d_verts, size_t n_verts, const void* d_indices,
+                      size_t n_indices, int index_bytes, int topology, size_t n_tris, int* d_err, DeviceMesh* out);
+
+// sign.hip: grid-line ray parity -> one "inside" bit per voxel (bit plane in grid layout).
+size_t sign_workspace_bytes(const GridParams& g);
+int build_grid_sign_plane(Arena& ws, hipStream_t st, const DeviceMesh& mesh, const GridParams& g,
+                          const uint32_t** d_inside_plane);
+
+// distance.hip
+int launch_grid_distance(hipStream_t st, const DeviceMesh& mesh, const GridParams& g, int mode,
+                         const uint32_t* d_inside_plane, int algorithm, float* d_out, int* d_err);
+size_t query_workspace_bytes(size_t n_q);
+int launch_query_distance(Arena& ws, hipStream_t st, const DeviceMesh& mesh, const float* d_queries, size_t n_q,
+                          int mode, int sign_src, int algorithm, float* d_out, int* d_err);
+
+}  // namespace m2s

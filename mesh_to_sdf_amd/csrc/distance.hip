@@ -1,0 +1,448 @@
+// distance.hip — nearest-triangle distance + sign resolve, the dominant kernels (gfx950).
+//
+// Semantics: D(p) = min over ALL triangles of geo.rs:26-30 in the reference's
+// f32 operation order; sign by the rule the caller's SignMethod / AccelerationMethod selects.
+//
+// Two kernel families, same arithmetic (geo.hip.h):
+//   k_brute  : every point against every triangle, triangle records staged through LDS in tiles
+//              (AccelerationMethod::None, and the on-device cross-check of the BVH path).
+//   k_packet : one wave = 64 spatially adjacent points (a 4x4x4 brick of voxels, or 64 Morton-
+//              sorted queries).  The wave walks the stackless pre-order BVH TOGETHER: the node
+//              index is wave-uniform (SGPR), node and triangle records arrive through scalar
+//              loads, each lane tests its own point, and a subtree is skipped when the ballot of
+//              "my bound reaches this box" is empty.  No per-lane stack, no divergence, no gather.
+//
+// Pruning is conservative: a subtree is dropped only if its box is farther than the lane's
+// current best by a margin that covers f32 rounding of both the box test and the reference
+// arithmetic (see prune_bound), so the minimum is the brute-force minimum bit for bit.
+#include <cstring>
+
+#include <rocprim/rocprim.hpp>
+
+#include "common.h"
+#include "geo.hip.h"
+
+namespace m2s {
+
+namespace {
+
+constexpr float F32_MAX_C = 3.402823466e+38f;
+constexpr int TILE = 128;  // triangles per LDS tile in k_brute (8 KiB)
+
+// ---- point sources -------------------------------------------------------------------------
+struct GridBrick {
+  uint32_t x, y, z;
+  bool in_range;
+};
+
+__device__ __forceinline__ GridBrick grid_lane_voxel(const GridParams& g, uint32_t brick, int lane) {
+  const uint32_t nby = (g.n[1] + 3) >> 2, nbz = (g.n[2] + 3) >> 2;
+  const uint32_t bz = brick % nbz, by = (brick / nbz) % nby, bx = brick / (nbz * nby);
+  GridBrick v;
+  v.x = g.xb + bx * 4 + (lane >> 4);
+  v.y = by * 4 + ((lane >> 2) & 3);
+  v.z = bz * 4 + (lane & 3);
+  v.in_range = v.x < g.xe && v.y < g.n[1] && v.z < g.n[2];
+  v.x = min(v.x, g.xe - 1);
+  v.y = min(v.y, g.n[1] - 1);
+  v.z = min(v.z, g.n[2] - 1);
+  return v;
+}
+__device__ __forceinline__ f3 grid_point(const GridParams& g, const GridBrick& v) {
+  return {cell_center(g.first[0], g.size[0], v.x), cell_center(g.first[1], g.size[1], v.y),
+          cell_center(g.first[2], g.size[2], v.z)};  // grid.rs:135-141
+}
+__device__ __forceinline__ uint32_t grid_brick_count(const GridParams& g) {
+  return ((g.xe - g.xb + 3) >> 2) * ((g.n[1] + 3) >> 2) * ((g.n[2] + 3) >> 2);
+}
+
+// XCD-aware work order: the dispatcher places block b on XCD b % 8; give every XCD one contiguous
+// run of the brick sequence so that its private L2 keeps seeing the same part of the BVH.
+__device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t chunk) { return (b & 7u) * chunk + (b >> 3); }
+
+// ---- per-lane search state -----------------------------------------------------------------
+template <int MODE>
+struct Best {
+  float d2 = __builtin_inff();      // min d2 over all triangles
+  float d2pos = __builtin_inff();   // MODE_NORMAL_FOLD: min d2 over triangles with positive signed distance
+  uint32_t idx = 0xffffffffu;       // MODE_NEAREST_NORMAL: triangle achieving d2 (lowest index on ties)
+  bool pos = false;                 // MODE_NEAREST_NORMAL: its sign
+  bool nan = false;
+};
+
+template <int MODE>
+__device__ __forceinline__ void eval_triangle(Best<MODE>& best, f3 p, f3 a, f3 b, f3 c, uint32_t cls, uint32_t index) {
+  if (MODE == MODE_UNSIGNED) {
+    best.d2 = fminf(best.d2, point_triangle_dist2(p, a, b, c, cls));  // f32::min drops a NaN operand (default.rs:47)
+  } else {
+    bool positive;
+    const float d2 = point_triangle_dist2_signed(p, a, b, c, cls, &positive);
+    if (MODE == MODE_NORMAL_FOLD) {
+      best.nan |= !(d2 == d2);  // the reference panics: "NaN distance" (lib.rs:257)
+      best.d2 = fminf(best.d2, d2);
+      if (positive) best.d2pos = fminf(best.d2pos, d2);
+    } else {
+      if (d2 < best.d2 || (d2 == best.d2 && index < best.idx)) { best.d2 = d2; best.idx = index; best.pos = positive; }
+    }
+  }
+}
+
+template <int MODE>
+__device__ __forceinline__ float finish(const Best<MODE>& best, bool negate_unsigned) {
+  if (MODE == MODE_UNSIGNED) {
+    const float d = fminf(F32_MAX_C, sqrtf(best.d2));   // fold starts from f32::MAX (default.rs:45)
+    return negate_unsigned ? -d : d;
+  }
+  if (MODE == MODE_NORMAL_FOLD) return normal_fold_result(best.d2, best.d2pos);
+  const float d = sqrtf(best.d2);
+  return best.pos ? d : -d;                              // rtree.rs:118-123
+}
+
+// Pruning threshold in d2 space for the current best.  margin: relative 2e-5 on the distance
+// plus `slack` absolute (~32 ulp of the coordinate scale, + the approx_eq window in Normal mode).
+__device__ __forceinline__ float prune_bound(float best_d2, float slack) {
+  const float d = __builtin_amdgcn_sqrtf(best_d2);
+  const float r = __builtin_fmaf(d, 1.00002f, slack);
+  return r * r;
+}
+
+__device__ __forceinline__ float box_dist2(f3 p, float mnx, float mny, float mnz, float mxx, float mxy, float mxz) {
+  const float dx = fmaxf(fmaxf(mnx - p.x, p.x - mxx), 0.0f);
+  const float dy = fmaxf(fmaxf(mny - p.y, p.y - mxy), 0.0f);
+  const float dz = fmaxf(fmaxf(mnz - p.z, p.z - mxz), 0.0f);
+  return __builtin_fmaf(dx, dx, __builtin_fmaf(dy, dy, dz * dz));
+}
+
+template <int AXIS>
+__device__ __forceinline__ uint32_t stab_count(const DeviceMesh& mesh, f3 p) {
+  uint32_t count = 0;
+  uint32_t node = 0;
+  while (node < mesh.n_nodes) {
+    node = __builtin_amdgcn_readfirstlane(node);
+    const NodeRec nr = mesh.nodes[node];
+    const bool hit = ray_meets_box<AXIS>(p, mk3(nr.mnx, nr.mny, nr.mnz), mk3(nr.mxx, nr.mxy, nr.mxz));
+    if (__ballot(hit) == 0ull) { node = nr.skip; continue; }
+    if (nr.tri >= 0) {
+      const TriRec tr = mesh.tris[nr.tri];
+      float t;
+      const bool h = ray_triangle_aligned<AXIS>(p, mk3(tr.ax, tr.ay, tr.az), mk3(tr.bx, tr.by, tr.bz),
+                                                mk3(tr.cx, tr.cy, tr.cz), &t);
+      count += (hit & h) ? 1u : 0u;   // leaf box == padded triangle box: `hit` is the candidate rule
+      node = nr.skip;
+    } else {
+      node = node + 1;
+    }
+  }
+  return count;
+}
+
+// ---- k_packet -------------------------------------------------------------------------------
+template <bool GRID, int MODE, int SIGN>
+__global__ __launch_bounds__(256) void k_packet(DeviceMesh mesh, GridParams g, const float4* __restrict__ qsorted,
+                                                const uint32_t* __restrict__ perm, uint32_t n_q,
+                                                const uint32_t* __restrict__ plane, float* __restrict__ out,
+                                                int* __restrict__ err, uint32_t n_packets, uint32_t chunk) {
+  const int lane = threadIdx.x & 63;
+  const uint32_t block = xcd_remap(blockIdx.x, chunk);
+  const uint32_t packet = block * 4 + (threadIdx.x >> 6);
+  if (packet >= n_packets) return;
+
+  f3 p;
+  size_t out_index;
+  bool store;
+  GridBrick vox{};
+  if (GRID) {
+    vox = grid_lane_voxel(g, packet, lane);
+    p = grid_point(g, vox);
+    out_index = ((size_t)vox.x * g.n[1] + vox.y) * g.n[2] + vox.z - (size_t)g.out_off;
+    store = vox.in_range;
+  } else {
+    const uint32_t i = min(packet * 64u + lane, n_q - 1);
+    const float4 q = qsorted[i];
+    p = mk3(q.x, q.y, q.z);
+    out_index = perm[i];
+    store = packet * 64u + lane < n_q;
+  }
+
+  Best<MODE> best;
+  if (mesh.n_nodes) {
+    const float scale = fmaxf(mesh_scale(mesh), fmaxf(fabsf(p.x), fmaxf(fabsf(p.y), fabsf(p.z))));
+    const float slack = 4.0e-6f * scale + (MODE == MODE_NORMAL_FOLD ? 2.5e-6f : 0.0f);
+
+    // seed: greedy descent towards the packet's first point, evaluate that leaf for every lane
+    {
+      const f3 c = {__shfl(p.x, 0), __shfl(p.y, 0), __shfl(p.z, 0)};
+      uint32_t n = 0;
+      NodeRec nr = mesh.nodes[0];
+      while (nr.tri < 0) {
+        const uint32_t l = n + 1;
+        const NodeRec nl = mesh.nodes[l];
+        const uint32_t r = nl.skip;
+        const NodeRec nrr = mesh.nodes[r];
+        const float dl = box_dist2(c, nl.mnx, nl.mny, nl.mnz, nl.mxx, nl.mxy, nl.mxz);
+        const float dr = box_dist2(c, nrr.mnx, nrr.mny, nrr.mnz, nrr.mxx, nrr.mxy, nrr.mxz);
+        const bool go_left = __builtin_amdgcn_readfirstlane((int)(dl <= dr)) != 0;
+        n = go_left ? l : r;
+        nr = go_left ? nl : nrr;
+      }
+      const TriRec tr = mesh.tris[nr.tri];
+      eval_triangle<MODE>(best, p, mk3(tr.ax, tr.ay, tr.az), mk3(tr.bx, tr.by, tr.bz), mk3(tr.cx, tr.cy, tr.cz),
+                          tr.cls, tr.index);
+    }
+
+    float thr = prune_bound(best.d2, slack);
+    uint32_t node = 0;
+    while (node < mesh.n_nodes) {
+      node = __builtin_amdgcn_readfirstlane(node);
+      const NodeRec nr = mesh.nodes[node];
+      const float bd2 = box_dist2(p, nr.mnx, nr.mny, nr.mnz, nr.mxx, nr.mxy, nr.mxz);
+      if (__ballot(bd2 <= thr) == 0ull) { node = nr.skip; continue; }
+      if (nr.tri >= 0) {
+        const TriRec tr = mesh.tris[nr.tri];
+        eval_triangle<MODE>(best, p, mk3(tr.ax, tr.ay, tr.az), mk3(tr.bx, tr.by, tr.bz), mk3(tr.cx, tr.cy, tr.cz),
+                            tr.cls, tr.index);
+        thr = prune_bound(best.d2, slack);
+        node = nr.skip;
+      } else {
+        node = node + 1;
+      }
+    }
+  }
+
+  bool negate = false;
+  if (MODE == MODE_UNSIGNED) {
+    if (SIGN == SIGN_GRID_PLANE) {
+      const size_t w = ((size_t)vox.x * g.n[1] + vox.y) * g.nzw + (vox.z >> 5);
+      negate = (plane[w] >> (vox.z & 31u)) & 1u;                       // grid.rs:630-636
+    } else if (SIGN == SIGN_RAYS3) {
+      const uint32_t cx = stab_count<0>(mesh, p), cy = stab_count<1>(mesh, p), cz = stab_count<2>(mesh, p);
+      negate = ((cx & 1u) + (cy & 1u) + (cz & 1u)) > 1u;               // bvh.rs:131-141, rtree_bvh.rs:161-171
+    }
+  }
+  if (MODE == MODE_NORMAL_FOLD && best.nan) atomicOr(err, ERRF_NAN);
+  if (store) out[out_index] = finish<MODE>(best, negate);
+}
+
+// ---- k_brute --------------------------------------------------------------------------------
+template <bool GRID, int MODE, int SIGN>
+__global__ __launch_bounds__(256) void k_brute(DeviceMesh mesh, GridParams g, const float* __restrict__ queries,
+                                               uint32_t n_q, const uint32_t* __restrict__ plane,
+                                               float* __restrict__ out, int* __restrict__ err, uint32_t n_packets) {
+  __shared__ TriRec tile[TILE];
+  const int lane = threadIdx.x & 63;
+  const uint32_t packet = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const bool active = packet < n_packets;
+
+  f3 p = {0, 0, 0};
+  size_t out_index = 0;
+  bool store = false;
+  GridBrick vox{};
+  if (active) {
+    if (GRID) {
+      vox = grid_lane_voxel(g, packet, lane);
+      p = grid_point(g, vox);
+      out_index = ((size_t)vox.x * g.n[1] + vox.y) * g.n[2] + vox.z - (size_t)g.out_off;
+      store = vox.in_range;
+    } else {
+      const uint32_t i = min(packet * 64u + lane, n_q - 1);
+      p = mk3(queries[3 * (size_t)i], queries[3 * (size_t)i + 1], queries[3 * (size_t)i + 2]);
+      out_index = i;
+      store = packet * 64u + lane < n_q;
+    }
+  }
+
+  Best<MODE> best;
+  uint32_t hits[3] = {0, 0, 0};
+  for (uint32_t t0 = 0; t0 < mesh.n_tris; t0 += TILE) {
+    const uint32_t nt = min((uint32_t)TILE, mesh.n_tris - t0);
+    __syncthreads();
+    {  // 128 records x 64 B = 512 float4; 256 threads x 2
+      const float4* src = reinterpret_cast<const float4*>(mesh.tris + t0);
+      float4* dst = reinterpret_cast<float4*>(tile);
+      for (uint32_t i = threadIdx.x; i < nt * 4; i += 256) dst[i] = src[i];
+    }
+    __syncthreads();
+    for (uint32_t k = 0; k < nt; ++k) {
+      const TriRec& tr = tile[k];
+      const f3 a = mk3(tr.ax, tr.ay, tr.az), b = mk3(tr.bx, tr.by, tr.bz), c = mk3(tr.cx, tr.cy, tr.cz);
+      eval_triangle<MODE>(best, p, a, b, c, tr.cls, tr.index);
+      if (MODE == MODE_UNSIGNED && SIGN == SIGN_XRAY_ALL) {
+        float t;
+        hits[0] += ray_triangle_aligned<0>(p, a, b, c, &t) ? 1u : 0u;   // default.rs:35-37: every triangle
+      }
+      if (MODE == MODE_UNSIGNED && SIGN == SIGN_RAYS3) {
+        f3 mn, mx;
+        triangle_bounding_box(a, b, c, &mn, &mx);
+        float t;
+        hits[0] += (ray_meets_box<0>(p, mn, mx) & ray_triangle_aligned<0>(p, a, b, c, &t)) ? 1u : 0u;
+        hits[1] += (ray_meets_box<1>(p, mn, mx) & ray_triangle_aligned<1>(p, a, b, c, &t)) ? 1u : 0u;
+        hits[2] += (ray_meets_box<2>(p, mn, mx) & ray_triangle_aligned<2>(p, a, b, c, &t)) ? 1u : 0u;
+      }
+    }
+  }
+
+  bool negate = false;
+  if (MODE == MODE_UNSIGNED) {
+    if (SIGN == SIGN_GRID_PLANE && active) {
+      const size_t w = ((size_t)vox.x * g.n[1] + vox.y) * g.nzw + (vox.z >> 5);
+      negate = (plane[w] >> (vox.z & 31u)) & 1u;
+    } else if (SIGN == SIGN_XRAY_ALL) {
+      negate = hits[0] & 1u;                                            // default.rs:65-72
+    } else if (SIGN == SIGN_RAYS3) {
+      negate = ((hits[0] & 1u) + (hits[1] & 1u) + (hits[2] & 1u)) > 1u;
+    }
+  }
+  if (MODE == MODE_NORMAL_FOLD && best.nan && store) atomicOr(err, ERRF_NAN);
+  if (store) out[out_index] = finish<MODE>(best, negate);
+}
+
+// ---- query ordering (generic path): Morton sort so that a packet is spatially compact ---------
+__device__ __forceinline__ int ordf(float f) {
+  int i = __float_as_int(f);
+  return i >= 0 ? i : i ^ 0x7fffffff;
+}
+__device__ __forceinline__ float unordf(int i) { return __int_as_float(i >= 0 ? i : i ^ 0x7fffffff); }
+
+__global__ void k_qbounds_init(int* b) {
+  if (threadIdx.x < 3) b[threadIdx.x] = INT32_MAX;
+  else if (threadIdx.x < 6) b[threadIdx.x] = INT32_MIN;
+}
+__global__ __launch_bounds__(256) void k_qbounds(const float* __restrict__ q, uint32_t n_q, int* __restrict__ b) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  int lo[3] = {INT32_MAX, INT32_MAX, INT32_MAX}, hi[3] = {INT32_MIN, INT32_MIN, INT32_MIN};
+  if (i < n_q)
+    for (int k = 0; k < 3; ++k) {
+      const float v = q[3 * (size_t)i + k];
+      if (v == v && fabsf(v) < 3.0e38f) { lo[k] = ordf(v); hi[k] = lo[k]; }
+    }
+  for (int k = 0; k < 3; ++k) {
+    int l = lo[k], h = hi[k];
+    for (int off = 32; off > 0; off >>= 1) { l = min(l, __shfl_xor(l, off)); h = max(h, __shfl_xor(h, off)); }
+    if ((threadIdx.x & 63) == 0) {
+      if (l != INT32_MAX) atomicMin(&b[k], l);
+      if (h != INT32_MIN) atomicMax(&b[3 + k], h);
+    }
+  }
+}
+__device__ __forceinline__ uint64_t expand21q(uint32_t v) {
+  uint64_t x = v & 0x1fffffu;
+  x = (x | x << 32) & 0x1f00000000ffffull;
+  x = (x | x << 16) & 0x1f0000ff0000ffull;
+  x = (x | x << 8) & 0x100f00f00f00f00full;
+  x = (x | x << 4) & 0x10c30c30c30c30c3ull;
+  x = (x | x << 2) & 0x1249249249249249ull;
+  return x;
+}
+__global__ __launch_bounds__(256) void k_qkeys(const float* __restrict__ q, uint32_t n_q, const int* __restrict__ b,
+                                               uint64_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_q) return;
+  uint32_t c[3];
+  for (int k = 0; k < 3; ++k) {
+    const float lo = unordf(b[k]), hi = unordf(b[3 + k]);
+    float u = (q[3 * (size_t)i + k] - lo) / (hi - lo);
+    u = (u == u) ? fminf(fmaxf(u, 0.0f), 1.0f) : 0.0f;
+    c[k] = min((uint32_t)(u * 2097152.0f), 2097151u);
+  }
+  keys[i] = (expand21q(c[0]) << 2) | (expand21q(c[1]) << 1) | expand21q(c[2]);
+  vals[i] = i;
+}
+__global__ __launch_bounds__(256) void k_qgather(const float* __restrict__ q, const uint32_t* __restrict__ perm,
+                                                 uint32_t n_q, float4* __restrict__ sorted) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_q) return;
+  const size_t s = perm[i];
+  sorted[i] = make_float4(q[3 * s], q[3 * s + 1], q[3 * s + 2], 0.0f);
+}
+
+template <bool GRID, int MODE, int SIGN>
+void launch_packet(hipStream_t st, const DeviceMesh& mesh, const GridParams& g, const float4* qs, const uint32_t* perm,
+                   uint32_t n_q, const uint32_t* plane, float* out, int* err, uint32_t n_packets) {
+  const uint32_t blocks = (n_packets + 3) / 4;
+  const uint32_t chunk = (blocks + 7) / 8;
+  hipLaunchKernelGGL((k_packet<GRID, MODE, SIGN>), dim3(chunk * 8), dim3(256), 0, st, mesh, g, qs, perm, n_q, plane, out,
+                     err, n_packets, chunk);
+}
+template <bool GRID, int MODE, int SIGN>
+void launch_brute(hipStream_t st, const DeviceMesh& mesh, const GridParams& g, const float* q, uint32_t n_q,
+                  const uint32_t* plane, float* out, int* err, uint32_t n_packets) {
+  hipLaunchKernelGGL((k_brute<GRID, MODE, SIGN>), dim3((n_packets + 3) / 4), dim3(256), 0, st, mesh, g, q, n_q, plane,
+                     out, err, n_packets);
+}
+
+uint32_t host_brick_count(const GridParams& g) {
+  return ((g.xe - g.xb + 3) >> 2) * ((g.n[1] + 3) >> 2) * ((g.n[2] + 3) >> 2);
+}
+
+}  // namespace
+
+int launch_grid_distance(hipStream_t st, const DeviceMesh& mesh, const GridParams& g, int mode,
+                         const uint32_t* d_inside_plane, int algorithm, float* d_out, int* d_err) {
+  if (g.xe <= g.xb || g.n[1] == 0 || g.n[2] == 0) return 0;
+  const uint32_t packets = host_brick_count(g);
+  const bool brute = algorithm == 1;
+  if (mode == MODE_UNSIGNED && d_inside_plane) {
+    if (brute) launch_brute<true, MODE_UNSIGNED, SIGN_GRID_PLANE>(st, mesh, g, nullptr, 0, d_inside_plane, d_out, d_err, packets);
+    else launch_packet<true, MODE_UNSIGNED, SIGN_GRID_PLANE>(st, mesh, g, nullptr, nullptr, 0, d_inside_plane, d_out, d_err, packets);
+  } else if (mode == MODE_UNSIGNED) {
+    if (brute) launch_brute<true, MODE_UNSIGNED, SIGN_NONE>(st, mesh, g, nullptr, 0, nullptr, d_out, d_err, packets);
+    else launch_packet<true, MODE_UNSIGNED, SIGN_NONE>(st, mesh, g, nullptr, nullptr, 0, nullptr, d_out, d_err, packets);
+  } else {
+    if (brute) launch_brute<true, MODE_NORMAL_FOLD, SIGN_NONE>(st, mesh, g, nullptr, 0, nullptr, d_out, d_err, packets);
+    else launch_packet<true, MODE_NORMAL_FOLD, SIGN_NONE>(st, mesh, g, nullptr, nullptr, 0, nullptr, d_out, d_err, packets);
+  }
+  M2S_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+size_t query_workspace_bytes(size_t n_q) {
+  size_t n = n_q ? n_q : 1, tmp = 0;
+  (void)rocprim::radix_sort_pairs(nullptr, tmp, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr,
+                            n, 0, 64, (hipStream_t)0);
+  return n * (8 + 8 + 4 + 4 + 16) + tmp + 16 * 256;
+}
+
+int launch_query_distance(Arena& ws, hipStream_t st, const DeviceMesh& mesh, const float* d_queries, size_t n_q,
+                          int mode, int sign_src, int algorithm, float* d_out, int* d_err) {
+  if (n_q == 0) return 0;
+  GridParams g{};
+  const uint32_t nq = (uint32_t)n_q;
+  const uint32_t packets = (nq + 63) / 64;
+  if (algorithm == 1) {
+    if (mode == MODE_UNSIGNED && sign_src == SIGN_XRAY_ALL) launch_brute<false, MODE_UNSIGNED, SIGN_XRAY_ALL>(st, mesh, g, d_queries, nq, nullptr, d_out, d_err, packets);
+    else if (mode == MODE_UNSIGNED && sign_src == SIGN_RAYS3) launch_brute<false, MODE_UNSIGNED, SIGN_RAYS3>(st, mesh, g, d_queries, nq, nullptr, d_out, d_err, packets);
+    else if (mode == MODE_UNSIGNED) launch_brute<false, MODE_UNSIGNED, SIGN_NONE>(st, mesh, g, d_queries, nq, nullptr, d_out, d_err, packets);
+    else if (mode == MODE_NORMAL_FOLD) launch_brute<false, MODE_NORMAL_FOLD, SIGN_NONE>(st, mesh, g, d_queries, nq, nullptr, d_out, d_err, packets);
+    else launch_brute<false, MODE_NEAREST_NORMAL, SIGN_NONE>(st, mesh, g, d_queries, nq, nullptr, d_out, d_err, packets);
+    M2S_HIP_CHECK(hipGetLastError());
+    return 0;
+  }
+  // Morton order
+  int* qb = ws.take<int>(8);
+  uint64_t* keys = ws.take<uint64_t>(n_q);
+  uint64_t* keys2 = ws.take<uint64_t>(n_q);
+  uint32_t* vals = ws.take<uint32_t>(n_q);
+  uint32_t* perm = ws.take<uint32_t>(n_q);
+  float4* sorted = ws.take<float4>(n_q);
+  size_t tmp_bytes = 0;
+  (void)rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys, keys2, vals, perm, n_q, 0, 64, st);
+  void* tmp = ws.take<char>(tmp_bytes ? tmp_bytes : 1);
+  if (!qb || !keys || !keys2 || !vals || !perm || !sorted || !tmp) {
+    set_error("internal: query workspace too small");
+    return M2S_ERR_HIP_INTERNAL;
+  }
+  const unsigned B = 256, nb = (nq + B - 1) / B;
+  hipLaunchKernelGGL(k_qbounds_init, dim3(1), dim3(64), 0, st, qb);
+  hipLaunchKernelGGL(k_qbounds, dim3(nb), dim3(B), 0, st, d_queries, nq, qb);
+  hipLaunchKernelGGL(k_qkeys, dim3(nb), dim3(B), 0, st, d_queries, nq, qb, keys, vals);
+  M2S_HIP_CHECK(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, keys2, vals, perm, n_q, 0, 63, st));
+  hipLaunchKernelGGL(k_qgather, dim3(nb), dim3(B), 0, st, d_queries, perm, nq, sorted);
+  if (mode == MODE_UNSIGNED && sign_src == SIGN_RAYS3) launch_packet<false, MODE_UNSIGNED, SIGN_RAYS3>(st, mesh, g, sorted, perm, nq, nullptr, d_out, d_err, packets);
+  else if (mode == MODE_UNSIGNED) launch_packet<false, MODE_UNSIGNED, SIGN_NONE>(st, mesh, g, sorted, perm, nq, nullptr, d_out, d_err, packets);
+  else if (mode == MODE_NORMAL_FOLD) launch_packet<false, MODE_NORMAL_FOLD, SIGN_NONE>(st, mesh, g, sorted, perm, nq, nullptr, d_out, d_err, packets);
+  else launch_packet<false, MODE_NEAREST_NORMAL, SIGN_NONE>(st, mesh, g, sorted, perm, nq, nullptr, d_out, d_err, packets);
+  M2S_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+}  // namespace m2s

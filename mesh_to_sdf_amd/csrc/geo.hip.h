@@ -1,0 +1,202 @@
+// geo.hip.h — device restatement of the reference's f32 geometry for gfx950 (wave64).
+//
+// Numerics contract: every expression that reaches the output is IEEE
+// binary32 in the reference's operation order with NO fused multiply-add: this TU is compiled
+// with -ffp-contract=off and the pragma below; `/` and sqrtf are the correctly rounded forms
+// (hipcc default).  Where an FMA is wanted (conservative bounds only) it is written explicitly
+// as __builtin_fmaf, which -ffp-contract=off does not touch.
+//
+// The code is written select-style instead of the reference's early returns so that the 64
+// lanes of a wave, which all test the SAME triangle against 64 DIFFERENT points, never diverge;
+// the predicates and the arithmetic feeding each result are those of geo.rs.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#pragma clang fp contract(off)
+
+namespace m2s {
+
+struct f3 {
+  float x, y, z;
+};
+
+__device__ __forceinline__ f3 mk3(float x, float y, float z) { return {x, y, z}; }
+// point.rs:81-141 — operation order matters (x*x' + y*y' + z*z', left to right)
+__device__ __forceinline__ f3 add3(f3 a, f3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ f3 sub3(f3 a, f3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ float dot3(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ f3 cross3(f3 a, f3 b) {
+  return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+__device__ __forceinline__ f3 fmul3(f3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
+__device__ __forceinline__ f3 sel3(bool c, f3 a, f3 b) { return {c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z}; }
+__device__ __forceinline__ bool eq3(f3 a, f3 b) { return a.x == b.x && a.y == b.y && a.z == b.z; }
+
+// Triangle degeneracy class, decided once per triangle on the host side of the kernel
+// (geo.rs:73-88: the match on (a==b, b==c, a==c)).
+enum : uint32_t {
+  TRI_REGULAR = 0,
+  TRI_POINT = 1,   // a == b == c            -> closest point is a                     geo.rs:74-76
+  TRI_SEG_AC = 2,  // a == b                 -> closest_point_segment(p, a, c)         geo.rs:77-79
+  TRI_SEG_AB = 3,  // b == c  or  a == c     -> closest_point_segment(p, a, b)         geo.rs:80-85
+};
+__device__ __forceinline__ uint32_t tri_class(f3 a, f3 b, f3 c) {
+  const bool ab = eq3(a, b), bc = eq3(b, c), ac = eq3(a, c);
+  if (ab && bc && ac) return TRI_POINT;
+  if (ab) return TRI_SEG_AC;
+  if (bc || ac) return TRI_SEG_AB;
+  return TRI_REGULAR;
+}
+
+// geo.rs:141-151
+__device__ __forceinline__ f3 closest_point_segment(f3 p, f3 a, f3 b) {
+  f3 ab = sub3(b, a);
+  float m = dot3(ab, ab);
+  f3 ap = sub3(p, a);
+  float s12 = dot3(ab, ap) / m;
+  s12 = (s12 < 0.0f) ? 0.0f : ((s12 > 1.0f) ? 1.0f : s12);  // f32::clamp, NaN passes through
+  return add3(a, fmul3(ab, s12));
+}
+
+// geo.rs:90-137 for a non-degenerate-class triangle.  One IEEE division per call, as in the
+// reference (each region divides once; the numerator / denominator pair is selected first).
+__device__ __forceinline__ f3 closest_point_regular(f3 p, f3 a, f3 b, f3 c) {
+  const f3 ab = sub3(b, a);
+  const f3 ac = sub3(c, a);
+  const f3 ap = sub3(p, a);
+  const float d1 = dot3(ab, ap);
+  const float d2 = dot3(ac, ap);
+  const f3 bp = sub3(p, b);
+  const float d3 = dot3(ab, bp);
+  const float d4 = dot3(ac, bp);
+  const f3 cp = sub3(p, c);
+  const float d5 = dot3(ab, cp);
+  const float d6 = dot3(ac, cp);
+
+  const bool rA = (d1 <= 0.0f) & (d2 <= 0.0f);                       // geo.rs:97
+  const bool rB = (d3 >= 0.0f) & (d4 <= d3);                         // geo.rs:104
+  const bool rC = (d6 >= 0.0f) & (d5 <= d6);                         // geo.rs:111
+  const float vc = d1 * d4 - d3 * d2;                                // geo.rs:115
+  const bool rAB = (vc <= 0.0f) & (d1 >= 0.0f) & (d3 <= 0.0f);       // geo.rs:116
+  const float vb = d5 * d2 - d1 * d6;                                // geo.rs:121
+  const bool rAC = (vb <= 0.0f) & (d2 >= 0.0f) & (d6 <= 0.0f);       // geo.rs:122
+  const float va = d3 * d6 - d5 * d4;                                // geo.rs:127
+  const float d43 = d4 - d3;
+  const float d56 = d5 - d6;
+  const bool rBC = (va <= 0.0f) & (d43 >= 0.0f) & (d56 >= 0.0f);     // geo.rs:128
+
+  // numerator / denominator of the single division of the region that fires first
+  //   AB: d1/(d1-d3)   AC: d2/(d2-d6)   BC: (d4-d3)/((d4-d3)+(d5-d6))   interior: 1/(va+vb+vc)
+  float num = 1.0f, den = va + vb + vc;
+  f3 base = a, dir = ab;
+  if (rBC) { num = d43; den = d43 + d56; base = b; dir = sub3(c, b); }
+  if (rAC) { num = d2; den = d2 - d6; base = a; dir = ac; }
+  if (rAB) { num = d1; den = d1 - d3; base = a; dir = ab; }
+  const float r = num / den;
+  const bool edge = rAB | rAC | rBC;
+  const float s = edge ? r : vb * r;                                 // interior: v = vb * denom
+  f3 q = add3(base, fmul3(dir, s));                                  // a + ab*v   (geo.rs:118/124/131/137)
+  const float w = vc * r;                                            // interior: w = vc * denom
+  const f3 qi = add3(q, fmul3(ac, w));                               // (a + ab*v) + ac*w
+  q = sel3(edge, q, qi);
+  q = sel3(rC, c, q);
+  q = sel3(rB, b, q);
+  q = sel3(rA, a, q);
+  return q;
+}
+
+// Closest point for any triangle class (cls is wave-uniform: one triangle per wave step).
+__device__ __forceinline__ f3 closest_point_triangle(f3 p, f3 a, f3 b, f3 c, uint32_t cls) {
+  if (cls == TRI_REGULAR) return closest_point_regular(p, a, b, c);
+  if (cls == TRI_POINT) return a;
+  if (cls == TRI_SEG_AC) return closest_point_segment(p, a, c);
+  return closest_point_segment(p, a, b);
+}
+
+// geo.rs:33-37 — squared distance dot(p-n, p-n).  sqrt is monotone, so the minimum over
+// triangles of geo.rs:26-30's sqrt(dot) is sqrt(min dot): kernels minimise d2 and take ONE
+// correctly rounded sqrt at the end, which gives the identical f32.
+__device__ __forceinline__ float point_triangle_dist2(f3 p, f3 a, f3 b, f3 c, uint32_t cls) {
+  const f3 n = closest_point_triangle(p, a, b, c, cls);
+  const f3 d = sub3(p, n);
+  return dot3(d, d);
+}
+
+// geo.rs:43-56 — returns d2 and whether the reference's signed distance is positive
+// (direction . ((b-a) x (c-a)) > 0, normal not normalised; == 0 counts as negative).
+__device__ __forceinline__ float point_triangle_dist2_signed(f3 p, f3 a, f3 b, f3 c, uint32_t cls, bool* positive) {
+  const f3 n = closest_point_triangle(p, a, b, c, cls);
+  const f3 d = sub3(p, n);
+  const f3 nrm = cross3(sub3(b, a), sub3(c, a));
+  *positive = dot3(d, nrm) > 0.0f;
+  return dot3(d, d);
+}
+
+// geo.rs:165-216 — axis-aligned ray/triangle.  AXIS 0: ray +X, plane (y,z); 1: +Y, (z,x); 2: +Z, (x,y).
+template <int AXIS>
+__device__ __forceinline__ float gx_(f3 v) { return AXIS == 0 ? v.x : (AXIS == 1 ? v.y : v.z); }
+template <int AXIS>
+__device__ __forceinline__ float gy_(f3 v) { return AXIS == 0 ? v.y : (AXIS == 1 ? v.z : v.x); }
+template <int AXIS>
+__device__ __forceinline__ float gz_(f3 v) { return AXIS == 0 ? v.z : (AXIS == 1 ? v.x : v.y); }
+
+template <int AXIS>
+__device__ __forceinline__ bool ray_triangle_aligned(f3 o, f3 t0, f3 t1, f3 t2, float* t_out) {
+  const f3 e01 = sub3(t1, t0), e12 = sub3(t2, t1), e20 = sub3(t0, t2);
+  const f3 p0 = sub3(o, t0), p1 = sub3(o, t1), p2 = sub3(o, t2);
+  const float w0 = gz_<AXIS>(p1) * gy_<AXIS>(e12) - gy_<AXIS>(p1) * gz_<AXIS>(e12);  // geo.rs:199
+  const float w1 = gz_<AXIS>(p2) * gy_<AXIS>(e20) - gy_<AXIS>(p2) * gz_<AXIS>(e20);  // geo.rs:200
+  const float w2 = gz_<AXIS>(p0) * gy_<AXIS>(e01) - gy_<AXIS>(p0) * gz_<AXIS>(e01);  // geo.rs:201
+  const bool inside = ((w0 < 0.0f) & (w1 < 0.0f) & (w2 < 0.0f)) | ((w0 > 0.0f) & (w1 > 0.0f) & (w2 > 0.0f));  // :203
+  const float t = -(w0 * gx_<AXIS>(p0) + w2 * gx_<AXIS>(p2) + w1 * gx_<AXIS>(p1)) / (w0 + w1 + w2);           // :208
+  *t_out = t;
+  return inside & (t > 0.0f);                                                                                 // :210
+}
+__device__ __forceinline__ bool ray_triangle_aligned_rt(int axis, f3 o, f3 t0, f3 t1, f3 t2, float* t_out) {
+  if (axis == 0) return ray_triangle_aligned<0>(o, t0, t1, t2, t_out);
+  if (axis == 1) return ray_triangle_aligned<1>(o, t0, t1, t2, t_out);
+  return ray_triangle_aligned<2>(o, t0, t1, t2, t_out);
+}
+
+// geo.rs:4-22 — triangle AABB padded by 1e-4 (f32::min/max: a NaN operand is dropped)
+__device__ __forceinline__ void triangle_bounding_box(f3 a, f3 b, f3 c, f3* mn, f3* mx) {
+  const float e = 0.0001f;
+  *mn = {fminf(a.x, fminf(b.x, c.x)) - e, fminf(a.y, fminf(b.y, c.y)) - e, fminf(a.z, fminf(b.z, c.z)) - e};
+  *mx = {fmaxf(a.x, fmaxf(b.x, c.x)) + e, fmaxf(a.y, fmaxf(b.y, c.y)) + e, fmaxf(a.z, fmaxf(b.z, c.z)) + e};
+}
+
+// Candidate rule of bvh::traverse for an axis-aligned ray (closed padded box, see oracle).
+template <int AXIS>
+__device__ __forceinline__ bool ray_meets_box(f3 o, f3 mn, f3 mx) {
+  return (gy_<AXIS>(o) >= gy_<AXIS>(mn)) & (gy_<AXIS>(o) <= gy_<AXIS>(mx)) & (gz_<AXIS>(o) >= gz_<AXIS>(mn)) &
+         (gz_<AXIS>(o) <= gz_<AXIS>(mx)) & (gx_<AXIS>(mx) >= gx_<AXIS>(o));
+}
+
+// float-cmp approx_eq!(f32, a, b, ulps = 2, epsilon = 1e-6) for non-negative a, b (lib.rs:248)
+__device__ __forceinline__ bool approx_eq_abs(float a, float b) {
+  if (a == b) return true;
+  if (fabsf(a - b) <= 1e-6f) return true;
+  const int32_t d = (int32_t)((uint32_t)__float_as_int(a) - (uint32_t)__float_as_int(b));
+  const int32_t ad = d == INT32_MIN ? INT32_MAX : (d < 0 ? -d : d);
+  return ad <= 2;
+}
+
+// Final value of the compare_distances fold (lib.rs:242-259 applied as in default.rs:52-59)
+// from the two running minima the kernels keep: min d2 over all triangles and min d2 over the
+// triangles whose signed distance is positive.  With dmin = min|d| and P = {positive d with
+// approx_eq(|d|, dmin)} the fold returns min(P) if P is non-empty, else -dmin
+// (tests/test_oracle_fast.py::test_normal_fold_closed_form).
+__device__ __forceinline__ float normal_fold_result(float d2_all, float d2_pos) {
+  const float f32max = 3.402823466e+38f;
+  const float dall = sqrtf(d2_all);
+  const float dpos = sqrtf(d2_pos);
+  if (!(d2_all < __builtin_inff())) return f32max;     // nothing finite seen: the fold keeps f32::MAX
+  if (d2_pos < __builtin_inff() && approx_eq_abs(dpos, dall)) return dpos;
+  return -dall;
+}
+
+// Grid::get_cell_center for one axis (grid.rs:135-141): first + (i as f32) * size, mul then add.
+__device__ __forceinline__ float cell_center(float first, float size, uint32_t i) { return first + (float)i * size; }
+
+}  // namespace m2s

@@ -1,0 +1,217 @@
+// sign.hip — SignMethod::Raycast for the grid path (generate/grid.rs:568-684), gfx950.
+//
+// Reference rule: for every grid line along +X, +Y, +Z (origin = centre of cell 0 of the line,
+// grid.rs:570,648-684) every triangle hit with t > 0 (geo.rs:165-216) increments the cells
+// 0..=k of that line, k = min(floor(t / cell_size[axis]) as usize, n_axis - 1) (grid.rs:605-617);
+// a cell is inside iff at least two of its three per-axis counts are odd (grid.rs:622-639).
+//
+// Restated for the GPU as bit planes in the grid's own layout (bit z of word (x*ny + y)*nzw + z/32):
+//   k_ray_mark : TRIANGLE-parallel.  Each triangle visits only the grid lines whose cell-0 centre
+//                lies in its 1e-4-padded box (exactly the candidates bvh.traverse hands the
+//                reference), runs the exact ray test and XORs ONE marker bit at bucket k.
+//   k_scan_x/y : suffix XOR of the markers along x / y  ==  parity of "increment cells 0..=k".
+//   k_scan_z_combine : suffix XOR along z inside the words, then majority of the three planes.
+// Work is O(T * lines-per-triangle + N^3 / 32) instead of O(N^2 log T + hits * N) atomics.
+#include "common.h"
+#include "geo.hip.h"
+
+namespace m2s {
+
+namespace {
+
+constexpr int SMALL_WINDOW = 32;  // lines a lane handles alone; larger windows are spread over the wave
+
+struct Window {
+  uint32_t ulo, uhi, wlo, whi;  // inclusive index ranges on the two free axes; empty if ulo > uhi
+};
+
+__device__ __forceinline__ void axis_range(float bmn, float bmx, float first, float cs, uint32_t n, uint32_t* lo,
+                                           uint32_t* hi) {
+  // conservative index range of cells whose centre first + i*cs can lie in [bmn, bmx]
+  float i0 = (bmn - first) / cs, i1 = (bmx - first) / cs;
+  if (i0 > i1) { float t = i0; i0 = i1; i1 = t; }
+  const bool bad = !(i0 == i0) || !(i1 == i1) || !(fabsf(i0) < 3.0e38f) || !(fabsf(i1) < 3.0e38f);
+  if (bad) { *lo = 0; *hi = n - 1; return; }
+  const float l = floorf(i0) - 1.0f, h = ceilf(i1) + 1.0f;
+  if (h < 0.0f || l > (float)(n - 1)) { *lo = 1; *hi = 0; return; }
+  *lo = l < 0.0f ? 0u : (uint32_t)l;
+  *hi = h >= (float)(n - 1) ? n - 1 : (uint32_t)h;
+}
+
+template <int AXIS>
+struct FreeAxes {
+  static constexpr int U = AXIS == 0 ? 1 : 0;
+  static constexpr int W = AXIS == 2 ? 1 : 2;
+};
+
+template <int AXIS>
+__device__ __forceinline__ Window make_window(f3 mn, f3 mx, const GridParams& g) {
+  constexpr int U = FreeAxes<AXIS>::U, W = FreeAxes<AXIS>::W;
+  const float bmn[3] = {mn.x, mn.y, mn.z}, bmx[3] = {mx.x, mx.y, mx.z};
+  Window w;
+  axis_range(bmn[U], bmx[U], g.first[U], g.size[U], g.n[U], &w.ulo, &w.uhi);
+  axis_range(bmn[W], bmx[W], g.first[W], g.size[W], g.n[W], &w.wlo, &w.whi);
+  if (w.wlo > w.whi) { w.ulo = 1; w.uhi = 0; }
+  return w;
+}
+__device__ __forceinline__ uint32_t window_count(const Window& w) {
+  return w.ulo > w.uhi ? 0u : (w.uhi - w.ulo + 1u) * (w.whi - w.wlo + 1u);
+}
+
+// One grid line (free-axis cell iu, iw) against one triangle.
+template <int AXIS>
+__device__ __forceinline__ void mark_line(f3 a, f3 b, f3 c, f3 mn, f3 mx, const GridParams& g, uint32_t iu,
+                                          uint32_t iw, uint32_t* __restrict__ plane) {
+  constexpr int U = FreeAxes<AXIS>::U, W = FreeAxes<AXIS>::W;
+  uint32_t cell[3];
+  cell[AXIS] = 0; cell[U] = iu; cell[W] = iw;
+  const f3 o = {cell_center(g.first[0], g.size[0], cell[0]), cell_center(g.first[1], g.size[1], cell[1]),
+                cell_center(g.first[2], g.size[2], cell[2])};                     // grid.rs:570
+  if (!ray_meets_box<AXIS>(o, mn, mx)) return;                                   // bvh.traverse candidate rule
+  float t;
+  if (!ray_triangle_aligned<AXIS>(o, a, b, c, &t)) return;                       // grid.rs:601-603
+  const float f = floorf(t / g.size[AXIS]);                                      // grid.rs:605-606
+  const uint32_t n = g.n[AXIS];
+  uint32_t k = 0;                                                                // `as usize` saturates, NaN -> 0
+  if (f == f && f > 0.0f) k = f >= (float)n ? n - 1 : min((uint32_t)f, n - 1);   // .min(n - 1), grid.rs:607
+  cell[AXIS] = k;
+  const size_t word = ((size_t)cell[0] * g.n[1] + cell[1]) * g.nzw + (cell[2] >> 5);
+  atomicXor(&plane[word], 1u << (cell[2] & 31u));
+}
+
+template <int AXIS>
+__device__ __forceinline__ void mark_axis(bool valid, f3 a, f3 b, f3 c, f3 mn, f3 mx, const GridParams& g,
+                                          uint32_t* __restrict__ plane) {
+  Window w = {1, 0, 1, 0};
+  if (valid) w = make_window<AXIS>(mn, mx, g);
+  const uint32_t cnt = window_count(w);
+  const bool small = cnt <= SMALL_WINDOW;
+  if (small) {
+    for (uint32_t iu = w.ulo; iu <= w.uhi && cnt; ++iu)
+      for (uint32_t iw = w.wlo; iw <= w.whi; ++iw) mark_line<AXIS>(a, b, c, mn, mx, g, iu, iw, plane);
+  }
+  // windows too large for one lane: the whole wave walks them, one owner lane at a time
+  unsigned long long big = __ballot(!small);
+  const int lane = threadIdx.x & 63;
+  while (big) {
+    const int src = __ffsll((long long)big) - 1;
+    big &= big - 1;
+    const f3 sa = {__shfl(a.x, src), __shfl(a.y, src), __shfl(a.z, src)};
+    const f3 sb = {__shfl(b.x, src), __shfl(b.y, src), __shfl(b.z, src)};
+    const f3 sc = {__shfl(c.x, src), __shfl(c.y, src), __shfl(c.z, src)};
+    const f3 smn = {__shfl(mn.x, src), __shfl(mn.y, src), __shfl(mn.z, src)};
+    const f3 smx = {__shfl(mx.x, src), __shfl(mx.y, src), __shfl(mx.z, src)};
+    const uint32_t ulo = __shfl(w.ulo, src), uhi = __shfl(w.uhi, src), wlo = __shfl(w.wlo, src),
+                   whi = __shfl(w.whi, src);
+    const uint32_t nw = whi - wlo + 1u;
+    const uint64_t total = (uint64_t)(uhi - ulo + 1u) * nw;
+    for (uint64_t i = lane; i < total; i += 64)
+      mark_line<AXIS>(sa, sb, sc, smn, smx, g, ulo + (uint32_t)(i / nw), wlo + (uint32_t)(i % nw), plane);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_ray_mark(DeviceMesh mesh, GridParams g, uint32_t* __restrict__ px,
+                                                  uint32_t* __restrict__ py, uint32_t* __restrict__ pz) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool valid = t < mesh.n_tris;
+  f3 a = {0, 0, 0}, b = {0, 0, 0}, c = {0, 0, 0}, mn = {0, 0, 0}, mx = {0, 0, 0};
+  if (valid) {
+    const TriRec r = mesh.tris[t];
+    a = mk3(r.ax, r.ay, r.az);
+    b = mk3(r.bx, r.by, r.bz);
+    c = mk3(r.cx, r.cy, r.cz);
+    triangle_bounding_box(a, b, c, &mn, &mx);
+  }
+  mark_axis<0>(valid, a, b, c, mn, mx, g, px);
+  mark_axis<1>(valid, a, b, c, mn, mx, g, py);
+  mark_axis<2>(valid, a, b, c, mn, mx, g, pz);
+}
+
+// Suffix XOR along x: thread = one (y, zw) word column, walking x from nx-1 down to 0.
+__global__ __launch_bounds__(256) void k_scan_x(uint32_t* __restrict__ p, uint32_t nx, size_t row_words /*ny*nzw*/) {
+  const size_t col = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= row_words) return;
+  uint32_t run = 0;
+  int64_t x = (int64_t)nx - 1;
+  for (; x >= 7; x -= 8) {
+    uint32_t v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = p[(size_t)(x - k) * row_words + col];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { run ^= v[k]; p[(size_t)(x - k) * row_words + col] = run; }
+  }
+  for (; x >= 0; --x) { run ^= p[(size_t)x * row_words + col]; p[(size_t)x * row_words + col] = run; }
+}
+
+// Suffix XOR along y: thread = one (x, zw) pair.
+__global__ __launch_bounds__(256) void k_scan_y(uint32_t* __restrict__ p, uint32_t nx, uint32_t ny, uint32_t nzw) {
+  const size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (id >= (size_t)nx * nzw) return;
+  const size_t x = id / nzw, zw = id % nzw;
+  uint32_t* base = p + x * ny * nzw + zw;
+  uint32_t run = 0;
+  int64_t y = (int64_t)ny - 1;
+  for (; y >= 7; y -= 8) {
+    uint32_t v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = base[(size_t)(y - k) * nzw];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { run ^= v[k]; base[(size_t)(y - k) * nzw] = run; }
+  }
+  for (; y >= 0; --y) { run ^= base[(size_t)y * nzw]; base[(size_t)y * nzw] = run; }
+}
+
+// Suffix XOR along z inside each (x,y) row, then "at least two of three odd" (grid.rs:630-636).
+// The majority plane overwrites pz.
+__global__ __launch_bounds__(256) void k_scan_z_combine(const uint32_t* __restrict__ px, const uint32_t* __restrict__ py,
+                                                        uint32_t* __restrict__ pz, size_t rows, uint32_t nzw) {
+  const size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= rows) return;
+  uint32_t carry = 0;
+  for (int64_t zw = (int64_t)nzw - 1; zw >= 0; --zw) {
+    const size_t i = row * nzw + (size_t)zw;
+    uint32_t z = pz[i];
+    z ^= z >> 1; z ^= z >> 2; z ^= z >> 4; z ^= z >> 8; z ^= z >> 16;   // bit i = XOR of marker bits >= i
+    z ^= carry;
+    carry = (z & 1u) ? 0xffffffffu : 0u;
+    const uint32_t x = px[i], y = py[i];
+    pz[i] = (x & y) | (x & z) | (y & z);
+  }
+}
+
+}  // namespace
+
+size_t sign_workspace_bytes(const GridParams& g) {
+  return 3 * ((size_t)g.n[0] * g.n[1] * g.nzw * 4 + 256) + 1024;
+}
+
+int build_grid_sign_plane(Arena& ws, hipStream_t st, const DeviceMesh& mesh, const GridParams& g,
+                          const uint32_t** d_inside_plane) {
+  const size_t words = (size_t)g.n[0] * g.n[1] * g.nzw;
+  uint32_t* px = ws.take<uint32_t>(words);
+  uint32_t* py = ws.take<uint32_t>(words);
+  uint32_t* pz = ws.take<uint32_t>(words);
+  if (!px || !py || !pz) {
+    set_error("internal: sign workspace too small");
+    return M2S_ERR_HIP_INTERNAL;
+  }
+  *d_inside_plane = pz;
+  if (words == 0) return 0;
+  M2S_HIP_CHECK(hipMemsetAsync(px, 0, words * 4, st));
+  M2S_HIP_CHECK(hipMemsetAsync(py, 0, words * 4, st));
+  M2S_HIP_CHECK(hipMemsetAsync(pz, 0, words * 4, st));
+  const unsigned B = 256;
+  if (mesh.n_tris) {
+    hipLaunchKernelGGL(k_ray_mark, dim3((mesh.n_tris + B - 1) / B), dim3(B), 0, st, mesh, g, px, py, pz);
+    const size_t row_words = (size_t)g.n[1] * g.nzw;
+    hipLaunchKernelGGL(k_scan_x, dim3((unsigned)((row_words + B - 1) / B)), dim3(B), 0, st, px, g.n[0], row_words);
+    const size_t ycols = (size_t)g.n[0] * g.nzw;
+    hipLaunchKernelGGL(k_scan_y, dim3((unsigned)((ycols + B - 1) / B)), dim3(B), 0, st, py, g.n[0], g.n[1], g.nzw);
+    const size_t rows = (size_t)g.n[0] * g.n[1];
+    hipLaunchKernelGGL(k_scan_z_combine, dim3((unsigned)((rows + B - 1) / B)), dim3(B), 0, st, px, py, pz, rows, g.nzw);
+  }
+  M2S_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+}  // namespace m2s

@@ -400,7 +400,7 @@ int query_one(const Mesh& m, V3 q, int accel, int sign, float* out) {
   bool have = false;
   for (size_t t = 0; t < T; ++t) {
     float d2 = point_triangle_distance2(q, m.v(t, 0), m.v(t, 1), m.v(t, 2));
-    if (!have || d2 < best_d2) { best = t; best_d2 = d2; have = true; }
+    if (d2 == d2 && (!have || d2 < best_d2)) { best = t; best_d2 = d2; have = true; }  // a NaN distance_2 is never nearest
   }
   V3 a = m.v(best, 0), b = m.v(best, 1), c = m.v(best, 2);
   if (accel == 2) {
@@ -972,7 +972,7 @@ int query_one_fast(const Mesh& m, const CpuBvh& bvh, V3 q, int accel, int sign, 
   bvh.nearest(q, [&](uint32_t t) {
     V3 a = m.v(t, 0), b = m.v(t, 1), c = m.v(t, 2);
     float d2 = point_triangle_distance2(q, a, b, c);
-    if (!have || d2 < best_d2 || (d2 == best_d2 && t < best)) { have = true; best = t; best_d2 = d2; }
+    if (d2 == d2 && (!have || d2 < best_d2 || (d2 == best_d2 && t < best))) { have = true; best = t; best_d2 = d2; }
     return point_triangle_distance(q, a, b, c);
   });
   V3 a = m.v(best, 0), b = m.v(best, 1), c = m.v(best, 2);

@@ -1,0 +1,120 @@
+"""CPU-side checks of the C-ABI library: it loads, exports every symbol include/m2s.h declares,
+its host-side grid/topology helpers reproduce the reference arithmetic, and without a GPU the
+compute entry points fail loudly (there is no CPU fallback).  No GPU needed."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import oracle as orc
+from mesh_to_sdf_amd import _lib
+from mesh_to_sdf_amd import AccelerationMethod, Grid, M2SError, SignMethod, Topology, generate_grid_sdf, generate_sdf
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not os.path.exists(_lib.SO_PATH):
+        _lib.build()
+    return _lib.lib()
+
+
+def test_exports_match_header(lib):
+    hdr = open(os.path.join(ROOT, "include", "m2s.h")).read()
+    declared = set(re.findall(r"\b(m2s_[a-z_0-9]+)\s*\(", hdr))
+    assert declared == set(_lib.EXPORTS)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.m2s_version() == 1
+
+
+def test_struct_layout_matches_header(tmp_path):
+    # the ctypes mirrors must have the layout a C compiler gives the structs of m2s.h
+    import subprocess
+
+    src = tmp_path / "probe.c"
+    src.write_text(
+        '#include <stdio.h>\n#include <stddef.h>\n#include "m2s.h"\n'
+        'int main(void){printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(m2s_grid), sizeof(m2s_timings), sizeof(m2s_opts),'
+        ' offsetof(m2s_opts, x_begin), offsetof(m2s_opts, timings), offsetof(m2s_timings, n_units));return 0;}\n'
+    )
+    exe = tmp_path / "probe"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+    want = [C.sizeof(_lib.M2SGrid), C.sizeof(_lib.M2STimings), C.sizeof(_lib.M2SOpts), _lib.M2SOpts.x_begin.offset,
+            _lib.M2SOpts.timings.offset, _lib.M2STimings.n_units.offset]
+    assert got == want
+
+
+def test_grid_helpers_match_reference_arithmetic(lib):
+    rng = np.random.default_rng(0)
+    for _ in range(200):
+        mn = rng.uniform(-5, 5, 3).astype(np.float32)
+        mx = (mn + rng.uniform(0.1, 7, 3)).astype(np.float32)
+        cnt = rng.integers(1, 600, 3)
+        g = Grid.from_bounding_box(mn, mx, cnt)
+        first, size, _ = orc.grid_from_bounding_box(mn, mx, cnt)
+        assert np.array_equal(g.get_first_cell(), first) and np.array_equal(g.get_cell_size(), size)
+        cell = [int(rng.integers(0, c)) for c in cnt]
+        assert np.array_equal(g.get_cell_center(cell), orc.grid_cell_center(first, size, cnt, cell))
+        assert g.get_cell_idx(cell) == orc.grid_cell_idx(cnt, cell)
+        assert g.get_cell_integer_coordinates(g.get_cell_idx(cell)) == cell
+        p = rng.uniform(-6, 8, 3).astype(np.float32)
+        inside, c2 = orc.grid_snap(first, size, cnt, p)
+        assert g.snap_point_to_grid(p) == ("Inside" if inside else "Outside", c2)
+    # grid.rs:201-211, 282-297
+    g = Grid.from_bounding_box([-1.0, 0.0, 1.0], [0.0, 2.0, 5.0], [2, 2, 2])
+    assert g.get_first_cell().tolist() == [-0.75, 0.5, 2.0] and g.get_cell_size().tolist() == [0.5, 1.0, 2.0]
+    mn, mx = g.get_bounding_box()
+    assert mn.tolist() == [-1.0, 0.0, 1.0] and mx.tolist() == [0.0, 2.0, 5.0]
+    g = Grid.new([0.0, 1.0, 2.0], [1.0, 2.0, 3.0], [10, 20, 30])   # grid.rs:190-198
+    assert g.get_last_cell().tolist() == [10.0, 41.0, 92.0]
+
+
+def test_triangle_count(lib):
+    # lib.rs:175-193
+    for n in range(0, 12):
+        assert lib.m2s_triangle_count(99, n, 1, 0) == len(orc.get_triangles(99, list(range(n)), 0))
+        assert lib.m2s_triangle_count(99, n, 1, 1) == len(orc.get_triangles(99, list(range(n)), 1))
+        assert lib.m2s_triangle_count(n, 0, 0, 0) == len(orc.get_triangles(n, None, 0))
+        assert lib.m2s_triangle_count(n, 0, 0, 1) == len(orc.get_triangles(n, None, 1))
+
+
+def test_argument_errors_before_any_device_work(lib):
+    v = np.zeros((3, 3), np.float32)
+    with pytest.raises(M2SError) as e:
+        generate_sdf(v, Topology(7, None), v, AccelerationMethod.RtreeBvh)
+    assert e.value.code == _lib.ERR_BAD_ARG
+    with pytest.raises(M2SError) as e:
+        generate_sdf(v, Topology.TriangleList(None), v, AccelerationMethod(9))
+    assert e.value.code == _lib.ERR_BAD_ARG
+    # RtreeBvh on an empty mesh returns an empty vec (rtree_bvh.rs:104-106), Rtree panics (rtree.rs:117)
+    assert generate_sdf(np.zeros((0, 3), np.float32), Topology.TriangleList(None), v, AccelerationMethod.RtreeBvh).size == 0
+    with pytest.raises(M2SError) as e:
+        generate_sdf(np.zeros((0, 3), np.float32), Topology.TriangleList(None), v, AccelerationMethod.Rtree)
+    assert e.value.code == _lib.ERR_EMPTY_MESH
+    assert generate_sdf(v, Topology.TriangleList(None), np.zeros((0, 3), np.float32)).size == 0
+    assert generate_grid_sdf(v, Topology.TriangleList(None), Grid.new([0, 0, 0], [1, 1, 1], [0, 4, 4])).size == 0
+
+
+def test_no_gpu_means_loud_failure(lib):
+    if lib.m2s_device_count() > 0:
+        pytest.skip("a GPU is present")
+    v = np.array([[0.0, 1.0, 0.0], [1.0, 2.0, 3.0], [1.0, 3.0, 4.0]], np.float32)
+    with pytest.raises(M2SError) as e:
+        generate_sdf(v, Topology.TriangleList([0, 1, 2]), [[0.0, 0.0, 0.0]])
+    assert e.value.code == _lib.ERR_HIP and "no CPU fallback" in str(e.value)
+    with pytest.raises(M2SError):
+        generate_grid_sdf(v, Topology.TriangleList([0, 1, 2]), Grid.from_bounding_box([0, 0, 0], [1, 1, 1], [4, 4, 4]))
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "mesh_to_sdf_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp", "Makefile")):
+                txt = open(os.path.join(dp, f), errors="replace").read()
+                assert "import oracle" not in txt and "from oracle" not in txt and "m2s_oracle" not in txt, f
