@@ -1,0 +1,196 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of BASELINE.json: Mvoxels/s of generate_grid_sdf on a 512^3 grid,
+100k-triangle watertight mesh (blob-100k), SignMethod::Raycast, at N GPUs.
+
+One "step" = one complete generate_grid_sdf call through the C ABI with the mesh and the output
+resident in HBM (device pointers): topology flatten + LBVH build + sign planes + nearest-triangle
+kernel for this rank's x-slab, then the RCCL all-gather that leaves the full grid on every GPU.
+The work is FIXED as N grows (strong scaling): rank r computes cells x in [r*512/N, (r+1)*512/N).
+
+    python bench.py --gpus 1 --steps 10 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line.  `roofline` is the dominant kernel (k_packet, nearest triangle +
+fused sign) timed with HIP events on the stream it is launched on; `cpu_baseline` is the CPU
+oracle's multi-threaded restatement of the reference algorithm (oracle/, kind "port": the Rust
+reference cannot be built in this image) on a bounded sample, N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--grid", type=int, default=512)
+    ap.add_argument("--mesh", default="blob-100k")
+    ap.add_argument("--sign", default="Raycast", choices=["Raycast", "Normal"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=25.0, help="budget for the CPU baseline sample")
+    return ap.parse_args()
+
+
+def cpu_baseline(v, idx, lo, hi, sign, budget_s):
+    """Times the oracle's faithful multi-threaded restatement of generate/grid.rs:265-642 (one heap
+    per thread, like rayon::current_num_threads()) on the largest cubic sample of the SAME mesh and
+    bbox that fits the time budget."""
+    import oracle as orc
+    from mesh_to_sdf_amd import meshes
+
+    cores = orc.hardware_threads()
+
+    def run(n):
+        first, size, cnt = meshes.grid_from_bounding_box(lo, hi, [n, n, n])
+        t0 = time.perf_counter()
+        orc.generate_grid_sdf(v, idx, first, size, cnt, sign=sign, semantics=orc.PROPAGATE, heaps=cores, threads=cores)
+        return time.perf_counter() - t0
+
+    n, dt = 128, run(128)
+    rate = n ** 3 / dt
+    for cand in (256, 224, 192, 160):
+        if cand ** 3 / rate <= budget_s:
+            n, dt = cand, run(cand)
+            break
+    return {
+        "value": round(n ** 3 / dt / 1e6, 4),
+        "unit": "Mvoxels/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": f"{n}^3 grid (1/{(512 // n) ** 3 if 512 % n == 0 else round(512 ** 3 / n ** 3, 1)} of the voxels), same mesh and bbox, "
+                  f"C++ restatement of the reference's 3-phase propagation algorithm, {cores} threads, {dt:.2f} s",
+    }
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    from mesh_to_sdf_amd import Grid, M2STimings, SignMethod, Topology, generate_grid_sdf, meshes
+    from mesh_to_sdf_amd.distributed import generate_grid_sdf_sharded, slab_bounds
+
+    v, idx = meshes.named(args.mesh)
+    lo, hi = meshes.extended_bbox(v, 0.1)
+    n = args.grid
+    grid = Grid.from_bounding_box(lo, hi, [n, n, n])
+    sign = SignMethod[args.sign]
+    dv = torch.as_tensor(v, device=dev)
+    di = torch.as_tensor(idx.astype(np.int64), device=dev).to(torch.int32)
+    topo = Topology.TriangleList(di)
+    out = torch.empty(n ** 3, dtype=torch.float32, device=dev)
+    x0, x1 = slab_bounds(n, world, rank)
+
+    def step(t=None):
+        generate_grid_sdf_sharded(dv, topo, grid, sign, out=out, timings=t)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    tims = [M2STimings() for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(tims[k])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        elapsed = float(te.item())
+
+    if rank == 0:
+        ms_per_step = elapsed * 1e3 / args.steps
+        voxels = n ** 3
+        value = voxels * args.steps / elapsed / 1e6
+        dist_ms = float(np.mean([t.distance_ms for t in tims]))
+        build_ms = float(np.mean([t.accel_build_ms for t in tims]))
+        sign_ms = float(np.mean([t.sign_ms for t in tims]))
+        n_tris = int(tims[0].n_triangles)
+        slab_voxels = (x1 - x0) * n * n
+        # algorithmic bytes of one launch of the dominant kernel:
+        # 4 B per voxel written + the mesh read once (12 B per vertex + 12 B per triangle)
+        b_alg = 4.0 * slab_voxels + 12.0 * v.shape[0] + 12.0 * n_tris
+        achieved = b_alg / (dist_ms * 1e-3) / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("k_packet_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        res = {
+            "metric": "Mvoxels/s for generate_grid_sdf (512^3, 100k tris, Raycast)",
+            "value": round(value, 2),
+            "unit": "Mvoxels/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"generate_grid_sdf {n}^3 grid, {args.mesh} ({n_tris} tris, {v.shape[0]} verts), SignMethod::{args.sign}, "
+                            f"x-slab sharded over {world} GPU(s) + RCCL all-gather, inputs/outputs resident in HBM",
+                "grid": [n, n, n],
+                "mesh": args.mesh,
+                "sign_method": args.sign,
+                "parallelism": f"xslab{world}",
+            },
+            "phases_ms": {"accel_build": round(build_ms, 4), "sign_planes": round(sign_ms, 4), "distance": round(dist_ms, 4)},
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "k_packet<GRID, MODE_UNSIGNED, SIGN_GRID_PLANE>",
+                "achieved": round(achieved, 3),
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 6),
+                "traffic": traffic,
+                "algorithmic_bytes_per_launch": b_alg,
+                "avg_launch_ms": round(dist_ms, 4),
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(v, idx, lo, hi, int(sign), args.cpu_seconds)
+            # the PCIe-inclusive drop-in call (host pointers in/out), reported for DESIGN.md; never `value`
+            t1 = time.perf_counter()
+            generate_grid_sdf(v, Topology.TriangleList(idx), grid, sign)
+            res["host_pointer_call_ms"] = round((time.perf_counter() - t1) * 1e3, 2)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -84,6 +84,13 @@ def lib():
                 f"{SO_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(mesh_to_sdf_amd has no CPU fallback)"
             )
+        # torch ships its own libamdhip64.so (same SONAME, libamdhip64.so.7).  Two HIP/HSA runtimes in
+        # one process cannot both open the GPU, so when torch is installed it must be loaded FIRST:
+        # this library's NEEDED libamdhip64.so.7 then binds to the runtime torch already mapped.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(SO_PATH)
         L.m2s_generate_sdf.restype = C.c_int
         L.m2s_generate_sdf.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p,

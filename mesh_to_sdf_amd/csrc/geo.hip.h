@@ -15,23 +15,25 @@
 
 #pragma clang fp contract(off)
 
+#define M2S_HD __host__ __device__ __forceinline__
+
 namespace m2s {
 
 struct f3 {
   float x, y, z;
 };
 
-__device__ __forceinline__ f3 mk3(float x, float y, float z) { return {x, y, z}; }
+M2S_HD f3 mk3(float x, float y, float z) { return {x, y, z}; }
 // point.rs:81-141 — operation order matters (x*x' + y*y' + z*z', left to right)
-__device__ __forceinline__ f3 add3(f3 a, f3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
-__device__ __forceinline__ f3 sub3(f3 a, f3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
-__device__ __forceinline__ float dot3(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
-__device__ __forceinline__ f3 cross3(f3 a, f3 b) {
+M2S_HD f3 add3(f3 a, f3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+M2S_HD f3 sub3(f3 a, f3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+M2S_HD float dot3(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+M2S_HD f3 cross3(f3 a, f3 b) {
   return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
 }
-__device__ __forceinline__ f3 fmul3(f3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
-__device__ __forceinline__ f3 sel3(bool c, f3 a, f3 b) { return {c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z}; }
-__device__ __forceinline__ bool eq3(f3 a, f3 b) { return a.x == b.x && a.y == b.y && a.z == b.z; }
+M2S_HD f3 fmul3(f3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
+M2S_HD f3 sel3(bool c, f3 a, f3 b) { return {c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z}; }
+M2S_HD bool eq3(f3 a, f3 b) { return a.x == b.x && a.y == b.y && a.z == b.z; }
 
 // Triangle degeneracy class, decided once per triangle on the host side of the kernel
 // (geo.rs:73-88: the match on (a==b, b==c, a==c)).
@@ -41,7 +43,7 @@ enum : uint32_t {
   TRI_SEG_AC = 2,  // a == b                 -> closest_point_segment(p, a, c)         geo.rs:77-79
   TRI_SEG_AB = 3,  // b == c  or  a == c     -> closest_point_segment(p, a, b)         geo.rs:80-85
 };
-__device__ __forceinline__ uint32_t tri_class(f3 a, f3 b, f3 c) {
+M2S_HD uint32_t tri_class(f3 a, f3 b, f3 c) {
   const bool ab = eq3(a, b), bc = eq3(b, c), ac = eq3(a, c);
   if (ab && bc && ac) return TRI_POINT;
   if (ab) return TRI_SEG_AC;
@@ -50,7 +52,7 @@ __device__ __forceinline__ uint32_t tri_class(f3 a, f3 b, f3 c) {
 }
 
 // geo.rs:141-151
-__device__ __forceinline__ f3 closest_point_segment(f3 p, f3 a, f3 b) {
+M2S_HD f3 closest_point_segment(f3 p, f3 a, f3 b) {
   f3 ab = sub3(b, a);
   float m = dot3(ab, ab);
   f3 ap = sub3(p, a);
@@ -61,7 +63,7 @@ __device__ __forceinline__ f3 closest_point_segment(f3 p, f3 a, f3 b) {
 
 // geo.rs:90-137 for a non-degenerate-class triangle.  One IEEE division per call, as in the
 // reference (each region divides once; the numerator / denominator pair is selected first).
-__device__ __forceinline__ f3 closest_point_regular(f3 p, f3 a, f3 b, f3 c) {
+M2S_HD f3 closest_point_regular(f3 p, f3 a, f3 b, f3 c) {
   const f3 ab = sub3(b, a);
   const f3 ac = sub3(c, a);
   const f3 ap = sub3(p, a);
@@ -107,7 +109,7 @@ __device__ __forceinline__ f3 closest_point_regular(f3 p, f3 a, f3 b, f3 c) {
 }
 
 // Closest point for any triangle class (cls is wave-uniform: one triangle per wave step).
-__device__ __forceinline__ f3 closest_point_triangle(f3 p, f3 a, f3 b, f3 c, uint32_t cls) {
+M2S_HD f3 closest_point_triangle(f3 p, f3 a, f3 b, f3 c, uint32_t cls) {
   if (cls == TRI_REGULAR) return closest_point_regular(p, a, b, c);
   if (cls == TRI_POINT) return a;
   if (cls == TRI_SEG_AC) return closest_point_segment(p, a, c);
@@ -117,7 +119,7 @@ __device__ __forceinline__ f3 closest_point_triangle(f3 p, f3 a, f3 b, f3 c, uin
 // geo.rs:33-37 — squared distance dot(p-n, p-n).  sqrt is monotone, so the minimum over
 // triangles of geo.rs:26-30's sqrt(dot) is sqrt(min dot): kernels minimise d2 and take ONE
 // correctly rounded sqrt at the end, which gives the identical f32.
-__device__ __forceinline__ float point_triangle_dist2(f3 p, f3 a, f3 b, f3 c, uint32_t cls) {
+M2S_HD float point_triangle_dist2(f3 p, f3 a, f3 b, f3 c, uint32_t cls) {
   const f3 n = closest_point_triangle(p, a, b, c, cls);
   const f3 d = sub3(p, n);
   return dot3(d, d);
@@ -125,7 +127,7 @@ __device__ __forceinline__ float point_triangle_dist2(f3 p, f3 a, f3 b, f3 c, ui
 
 // geo.rs:43-56 — returns d2 and whether the reference's signed distance is positive
 // (direction . ((b-a) x (c-a)) > 0, normal not normalised; == 0 counts as negative).
-__device__ __forceinline__ float point_triangle_dist2_signed(f3 p, f3 a, f3 b, f3 c, uint32_t cls, bool* positive) {
+M2S_HD float point_triangle_dist2_signed(f3 p, f3 a, f3 b, f3 c, uint32_t cls, bool* positive) {
   const f3 n = closest_point_triangle(p, a, b, c, cls);
   const f3 d = sub3(p, n);
   const f3 nrm = cross3(sub3(b, a), sub3(c, a));
@@ -135,14 +137,14 @@ __device__ __forceinline__ float point_triangle_dist2_signed(f3 p, f3 a, f3 b, f
 
 // geo.rs:165-216 — axis-aligned ray/triangle.  AXIS 0: ray +X, plane (y,z); 1: +Y, (z,x); 2: +Z, (x,y).
 template <int AXIS>
-__device__ __forceinline__ float gx_(f3 v) { return AXIS == 0 ? v.x : (AXIS == 1 ? v.y : v.z); }
+M2S_HD float gx_(f3 v) { return AXIS == 0 ? v.x : (AXIS == 1 ? v.y : v.z); }
 template <int AXIS>
-__device__ __forceinline__ float gy_(f3 v) { return AXIS == 0 ? v.y : (AXIS == 1 ? v.z : v.x); }
+M2S_HD float gy_(f3 v) { return AXIS == 0 ? v.y : (AXIS == 1 ? v.z : v.x); }
 template <int AXIS>
-__device__ __forceinline__ float gz_(f3 v) { return AXIS == 0 ? v.z : (AXIS == 1 ? v.x : v.y); }
+M2S_HD float gz_(f3 v) { return AXIS == 0 ? v.z : (AXIS == 1 ? v.x : v.y); }
 
 template <int AXIS>
-__device__ __forceinline__ bool ray_triangle_aligned(f3 o, f3 t0, f3 t1, f3 t2, float* t_out) {
+M2S_HD bool ray_triangle_aligned(f3 o, f3 t0, f3 t1, f3 t2, float* t_out) {
   const f3 e01 = sub3(t1, t0), e12 = sub3(t2, t1), e20 = sub3(t0, t2);
   const f3 p0 = sub3(o, t0), p1 = sub3(o, t1), p2 = sub3(o, t2);
   const float w0 = gz_<AXIS>(p1) * gy_<AXIS>(e12) - gy_<AXIS>(p1) * gz_<AXIS>(e12);  // geo.rs:199
@@ -153,14 +155,14 @@ __device__ __forceinline__ bool ray_triangle_aligned(f3 o, f3 t0, f3 t1, f3 t2, 
   *t_out = t;
   return inside & (t > 0.0f);                                                                                 // :210
 }
-__device__ __forceinline__ bool ray_triangle_aligned_rt(int axis, f3 o, f3 t0, f3 t1, f3 t2, float* t_out) {
+M2S_HD bool ray_triangle_aligned_rt(int axis, f3 o, f3 t0, f3 t1, f3 t2, float* t_out) {
   if (axis == 0) return ray_triangle_aligned<0>(o, t0, t1, t2, t_out);
   if (axis == 1) return ray_triangle_aligned<1>(o, t0, t1, t2, t_out);
   return ray_triangle_aligned<2>(o, t0, t1, t2, t_out);
 }
 
 // geo.rs:4-22 — triangle AABB padded by 1e-4 (f32::min/max: a NaN operand is dropped)
-__device__ __forceinline__ void triangle_bounding_box(f3 a, f3 b, f3 c, f3* mn, f3* mx) {
+M2S_HD void triangle_bounding_box(f3 a, f3 b, f3 c, f3* mn, f3* mx) {
   const float e = 0.0001f;
   *mn = {fminf(a.x, fminf(b.x, c.x)) - e, fminf(a.y, fminf(b.y, c.y)) - e, fminf(a.z, fminf(b.z, c.z)) - e};
   *mx = {fmaxf(a.x, fmaxf(b.x, c.x)) + e, fmaxf(a.y, fmaxf(b.y, c.y)) + e, fmaxf(a.z, fmaxf(b.z, c.z)) + e};
@@ -168,18 +170,26 @@ __device__ __forceinline__ void triangle_bounding_box(f3 a, f3 b, f3 c, f3* mn, 
 
 // Candidate rule of bvh::traverse for an axis-aligned ray (closed padded box, see oracle).
 template <int AXIS>
-__device__ __forceinline__ bool ray_meets_box(f3 o, f3 mn, f3 mx) {
+M2S_HD bool ray_meets_box(f3 o, f3 mn, f3 mx) {
   return (gy_<AXIS>(o) >= gy_<AXIS>(mn)) & (gy_<AXIS>(o) <= gy_<AXIS>(mx)) & (gz_<AXIS>(o) >= gz_<AXIS>(mn)) &
          (gz_<AXIS>(o) <= gz_<AXIS>(mx)) & (gx_<AXIS>(mx) >= gx_<AXIS>(o));
 }
 
+M2S_HD int32_t f32_bits(float f) {
+#ifdef __HIP_DEVICE_COMPILE__
+  return __float_as_int(f);
+#else
+  int32_t i;
+  __builtin_memcpy(&i, &f, 4);
+  return i;
+#endif
+}
+
 // float-cmp approx_eq!(f32, a, b, ulps = 2, epsilon = 1e-6) for non-negative a, b (lib.rs:248)
-__device__ __forceinline__ bool approx_eq_abs(float a, float b) {
-  if (a == b) return true;
-  if (fabsf(a - b) <= 1e-6f) return true;
-  const int32_t d = (int32_t)((uint32_t)__float_as_int(a) - (uint32_t)__float_as_int(b));
+M2S_HD bool approx_eq_abs(float a, float b) {
+  const int32_t d = (int32_t)((uint32_t)f32_bits(a) - (uint32_t)f32_bits(b));
   const int32_t ad = d == INT32_MIN ? INT32_MAX : (d < 0 ? -d : d);
-  return ad <= 2;
+  return (a == b) | (fabsf(a - b) <= 1e-6f) | (ad <= 2);   // select-style on purpose, see normal_fold_result
 }
 
 // Final value of the compare_distances fold (lib.rs:242-259 applied as in default.rs:52-59)
@@ -187,16 +197,20 @@ __device__ __forceinline__ bool approx_eq_abs(float a, float b) {
 // triangles whose signed distance is positive.  With dmin = min|d| and P = {positive d with
 // approx_eq(|d|, dmin)} the fold returns min(P) if P is non-empty, else -dmin
 // (tests/test_oracle_fast.py::test_normal_fold_closed_form).
-__device__ __forceinline__ float normal_fold_result(float d2_all, float d2_pos) {
+// Written with selects only: hipcc 7.2 (clang 22) dropped the `return -dall` path of the
+// equivalent early-return form for lanes that failed approx_eq (caught by the parity tests).
+M2S_HD float normal_fold_result(float d2_all, float d2_pos) {
   const float f32max = 3.402823466e+38f;
+  const float inf = __builtin_inff();
   const float dall = sqrtf(d2_all);
   const float dpos = sqrtf(d2_pos);
-  if (!(d2_all < __builtin_inff())) return f32max;     // nothing finite seen: the fold keeps f32::MAX
-  if (d2_pos < __builtin_inff() && approx_eq_abs(dpos, dall)) return dpos;
-  return -dall;
+  const bool use_pos = (d2_pos < inf) & approx_eq_abs(dpos, dall);
+  float r = use_pos ? dpos : -dall;
+  r = (d2_all < inf) ? r : f32max;   // nothing finite seen: the fold keeps f32::MAX
+  return r;
 }
 
 // Grid::get_cell_center for one axis (grid.rs:135-141): first + (i as f32) * size, mul then add.
-__device__ __forceinline__ float cell_center(float first, float size, uint32_t i) { return first + (float)i * size; }
+M2S_HD float cell_center(float first, float size, uint32_t i) { return first + (float)i * size; }
 
 }  // namespace m2s

@@ -1,0 +1,79 @@
+"""The N>1 path (x-slab shards + all-gather) under gloo, world_size 2 and 3, on CPU.  The slab
+computation is injected (the oracle's exact semantics restricted to the slab) so that the
+partition / gather logic of mesh_to_sdf_amd.distributed runs without a GPU."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import oracle as orc
+from mesh_to_sdf_amd import Grid, SignMethod, Topology, meshes
+from mesh_to_sdf_amd.distributed import gather_slabs, generate_grid_sdf_sharded, slab_bounds
+
+
+def test_slab_bounds_cover_and_are_contiguous():
+    for nx in (1, 5, 7, 64, 512, 513):
+        for world in (1, 2, 3, 4, 8):
+            prev = 0
+            for r in range(world):
+                x0, x1 = slab_bounds(nx, world, r)
+                assert x0 == prev and x1 >= x0
+                prev = x1
+            assert prev == nx
+            sizes = [slab_bounds(nx, world, r)[1] - slab_bounds(nx, world, r)[0] for r in range(world)]
+            assert max(sizes) - min(sizes) <= 1
+    assert [slab_bounds(512, 8, r) for r in (0, 7)] == [(0, 64), (448, 512)]
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, nx, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        v, idx = meshes.blob(24, 13)
+        lo, hi = meshes.extended_bbox(v, 0.1)
+        grid = Grid.from_bounding_box(lo, hi, [nx, 10, 12])
+        first, size, cnt = grid.get_first_cell(), grid.get_cell_size(), grid.get_cell_count()
+        whole = orc.generate_grid_sdf(v, idx, first, size, cnt, sign=0, semantics=orc.EXACT, threads=1)
+        row = cnt[1] * cnt[2]
+
+        def compute_slab(out, x0, x1):
+            out.fill_(float("nan"))
+            out[x0 * row : x1 * row] = torch.from_numpy(whole[x0 * row : x1 * row].copy())
+
+        out = generate_grid_sdf_sharded(torch.from_numpy(v), Topology.TriangleList(idx), grid, SignMethod.Raycast,
+                                        compute_slab=compute_slab)
+        ok = np.array_equal(out.numpy().view(np.uint32), whole.view(np.uint32))
+        x0, x1 = slab_bounds(nx, world, rank)
+        q.put((rank, bool(ok), x0, x1))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,nx", [(2, 16), (2, 15), (3, 16)])
+def test_sharded_grid_gloo(world, nx):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, nx, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _, _ in res), res
+    covered = sorted((x0, x1) for _, _, x0, x1 in res)
+    assert covered[0][0] == 0 and covered[-1][1] == nx

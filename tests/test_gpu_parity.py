@@ -319,7 +319,7 @@ def test_full_size_512_properties():
     s3 = sdf.view(n, n, n)
     cs = float(g.get_cell_size()[2])
     dz = (s3[:, :, 1:].abs() - s3[:, :, :-1].abs()).abs().max().item()
-    assert dz <= cs * (1 + 1e-5)
+    assert dz <= cs + 2e-6   # 1-Lipschitz up to f32 rounding of the two distances
     sub = s3[::8, ::8, ::8].contiguous().cpu().numpy().reshape(-1)
     first, size = g.get_first_cell(), g.get_cell_size()
     ii = np.arange(0, n, 8, dtype=np.float32)
