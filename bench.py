@@ -134,6 +134,8 @@ def main():
         dist_ms = float(np.mean([t.distance_ms for t in tims]))
         build_ms = float(np.mean([t.accel_build_ms for t in tims]))
         sign_ms = float(np.mean([t.sign_ms for t in tims]))
+        seed_ms = float(np.mean([t.seed_ms for t in tims]))
+        total_ms = float(np.mean([t.total_ms for t in tims]))
         n_tris = int(tims[0].n_triangles)
         slab_voxels = (x1 - x0) * n * n
         # algorithmic bytes of one launch of the dominant kernel:
@@ -168,7 +170,8 @@ def main():
                 "sign_method": args.sign,
                 "parallelism": f"xslab{world}",
             },
-            "phases_ms": {"accel_build": round(build_ms, 4), "sign_planes": round(sign_ms, 4), "distance": round(dist_ms, 4)},
+            "phases_ms": {"accel_build": round(build_ms, 4), "sign_planes": round(sign_ms, 4), "seed_passes": round(seed_ms, 4),
+                          "distance": round(dist_ms, 4), "device_total": round(total_ms, 4)},
             "roofline": {
                 "bound": "hbm",
                 "kernel": "k_packet<GRID, MODE_UNSIGNED, SIGN_GRID_PLANE>",

@@ -82,8 +82,10 @@ enum m2s_mem_kind {
 typedef struct m2s_timings {
   float accel_build_ms;  /* topology flatten + triangle records + LBVH */
   float sign_ms;         /* grid-line ray parity planes (Raycast grid path) */
-  float distance_ms;     /* nearest-triangle search (+ fused sign resolve) — the dominant kernel */
+  float distance_ms;     /* nearest-triangle search (+ fused sign resolve) — the dominant kernel's launch */
   float total_ms;        /* first kernel to last kernel, device side */
+  float seed_ms;         /* grid path: the two coarse seed passes that precede the dominant launch */
+  float reserved_f;
   uint64_t n_triangles;
   uint64_t n_units;      /* voxels or queries produced by this call */
   uint32_t distance_launches;  /* number of launches of the dominant kernel in this call */

@@ -27,6 +27,8 @@ class M2STimings(C.Structure):
         ("sign_ms", C.c_float),
         ("distance_ms", C.c_float),
         ("total_ms", C.c_float),
+        ("seed_ms", C.c_float),
+        ("reserved_f", C.c_float),
         ("n_triangles", C.c_uint64),
         ("n_units", C.c_uint64),
         ("distance_launches", C.c_uint32),

@@ -208,7 +208,8 @@ __device__ __forceinline__ Box seg_query(const Box* __restrict__ seg, const SegL
 __global__ __launch_bounds__(256) void k_emit(int n, const int2* __restrict__ range, const int* __restrict__ parent,
                                               const Box* __restrict__ seg, SegLevels lv,
                                               const uint32_t* __restrict__ order, const TriRec* __restrict__ raw,
-                                              NodeRec* __restrict__ nodes, TriRec* __restrict__ tris) {
+                                              NodeRec* __restrict__ nodes, TriRec* __restrict__ tris,
+                                              uint32_t* __restrict__ slot_first) {
   const int id = blockIdx.x * blockDim.x + threadIdx.x;
   if (id >= 2 * n - 1) return;
   const bool leaf = id >= n - 1;
@@ -232,7 +233,88 @@ __global__ __launch_bounds__(256) void k_emit(int n, const int2* __restrict__ ra
   nr.mxx = b.mxx; nr.mxy = b.mxy; nr.mxz = b.mxz;
   nr.tri = leaf ? first : -1;
   nodes[slot] = nr;
+  slot_first[slot] = (uint32_t)first;
   if (leaf) tris[first] = raw[order[first]];
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+__device__ __forceinline__ float wave_min(float v) {
+  for (int off = 32; off > 0; off >>= 1) v = fminf(v, __shfl_xor(v, off));
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
+  return v;
+}
+
+// Oriented bound (NodeExt) of every node: one wave per pre-order slot, lanes stride over the
+// triangles of the subtree (contiguous in Morton order).  Pass 1: area-weighted mean normal.
+// Pass 2: extent along it and lateral radius about the AABB centre.  All roundings go outwards.
+__global__ __launch_bounds__(256) void k_node_ext(const NodeRec* __restrict__ nodes,
+                                                  const uint32_t* __restrict__ slot_first,
+                                                  const TriRec* __restrict__ tris, uint32_t n_nodes,
+                                                  NodeExt* __restrict__ ext) {
+  const uint32_t slot = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (slot >= n_nodes) return;
+  const NodeRec nr = nodes[slot];
+  const uint32_t first = slot_first[slot];
+  const uint32_t cnt = (nr.skip - slot + 1u) >> 1;
+  float cx = 0.5f * (nr.mnx + nr.mxx), cy = 0.5f * (nr.mny + nr.mxy), cz = 0.5f * (nr.mnz + nr.mxz);
+  if (!(fabsf(cx) < 3.0e38f)) cx = 0.0f;
+  if (!(fabsf(cy) < 3.0e38f)) cy = 0.0f;
+  if (!(fabsf(cz) < 3.0e38f)) cz = 0.0f;
+  if (cnt > EXT_TRIVIAL_ABOVE) {
+    if (lane == 0) {  // cylinder (axis +x) around the AABB
+      const float hx = fmaxf(nr.mxx - cx, cx - nr.mnx), hy = fmaxf(nr.mxy - cy, cy - nr.mny), hz = fmaxf(nr.mxz - cz, cz - nr.mnz);
+      const float e = 1.0e-5f * (fabsf(hx) + fabsf(hy) + fabsf(hz)) + 1.0e-30f;
+      NodeExt x;
+      x.cx = cx; x.cy = cy; x.cz = cz; x.R = sqrtf(hy * hy + hz * hz) * 1.00001f + e;
+      x.nx = 1.0f; x.ny = 0.0f; x.nz = 0.0f; x.dlo = -hx - e;
+      x.dhi = hx + e; x.skip = nr.skip; x.tri = nr.tri; x.pad = 0;
+      ext[slot] = x;
+    }
+    return;
+  }
+  float sx = 0.0f, sy = 0.0f, sz = 0.0f;
+  for (uint32_t i = lane; i < cnt; i += 64) {
+    const TriRec t = tris[first + i];
+    const f3 n = cross3(mk3(t.bx - t.ax, t.by - t.ay, t.bz - t.az), mk3(t.cx - t.ax, t.cy - t.ay, t.cz - t.az));
+    if (fabsf(n.x) < 3.0e38f && fabsf(n.y) < 3.0e38f && fabsf(n.z) < 3.0e38f) { sx += n.x; sy += n.y; sz += n.z; }
+  }
+  sx = wave_sum(sx); sy = wave_sum(sy); sz = wave_sum(sz);
+  float len = sqrtf(sx * sx + sy * sy + sz * sz);
+  float nx = 1.0f, ny = 0.0f, nz = 0.0f;
+  if (len > 1.0e-30f && len < 3.0e38f) { nx = sx / len; ny = sy / len; nz = sz / len; }
+  const float inf = __builtin_inff();
+  float dlo = inf, dhi = -inf, r2 = 0.0f, w2max = 0.0f;
+  for (uint32_t i = lane; i < cnt; i += 64) {
+    const TriRec t = tris[first + i];
+    const float vx[3] = {t.ax, t.bx, t.cx}, vy[3] = {t.ay, t.by, t.cy}, vz[3] = {t.az, t.bz, t.cz};
+    for (int k = 0; k < 3; ++k) {
+      const float wx = vx[k] - cx, wy = vy[k] - cy, wz = vz[k] - cz;
+      const float tt = nx * wx + ny * wy + nz * wz;
+      const float w2 = wx * wx + wy * wy + wz * wz;
+      dlo = fminf(dlo, tt);
+      dhi = fmaxf(dhi, tt);
+      r2 = fmaxf(r2, w2 - tt * tt);
+      w2max = fmaxf(w2max, w2);
+    }
+  }
+  dlo = wave_min(dlo); dhi = wave_max(dhi); r2 = wave_max(r2); w2max = wave_max(w2max);
+  if (lane == 0) {
+    // outward rounding: l^2 = w^2 - t^2 cancels, so widen by a few ulps of w^2 before the sqrt
+    const float R = sqrtf(fmaxf(r2, 0.0f) + 1.0e-6f * w2max) * 1.00001f + 1.0e-30f;
+    const float e = 1.0e-5f * (fabsf(dlo) + fabsf(dhi)) + 2.0e-6f * sqrtf(w2max) + 1.0e-30f;
+    NodeExt x;
+    x.cx = cx; x.cy = cy; x.cz = cz; x.R = R;
+    x.nx = nx; x.ny = ny; x.nz = nz; x.dlo = dlo - e;
+    x.dhi = dhi + e; x.skip = nr.skip; x.tri = nr.tri; x.pad = 0;
+    ext[slot] = x;
+  }
 }
 
 __global__ void k_init_scene(int* scene, int* parent, int n_nodes) {
@@ -253,7 +335,7 @@ size_t bvh_workspace_bytes(size_t n_tris) {
                             (uint32_t*)nullptr, n, 0, 64, (hipStream_t)0);
   size_t b = 0;
   b += n * sizeof(TriRec) * 2 + n * sizeof(Box) * 3 + n * (8 + 4) * 2 + sort_tmp;
-  b += n * (sizeof(int2) * 2) + 2 * n * sizeof(int) + 2 * n * sizeof(NodeRec);
+  b += n * (sizeof(int2) * 2) + 2 * n * sizeof(int) + 2 * n * sizeof(NodeRec) + 2 * n * (sizeof(NodeExt) + 4);
   return b + 64 * 256 + 4096;
 }
 
@@ -262,6 +344,8 @@ int build_device_mesh(Arena& ws, hipStream_t st, const float* d_verts, size_t n_
   (void)n_indices;
   out->tris = nullptr;
   out->nodes = nullptr;
+  out->ext = nullptr;
+  out->stats = nullptr;
   out->scene = nullptr;
   out->n_tris = (uint32_t)n_tris;
   out->n_nodes = n_tris ? (uint32_t)(2 * n_tris - 1) : 0;
@@ -280,12 +364,14 @@ int build_device_mesh(Arena& ws, hipStream_t st, const float* d_verts, size_t n_
   int2* child = ws.take<int2>(n_tris);
   int* parent = ws.take<int>(2 * n_tris);
   NodeRec* nodes = ws.take<NodeRec>(2 * n_tris);
+  NodeExt* ext = ws.take<NodeExt>(2 * n_tris);
+  uint32_t* slot_first = ws.take<uint32_t>(2 * n_tris);
   int* scene = ws.take<int>(8);
   size_t sort_tmp = 0;
   (void)rocprim::radix_sort_pairs(nullptr, sort_tmp, keys, keys2, vals, order, n_tris, 0, 64, st);
   void* tmp = ws.take<char>(sort_tmp ? sort_tmp : 1);
   if (!raw || !tris || !boxes || !seg || !keys || !keys2 || !vals || !order || !range || !child || !parent || !nodes ||
-      !scene || !tmp) {
+      !scene || !tmp || !ext || !slot_first) {
     set_error("internal: BVH workspace too small");
     return M2S_ERR_HIP_INTERNAL;
   }
@@ -316,10 +402,13 @@ int build_device_mesh(Arena& ws, hipStream_t st, const float* d_verts, size_t n_
     hipLaunchKernelGGL(k_seg_level, dim3(cdiv(lv.cnt[l], B)), dim3(B), 0, st, seg + lv.off[l - 1], (int)lv.cnt[l - 1],
                        seg + lv.off[l], (int)lv.cnt[l]);
   hipLaunchKernelGGL(k_emit, dim3(cdiv(2 * n_tris - 1, B)), dim3(B), 0, st, n, range, parent, seg, lv, order, raw,
-                     nodes, tris);
+                     nodes, tris, slot_first);
+  hipLaunchKernelGGL(k_node_ext, dim3(cdiv(2 * n_tris - 1, 4)), dim3(B), 0, st, nodes, slot_first, tris,
+                     (uint32_t)(2 * n_tris - 1), ext);
   M2S_HIP_CHECK(hipGetLastError());
   out->tris = tris;
   out->nodes = nodes;
+  out->ext = ext;
   out->scene = scene;
   return 0;
 }

@@ -2,6 +2,7 @@
 // per-device workspace, host<->device staging for the drop-in (host pointer) case, phase timing.
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -26,7 +27,7 @@ struct DeviceState {
   char* base = nullptr;
   size_t cap = 0;
   hipStream_t stream = nullptr;
-  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   int* h_err = nullptr;  // pinned
 };
 
@@ -146,7 +147,7 @@ int stage_mesh(Arena& ws, const CallCtx& c, const float* vertices, size_t n_vert
 }
 
 int finish_call(const CallCtx& c, DeviceState& st, int* d_err, m2s_timings* t, size_t n_tris, size_t n_units,
-                bool had_sign) {
+                bool had_sign, bool had_seed_event = false) {
   if (!c.sync) return M2S_OK;
   M2S_HIP_CHECK(hipMemcpyAsync(st.h_err, d_err, sizeof(int), hipMemcpyDeviceToHost, c.stream));
   M2S_HIP_CHECK(hipStreamSynchronize(c.stream));
@@ -154,11 +155,18 @@ int finish_call(const CallCtx& c, DeviceState& st, int* d_err, m2s_timings* t, s
     float a = 0, b = 0, d = 0, tot = 0;
     (void)hipEventElapsedTime(&a, st.ev[0], st.ev[1]);
     (void)hipEventElapsedTime(&b, st.ev[1], st.ev[2]);
-    (void)hipEventElapsedTime(&d, st.ev[2], st.ev[3]);
+    float sd = 0;
+    if (had_seed_event) {
+      (void)hipEventElapsedTime(&sd, st.ev[2], st.ev[4]);
+      (void)hipEventElapsedTime(&d, st.ev[4], st.ev[3]);
+    } else {
+      (void)hipEventElapsedTime(&d, st.ev[2], st.ev[3]);
+    }
     (void)hipEventElapsedTime(&tot, st.ev[0], st.ev[3]);
     t->accel_build_ms = a;
     t->sign_ms = had_sign ? b : 0.0f;
     t->distance_ms = d;
+    t->seed_ms = sd;
     t->total_ms = tot;
     t->n_triangles = n_tris;
     t->n_units = n_units;
@@ -269,6 +277,7 @@ int m2s_generate_grid_sdf(const float* vertices, size_t n_vertices, const void* 
 
   size_t need = bvh_workspace_bytes(n_tris) + 4096;
   if (sign_method == M2S_SIGN_RAYCAST) need += sign_workspace_bytes(g);
+  need += grid_distance_workspace_bytes(g);
   if (c.mem_kind == M2S_MEM_HOST)
     need += align_up(n_vertices * 12) + align_up(n_indices * (size_t)(indices ? index_bytes : 0)) + align_up(slab_cells * 4) + 1024;
   rc = ensure_capacity(*st, need);
@@ -293,6 +302,14 @@ int m2s_generate_grid_sdf(const float* vertices, size_t n_vertices, const void* 
   DeviceMesh mesh;
   rc = build_device_mesh(ws, c.stream, sm.d_verts, n_vertices, sm.d_indices, n_indices, index_bytes, topology, n_tris, d_err, &mesh);
   if (rc) return rc;
+  unsigned long long* d_stats = nullptr;
+  if (getenv("M2S_STATS")) {
+    d_stats = ws.take<unsigned long long>(8);
+    unsigned long long init[8] = {0, 0, 0, 0, 0, 0, 0, (unsigned long long)atoi(getenv("M2S_STATS"))};
+    M2S_HIP_CHECK(hipMemcpyAsync(d_stats, init, 64, hipMemcpyHostToDevice, c.stream));
+    M2S_HIP_CHECK(hipStreamSynchronize(c.stream));
+    mesh.stats = d_stats;
+  }
   M2S_HIP_CHECK(hipEventRecord(st->ev[1], c.stream));
   const uint32_t* plane = nullptr;
   if (sign_method == M2S_SIGN_RAYCAST) {
@@ -300,13 +317,21 @@ int m2s_generate_grid_sdf(const float* vertices, size_t n_vertices, const void* 
     if (rc) return rc;
   }
   M2S_HIP_CHECK(hipEventRecord(st->ev[2], c.stream));
-  rc = launch_grid_distance(c.stream, mesh, g, sign_method == M2S_SIGN_RAYCAST ? MODE_UNSIGNED : MODE_NORMAL_FOLD, plane,
-                            c.algorithm, d_out, d_err);
+  rc = launch_grid_distance(ws, c.stream, mesh, g, sign_method == M2S_SIGN_RAYCAST ? MODE_UNSIGNED : MODE_NORMAL_FOLD, plane,
+                            c.algorithm, d_out, d_err, st->ev[4]);
   if (rc) return rc;
   M2S_HIP_CHECK(hipEventRecord(st->ev[3], c.stream));
   if (c.mem_kind == M2S_MEM_HOST)
     M2S_HIP_CHECK(hipMemcpyAsync(out + (size_t)xb * ny * nz, d_slab, slab_cells * 4, hipMemcpyDeviceToHost, c.stream));
-  return finish_call(c, *st, d_err, c.timings, n_tris, slab_cells, sign_method == M2S_SIGN_RAYCAST);
+  if (d_stats) {
+    unsigned long long h[8];
+    M2S_HIP_CHECK(hipMemcpyAsync(h, d_stats, 64, hipMemcpyDeviceToHost, c.stream));
+    M2S_HIP_CHECK(hipStreamSynchronize(c.stream));
+    const double w = h[3] ? (double)h[3] : 1.0;
+    fprintf(stderr, "[m2s stats] packets %llu: per packet box tests %.1f, oriented-bound tests %.1f, exact triangle tests %.1f\n",
+            h[3], h[0] / w, h[1] / w, h[2] / w);
+  }
+  return finish_call(c, *st, d_err, c.timings, n_tris, slab_cells, sign_method == M2S_SIGN_RAYCAST, true);
 }
 
 int m2s_generate_sdf(const float* vertices, size_t n_vertices, const void* indices, size_t n_indices, int index_bytes,

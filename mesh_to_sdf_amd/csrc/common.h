@@ -35,9 +35,33 @@ struct alignas(32) NodeRec {
 };
 static_assert(sizeof(NodeRec) == 32, "NodeRec must be 32 bytes");
 
+// Oriented bound of a node, 48 B, same index as NodeRec.  Every triangle of the subtree lies inside
+//   { x : dlo <= n.(x - c) <= dhi  and  |(x - c) - n (n.(x - c))| <= R }      (a disc-shaped slab)
+// for the unit vector n (area-weighted mean normal; ANY unit vector keeps the bound valid).
+// For a smooth surface patch the slab is thin, which is what an AABB cannot express: a query at
+// distance D from a flat patch meets ~rho*pi*2*s*D leaf AABBs of thickness s but only the O(1)
+// discs that cover its foot point.  lower bound^2 = max(dlo - t, t - dhi, 0)^2 + max(l - R, 0)^2
+// with t = n.(p - c), l^2 = |p - c|^2 - t^2.
+// The record also repeats the node's `skip` and `tri`, so the nearest-triangle traversal reads
+// ONLY this array (one 48-byte scalar load per node); NodeRec boxes serve the ray stabbing.
+// Nodes with more than EXT_TRIVIAL_ABOVE triangles get the cylinder around their AABB instead
+// (n = +x): at that size a surface patch is not flat and the loop over its triangles is not worth it.
+struct alignas(16) NodeExt {
+  float cx, cy, cz, R;
+  float nx, ny, nz, dlo;
+  float dhi;
+  uint32_t skip;
+  int32_t tri;
+  uint32_t pad;
+};
+constexpr uint32_t EXT_TRIVIAL_ABOVE = 2048;
+static_assert(sizeof(NodeExt) == 48, "NodeExt must be 48 bytes");
+
 struct DeviceMesh {
   const TriRec* tris;   // n_tris records, Morton order
   const NodeRec* nodes; // n_nodes = 2*n_tris - 1 (0 if n_tris == 0)
+  const NodeExt* ext;   // n_nodes oriented bounds
+  unsigned long long* stats;  // optional traversal counters (M2S_STATS=1), else nullptr
   uint32_t n_tris;
   uint32_t n_nodes;
   const int* scene;     // 6 order-encoded ints: min xyz / max xyz of the triangle box centres (see bvh.hip)
@@ -120,8 +144,11 @@ int build_grid_sign_plane(Arena& ws, hipStream_t st, const DeviceMesh& mesh, con
                           const uint32_t** d_inside_plane);
 
 // distance.hip
-int launch_grid_distance(hipStream_t st, const DeviceMesh& mesh, const GridParams& g, int mode,
-                         const uint32_t* d_inside_plane, int algorithm, float* d_out, int* d_err);
+size_t grid_distance_workspace_bytes(const GridParams& g);
+// Records `ev_before_final` (if non-null) between the seed passes and the final k_packet launch.
+int launch_grid_distance(Arena& ws, hipStream_t st, const DeviceMesh& mesh, const GridParams& g, int mode,
+                         const uint32_t* d_inside_plane, int algorithm, float* d_out, int* d_err,
+                         hipEvent_t ev_before_final);
 size_t query_workspace_bytes(size_t n_q);
 int launch_query_distance(Arena& ws, hipStream_t st, const DeviceMesh& mesh, const float* d_queries, size_t n_q,
                           int mode, int sign_src, int algorithm, float* d_out, int* d_err);

@@ -15,6 +15,7 @@
 // Pruning is conservative: a subtree is dropped only if its box is farther than the lane's
 // current best by a margin that covers f32 rounding of both the box test and the reference
 // arithmetic (see prune_bound), so the minimum is the brute-force minimum bit for bit.
+#include <cstdlib>
 #include <cstring>
 
 #include <rocprim/rocprim.hpp>
@@ -58,7 +59,9 @@ __device__ __forceinline__ uint32_t grid_brick_count(const GridParams& g) {
 
 // XCD-aware work order: the dispatcher places block b on XCD b % 8; give every XCD one contiguous
 // run of the brick sequence so that its private L2 keeps seeing the same part of the BVH.
-__device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t chunk) { return (b & 7u) * chunk + (b >> 3); }
+__device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t chunk) {
+  return chunk ? (b & 7u) * chunk + (b >> 3) : b;   // chunk == 0: plain order (M2S_XCD_REMAP=0)
+}
 
 // ---- per-lane search state -----------------------------------------------------------------
 template <int MODE>
@@ -66,14 +69,18 @@ struct Best {
   float d2 = __builtin_inff();      // min d2 over all triangles
   float d2pos = __builtin_inff();   // MODE_NORMAL_FOLD: min d2 over triangles with positive signed distance
   uint32_t idx = 0xffffffffu;       // MODE_NEAREST_NORMAL: triangle achieving d2 (lowest index on ties)
+  uint32_t slot = 0;                // seed passes: TriRec slot (Morton order) achieving d2
   bool pos = false;                 // MODE_NEAREST_NORMAL: its sign
   bool nan = false;
 };
 
-template <int MODE>
-__device__ __forceinline__ void eval_triangle(Best<MODE>& best, f3 p, f3 a, f3 b, f3 c, uint32_t cls, uint32_t index) {
+template <int MODE, bool TRACK = false>
+__device__ __forceinline__ void eval_triangle(Best<MODE>& best, f3 p, f3 a, f3 b, f3 c, uint32_t cls, uint32_t index,
+                                              uint32_t slot = 0) {
   if (MODE == MODE_UNSIGNED) {
-    best.d2 = fminf(best.d2, point_triangle_dist2(p, a, b, c, cls));  // f32::min drops a NaN operand (default.rs:47)
+    const float d2 = point_triangle_dist2(p, a, b, c, cls);
+    if (TRACK && d2 < best.d2) best.slot = slot;
+    best.d2 = fminf(best.d2, d2);  // f32::min drops a NaN operand (default.rs:47)
   } else {
     bool positive;
     const float d2 = point_triangle_dist2_signed(p, a, b, c, cls, &positive);
@@ -113,6 +120,19 @@ __device__ __forceinline__ float box_dist2(f3 p, float mnx, float mny, float mnz
   return __builtin_fmaf(dx, dx, __builtin_fmaf(dy, dy, dz * dz));
 }
 
+// Lower bound (squared) of the distance from p to anything inside the node's disc-shaped slab
+// (common.h NodeExt).  Every rounding is taken towards a SMALLER bound; FMAs are fine here.
+__device__ __forceinline__ float ext_dist2(f3 p, const NodeExt& e) {
+  const float vx = p.x - e.cx, vy = p.y - e.cy, vz = p.z - e.cz;
+  const float t = __builtin_fmaf(e.nz, vz, __builtin_fmaf(e.ny, vy, e.nx * vx));
+  const float v2 = __builtin_fmaf(vz, vz, __builtin_fmaf(vy, vy, vx * vx));
+  // l^2 = v2 - t^2 cancels when p sits over the disc centre: shave a few ulps of v2 off first
+  const float l2 = fmaxf(__builtin_fmaf(-1.0e-6f, v2, __builtin_fmaf(-t, t, v2)), 0.0f);
+  const float lat = fmaxf(__builtin_amdgcn_sqrtf(l2) - e.R, 0.0f);
+  const float s = fmaxf(fmaxf(e.dlo - t, t - e.dhi), 0.0f);
+  return __builtin_fmaf(s, s, lat * lat);
+}
+
 template <int AXIS>
 __device__ __forceinline__ uint32_t stab_count(const DeviceMesh& mesh, f3 p) {
   uint32_t count = 0;
@@ -137,11 +157,16 @@ __device__ __forceinline__ uint32_t stab_count(const DeviceMesh& mesh, f3 p) {
 }
 
 // ---- k_packet -------------------------------------------------------------------------------
-template <bool GRID, int MODE, int SIGN>
+// SEEDPASS: instead of a distance, write for every point the TriRec slot of its nearest triangle
+// (`seed_out`, same indexing as `out`); used on coarse lattices whose points are the brick
+// centres of the next finer level.  `seed_in` (one slot per packet, may be null) replaces the
+// greedy descent: the packet starts from the nearest triangle of its own centre.
+template <bool GRID, int MODE, int SIGN, bool SEEDPASS = false>
 __global__ __launch_bounds__(256) void k_packet(DeviceMesh mesh, GridParams g, const float4* __restrict__ qsorted,
                                                 const uint32_t* __restrict__ perm, uint32_t n_q,
                                                 const uint32_t* __restrict__ plane, float* __restrict__ out,
-                                                int* __restrict__ err, uint32_t n_packets, uint32_t chunk) {
+                                                int* __restrict__ err, uint32_t n_packets, uint32_t chunk,
+                                                const uint32_t* __restrict__ seed_in, uint32_t* __restrict__ seed_out) {
   const int lane = threadIdx.x & 63;
   const uint32_t block = xcd_remap(blockIdx.x, chunk);
   const uint32_t packet = block * 4 + (threadIdx.x >> 6);
@@ -165,12 +190,19 @@ __global__ __launch_bounds__(256) void k_packet(DeviceMesh mesh, GridParams g, c
   }
 
   Best<MODE> best;
+  uint32_t st_box = 0, st_ext = 0, st_leaf = 0;   // wave-uniform traversal counters (SGPRs)
   if (mesh.n_nodes) {
     const float scale = fmaxf(mesh_scale(mesh), fmaxf(fabsf(p.x), fmaxf(fabsf(p.y), fabsf(p.z))));
     const float slack = 4.0e-6f * scale + (MODE == MODE_NORMAL_FOLD ? 2.5e-6f : 0.0f);
 
-    // seed: greedy descent towards the packet's first point, evaluate that leaf for every lane
-    {
+    if (seed_in != nullptr) {
+      // seed: nearest triangle of this packet's centre, found by the coarser pass
+      const uint32_t slot = min(seed_in[packet], mesh.n_tris - 1);
+      const TriRec tr = mesh.tris[slot];
+      eval_triangle<MODE, SEEDPASS>(best, p, mk3(tr.ax, tr.ay, tr.az), mk3(tr.bx, tr.by, tr.bz), mk3(tr.cx, tr.cy, tr.cz),
+                                    tr.cls, tr.index, slot);
+    } else {
+      // seed: greedy descent towards the packet's first point, evaluate that leaf for every lane
       const f3 c = {__shfl(p.x, 0), __shfl(p.y, 0), __shfl(p.z, 0)};
       uint32_t n = 0;
       NodeRec nr = mesh.nodes[0];
@@ -186,27 +218,44 @@ __global__ __launch_bounds__(256) void k_packet(DeviceMesh mesh, GridParams g, c
         nr = go_left ? nl : nrr;
       }
       const TriRec tr = mesh.tris[nr.tri];
-      eval_triangle<MODE>(best, p, mk3(tr.ax, tr.ay, tr.az), mk3(tr.bx, tr.by, tr.bz), mk3(tr.cx, tr.cy, tr.cz),
-                          tr.cls, tr.index);
+      eval_triangle<MODE, SEEDPASS>(best, p, mk3(tr.ax, tr.ay, tr.az), mk3(tr.bx, tr.by, tr.bz), mk3(tr.cx, tr.cy, tr.cz),
+                                    tr.cls, tr.index, (uint32_t)nr.tri);
     }
 
     float thr = prune_bound(best.d2, slack);
+    // M2S_STATS=2: a second, counting-only traversal that starts from the final bound ("perfect seed")
+    const int passes = (mesh.stats != nullptr && mesh.stats[7] == 2ull) ? 2 : 1;
+    for (int pass = 0; pass < passes; ++pass) {
+    if (pass == 1) { st_box = 0; st_ext = 0; st_leaf = 0; }
     uint32_t node = 0;
     while (node < mesh.n_nodes) {
       node = __builtin_amdgcn_readfirstlane(node);
-      const NodeRec nr = mesh.nodes[node];
-      const float bd2 = box_dist2(p, nr.mnx, nr.mny, nr.mnz, nr.mxx, nr.mxy, nr.mxz);
-      if (__ballot(bd2 <= thr) == 0ull) { node = nr.skip; continue; }
+      const NodeExt nr = mesh.ext[node];
+      ++st_box;
+      const float ed2 = ext_dist2(p, nr);
+      if (__ballot(!(ed2 > thr)) == 0ull) { node = nr.skip; continue; }   // a NaN bound keeps the node
       if (nr.tri >= 0) {
+        ++st_leaf;
         const TriRec tr = mesh.tris[nr.tri];
-        eval_triangle<MODE>(best, p, mk3(tr.ax, tr.ay, tr.az), mk3(tr.bx, tr.by, tr.bz), mk3(tr.cx, tr.cy, tr.cz),
-                            tr.cls, tr.index);
+        eval_triangle<MODE, SEEDPASS>(best, p, mk3(tr.ax, tr.ay, tr.az), mk3(tr.bx, tr.by, tr.bz),
+                                      mk3(tr.cx, tr.cy, tr.cz), tr.cls, tr.index, (uint32_t)nr.tri);
         thr = prune_bound(best.d2, slack);
         node = nr.skip;
       } else {
         node = node + 1;
       }
     }
+    }
+  }
+  if (SEEDPASS) {
+    if (store) seed_out[out_index] = best.slot;
+    return;
+  }
+  if (mesh.stats != nullptr && lane == 0) {
+    atomicAdd(&mesh.stats[0], (unsigned long long)st_box);
+    atomicAdd(&mesh.stats[1], (unsigned long long)st_ext);
+    atomicAdd(&mesh.stats[2], (unsigned long long)st_leaf);
+    atomicAdd(&mesh.stats[3], 1ull);
   }
 
   bool negate = false;
@@ -355,13 +404,15 @@ __global__ __launch_bounds__(256) void k_qgather(const float* __restrict__ q, co
   sorted[i] = make_float4(q[3 * s], q[3 * s + 1], q[3 * s + 2], 0.0f);
 }
 
-template <bool GRID, int MODE, int SIGN>
+template <bool GRID, int MODE, int SIGN, bool SEEDPASS = false>
 void launch_packet(hipStream_t st, const DeviceMesh& mesh, const GridParams& g, const float4* qs, const uint32_t* perm,
-                   uint32_t n_q, const uint32_t* plane, float* out, int* err, uint32_t n_packets) {
+                   uint32_t n_q, const uint32_t* plane, float* out, int* err, uint32_t n_packets,
+                   const uint32_t* seed_in = nullptr, uint32_t* seed_out = nullptr) {
   const uint32_t blocks = (n_packets + 3) / 4;
-  const uint32_t chunk = (blocks + 7) / 8;
-  hipLaunchKernelGGL((k_packet<GRID, MODE, SIGN>), dim3(chunk * 8), dim3(256), 0, st, mesh, g, qs, perm, n_q, plane, out,
-                     err, n_packets, chunk);
+  static const bool remap = !(getenv("M2S_XCD_REMAP") && atoi(getenv("M2S_XCD_REMAP")) == 0);
+  const uint32_t chunk = remap ? (blocks + 7) / 8 : 0;
+  hipLaunchKernelGGL((k_packet<GRID, MODE, SIGN, SEEDPASS>), dim3(remap ? chunk * 8 : blocks), dim3(256), 0, st, mesh, g,
+                     qs, perm, n_q, plane, out, err, n_packets, chunk, seed_in, seed_out);
 }
 template <bool GRID, int MODE, int SIGN>
 void launch_brute(hipStream_t st, const DeviceMesh& mesh, const GridParams& g, const float* q, uint32_t n_q,
@@ -376,20 +427,70 @@ uint32_t host_brick_count(const GridParams& g) {
 
 }  // namespace
 
-int launch_grid_distance(hipStream_t st, const DeviceMesh& mesh, const GridParams& g, int mode,
-                         const uint32_t* d_inside_plane, int algorithm, float* d_out, int* d_err) {
-  if (g.xe <= g.xb || g.n[1] == 0 || g.n[2] == 0) return 0;
+// Coarse lattice whose points sit at the centres of the `stride`-sized blocks of `fine`.
+static GridParams coarse_level(const GridParams& fine, uint32_t stride, uint32_t x_origin) {
+  GridParams c = fine;
+  for (int k = 0; k < 3; ++k) {
+    const uint32_t span = k == 0 ? fine.xe - fine.xb : fine.n[k];
+    c.n[k] = (span + stride - 1) / stride;
+    c.first[k] = fine.first[k] + (float)((k == 0 ? x_origin : 0u) + stride / 2) * fine.size[k];
+    c.size[k] = (float)stride * fine.size[k];
+  }
+  c.xb = 0;
+  c.xe = c.n[0];
+  c.out_off = 0;
+  return c;
+}
+
+size_t grid_distance_workspace_bytes(const GridParams& g) {
+  const size_t bricks = (size_t)host_brick_count(g);
+  return bricks * 4 + bricks / 16 + 4096;
+}
+
+int launch_grid_distance(Arena& ws, hipStream_t st, const DeviceMesh& mesh, const GridParams& g, int mode,
+                         const uint32_t* d_inside_plane, int algorithm, float* d_out, int* d_err,
+                         hipEvent_t ev_before_final) {
+  if (g.xe <= g.xb || g.n[1] == 0 || g.n[2] == 0) {
+    if (ev_before_final) M2S_HIP_CHECK(hipEventRecord(ev_before_final, st));
+    return 0;
+  }
   const uint32_t packets = host_brick_count(g);
   const bool brute = algorithm == 1;
+
+  // Hierarchical seeding (BVH path): level 2 = one point per 16^3 voxels (greedy seeds), level 1 = one
+  // point per 4^3 brick seeded from level 2; every fine packet then starts from the nearest triangle of
+  // its own brick centre.  ~1.6 % extra points; halves the nodes visited by the fine pass.
+  const uint32_t* seed1 = nullptr;
+  static const bool use_seeds = !(getenv("M2S_SEEDS") && atoi(getenv("M2S_SEEDS")) == 0);
+  if (!brute && mesh.n_tris && packets >= 64 && use_seeds) {
+    const GridParams g1 = coarse_level(g, 4, g.xb);
+    const uint32_t packets1 = host_brick_count(g1);
+    uint32_t* s1 = ws.take<uint32_t>(packets);
+    if (!s1) { set_error("internal: seed workspace too small"); return M2S_ERR_HIP_INTERNAL; }
+    const uint32_t* seed2 = nullptr;
+    if (packets1 >= 64) {
+      const GridParams g2 = coarse_level(g, 16, g.xb);
+      uint32_t* s2 = ws.take<uint32_t>(packets1);
+      if (!s2) { set_error("internal: seed workspace too small"); return M2S_ERR_HIP_INTERNAL; }
+      launch_packet<true, MODE_UNSIGNED, SIGN_NONE, true>(st, mesh, g2, nullptr, nullptr, 0, nullptr, nullptr, d_err,
+                                                          host_brick_count(g2), nullptr, s2);
+      seed2 = s2;
+    }
+    launch_packet<true, MODE_UNSIGNED, SIGN_NONE, true>(st, mesh, g1, nullptr, nullptr, 0, nullptr, nullptr, d_err, packets1,
+                                                        seed2, s1);
+    seed1 = s1;
+  }
+  if (ev_before_final) M2S_HIP_CHECK(hipEventRecord(ev_before_final, st));
+
   if (mode == MODE_UNSIGNED && d_inside_plane) {
     if (brute) launch_brute<true, MODE_UNSIGNED, SIGN_GRID_PLANE>(st, mesh, g, nullptr, 0, d_inside_plane, d_out, d_err, packets);
-    else launch_packet<true, MODE_UNSIGNED, SIGN_GRID_PLANE>(st, mesh, g, nullptr, nullptr, 0, d_inside_plane, d_out, d_err, packets);
+    else launch_packet<true, MODE_UNSIGNED, SIGN_GRID_PLANE>(st, mesh, g, nullptr, nullptr, 0, d_inside_plane, d_out, d_err, packets, seed1);
   } else if (mode == MODE_UNSIGNED) {
     if (brute) launch_brute<true, MODE_UNSIGNED, SIGN_NONE>(st, mesh, g, nullptr, 0, nullptr, d_out, d_err, packets);
-    else launch_packet<true, MODE_UNSIGNED, SIGN_NONE>(st, mesh, g, nullptr, nullptr, 0, nullptr, d_out, d_err, packets);
+    else launch_packet<true, MODE_UNSIGNED, SIGN_NONE>(st, mesh, g, nullptr, nullptr, 0, nullptr, d_out, d_err, packets, seed1);
   } else {
     if (brute) launch_brute<true, MODE_NORMAL_FOLD, SIGN_NONE>(st, mesh, g, nullptr, 0, nullptr, d_out, d_err, packets);
-    else launch_packet<true, MODE_NORMAL_FOLD, SIGN_NONE>(st, mesh, g, nullptr, nullptr, 0, nullptr, d_out, d_err, packets);
+    else launch_packet<true, MODE_NORMAL_FOLD, SIGN_NONE>(st, mesh, g, nullptr, nullptr, 0, nullptr, d_out, d_err, packets, seed1);
   }
   M2S_HIP_CHECK(hipGetLastError());
   return 0;
