@@ -74,12 +74,10 @@ __global__ __launch_bounds__(256) void k_tri_setup(const float* __restrict__ ver
     r.ax = a.x; r.ay = a.y; r.az = a.z; r.cls = tri_class(a, b, c);
     r.bx = b.x; r.by = b.y; r.bz = b.z; r.index = t;
     r.cx = c.x; r.cy = c.y; r.cz = c.z; r.pad0 = 0.0f;
-    // bounding sphere about the box centre; radius rounded outwards
+    r.abx = b.x - a.x; r.aby = b.y - a.y; r.abz = b.z - a.z; r.pad1 = 0.0f;
+    r.acx = c.x - a.x; r.acy = c.y - a.y; r.acz = c.z - a.z; r.pad2 = 0.0f;
+    r.bcx = c.x - b.x; r.bcy = c.y - b.y; r.bcz = c.z - b.z; r.pad3 = 0.0f;
     const float sx = 0.5f * (mn.x + mx.x), sy = 0.5f * (mn.y + mx.y), sz = 0.5f * (mn.z + mx.z);
-    auto d2 = [&](f3 p) { float dx = p.x - sx, dy = p.y - sy, dz = p.z - sz; return dx * dx + dy * dy + dz * dz; };
-    const float r2 = fmaxf(d2(a), fmaxf(d2(b), d2(c)));
-    r.sx = sx; r.sy = sy; r.sz = sz;
-    r.sr = sqrtf(r2) * 1.000001f + 1e-30f;
     raw[t] = r;
     boxes[t] = {mn.x, mn.y, mn.z, mx.x, mx.y, mx.z};
     const float cen[3] = {sx, sy, sz};
@@ -110,12 +108,13 @@ __device__ __forceinline__ uint64_t expand21(uint32_t v) {
   return x;
 }
 
-__global__ __launch_bounds__(256) void k_morton(const TriRec* __restrict__ raw, uint32_t n_tris,
+__global__ __launch_bounds__(256) void k_morton(const Box* __restrict__ boxes, uint32_t n_tris,
                                                 const int* __restrict__ scene, uint64_t* __restrict__ keys,
                                                 uint32_t* __restrict__ vals) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n_tris) return;
-  const float c[3] = {raw[t].sx, raw[t].sy, raw[t].sz};
+  const Box bx = boxes[t];
+  const float c[3] = {0.5f * (bx.mnx + bx.mxx), 0.5f * (bx.mny + bx.mxy), 0.5f * (bx.mnz + bx.mxz)};
   uint32_t q[3];
   for (int k = 0; k < 3; ++k) {
     const float lo = unord(scene[k]), hi = unord(scene[3 + k]);
@@ -380,7 +379,7 @@ int build_device_mesh(Arena& ws, hipStream_t st, const float* d_verts, size_t n_
   hipLaunchKernelGGL(k_init_scene, dim3(cdiv(2 * n_tris, B)), dim3(B), 0, st, scene, parent, 2 * n - 1);
   hipLaunchKernelGGL(k_tri_setup, dim3(cdiv(n_tris, B)), dim3(B), 0, st, d_verts, (uint32_t)n_verts, d_indices,
                      index_bytes, topology, (uint32_t)n_tris, raw, boxes, scene, d_err);
-  hipLaunchKernelGGL(k_morton, dim3(cdiv(n_tris, B)), dim3(B), 0, st, raw, (uint32_t)n_tris, scene, keys, vals);
+  hipLaunchKernelGGL(k_morton, dim3(cdiv(n_tris, B)), dim3(B), 0, st, boxes, (uint32_t)n_tris, scene, keys, vals);
   M2S_HIP_CHECK(rocprim::radix_sort_pairs(tmp, sort_tmp, keys, keys2, vals, order, n_tris, 0, 64, st));
   if (n > 1) hipLaunchKernelGGL(k_karras, dim3(cdiv(n_tris - 1, B)), dim3(B), 0, st, keys2, n, range, child, parent);
 

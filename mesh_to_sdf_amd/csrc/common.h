@@ -7,21 +7,24 @@
 namespace m2s {
 
 // ---- HBM layout --------------------------------------------------------------------------
-// Triangle record, 64 B, 64-B aligned, stored in Morton (= BVH leaf) order.  Every lane of a
+// Triangle record, 96 B, stored in Morton (= BVH leaf) order.  Every lane of a
 // wave tests the SAME triangle, so a record is fetched with wave-uniform (scalar) loads:
-// one s_load_dwordx16 per triangle; the record is therefore packed per triangle, while
+// a few s_load_dwordx4/x8 per triangle; the record is therefore packed per triangle, while
 // everything that is read lane-parallel (queries, outputs, bit planes) is SoA / linear.
-struct alignas(64) TriRec {
+struct alignas(32) TriRec {
   float ax, ay, az;
   uint32_t cls;        // geo.hip.h tri_class (degeneracy class of geo.rs:73-88)
   float bx, by, bz;
   uint32_t index;      // triangle index in Topology::get_triangles order (tie-break for Rtree)
   float cx, cy, cz;
   float pad0;
-  float sx, sy, sz;    // bounding sphere of the triangle: centre ...
-  float sr;            // ... and radius (conservative), for the cheap per-lane reject
+  // edge vectors exactly as geo.rs computes them per call (b.sub(a), c.sub(a), c.sub(b)): they are
+  // the same for all 64 lanes, so they are formed once at build time instead of on the VALU
+  float abx, aby, abz, pad1;
+  float acx, acy, acz, pad2;
+  float bcx, bcy, bcz, pad3;
 };
-static_assert(sizeof(TriRec) == 64, "TriRec must be 64 bytes");
+static_assert(sizeof(TriRec) == 96, "TriRec must be 96 bytes");
 
 // Stackless BVH node, 32 B, pre-order (depth-first) layout:
 //   the left child of node i is i+1; `skip` is the next node once the subtree of i is done

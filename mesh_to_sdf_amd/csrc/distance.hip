@@ -28,7 +28,7 @@ namespace m2s {
 namespace {
 
 constexpr float F32_MAX_C = 3.402823466e+38f;
-constexpr int TILE = 128;  // triangles per LDS tile in k_brute (8 KiB)
+constexpr int TILE = 128;  // triangles per LDS tile in k_brute (12 KiB)
 
 // ---- point sources -------------------------------------------------------------------------
 struct GridBrick {
@@ -75,15 +75,17 @@ struct Best {
 };
 
 template <int MODE, bool TRACK = false>
-__device__ __forceinline__ void eval_triangle(Best<MODE>& best, f3 p, f3 a, f3 b, f3 c, uint32_t cls, uint32_t index,
-                                              uint32_t slot = 0) {
+__device__ __forceinline__ void eval_triangle(Best<MODE>& best, f3 p, const TriRec& tr, uint32_t slot = 0) {
+  const f3 a = mk3(tr.ax, tr.ay, tr.az), b = mk3(tr.bx, tr.by, tr.bz), c = mk3(tr.cx, tr.cy, tr.cz);
+  const TriEdges e = {mk3(tr.abx, tr.aby, tr.abz), mk3(tr.acx, tr.acy, tr.acz), mk3(tr.bcx, tr.bcy, tr.bcz)};
+  const uint32_t cls = tr.cls, index = tr.index;
   if (MODE == MODE_UNSIGNED) {
-    const float d2 = point_triangle_dist2(p, a, b, c, cls);
+    const float d2 = point_triangle_dist2(p, a, b, c, e, cls);
     if (TRACK && d2 < best.d2) best.slot = slot;
     best.d2 = fminf(best.d2, d2);  // f32::min drops a NaN operand (default.rs:47)
   } else {
     bool positive;
-    const float d2 = point_triangle_dist2_signed(p, a, b, c, cls, &positive);
+    const float d2 = point_triangle_dist2_signed(p, a, b, c, e, cls, &positive);
     if (MODE == MODE_NORMAL_FOLD) {
       best.nan |= !(d2 == d2);  // the reference panics: "NaN distance" (lib.rs:257)
       best.d2 = fminf(best.d2, d2);
@@ -127,7 +129,8 @@ __device__ __forceinline__ float ext_dist2(f3 p, const NodeExt& e) {
   const float t = __builtin_fmaf(e.nz, vz, __builtin_fmaf(e.ny, vy, e.nx * vx));
   const float v2 = __builtin_fmaf(vz, vz, __builtin_fmaf(vy, vy, vx * vx));
   // l^2 = v2 - t^2 cancels when p sits over the disc centre: shave a few ulps of v2 off first
-  const float l2 = fmaxf(__builtin_fmaf(-1.0e-6f, v2, __builtin_fmaf(-t, t, v2)), 0.0f);
+  const float l2 = __builtin_fmaf(-1.0e-6f, v2, __builtin_fmaf(-t, t, v2));
+  // l2 < 0 (rounding) gives sqrt = NaN and fmaxf(NaN - R, 0) = 0: still a valid lower bound
   const float lat = fmaxf(__builtin_amdgcn_sqrtf(l2) - e.R, 0.0f);
   const float s = fmaxf(fmaxf(e.dlo - t, t - e.dhi), 0.0f);
   return __builtin_fmaf(s, s, lat * lat);
@@ -166,7 +169,8 @@ __global__ __launch_bounds__(256) void k_packet(DeviceMesh mesh, GridParams g, c
                                                 const uint32_t* __restrict__ perm, uint32_t n_q,
                                                 const uint32_t* __restrict__ plane, float* __restrict__ out,
                                                 int* __restrict__ err, uint32_t n_packets, uint32_t chunk,
-                                                const uint32_t* __restrict__ seed_in, uint32_t* __restrict__ seed_out) {
+                                                const uint32_t* __restrict__ seed_in, uint32_t* __restrict__ seed_out,
+                                                uint32_t seed_shift, uint32_t seed_ny, uint32_t seed_nz, uint32_t node_budget) {
   const int lane = threadIdx.x & 63;
   const uint32_t block = xcd_remap(blockIdx.x, chunk);
   const uint32_t packet = block * 4 + (threadIdx.x >> 6);
@@ -197,10 +201,15 @@ __global__ __launch_bounds__(256) void k_packet(DeviceMesh mesh, GridParams g, c
 
     if (seed_in != nullptr) {
       // seed: nearest triangle of this packet's centre, found by the coarser pass
-      const uint32_t slot = min(seed_in[packet], mesh.n_tris - 1);
+      uint32_t sidx = packet;
+      if (GRID) {  // 2^seed_shift bricks per axis share one seed point
+        const uint32_t nby = (g.n[1] + 3) >> 2, nbz = (g.n[2] + 3) >> 2;
+        const uint32_t bz = packet % nbz, by = (packet / nbz) % nby, bx = packet / (nbz * nby);
+        sidx = ((bx >> seed_shift) * seed_ny + (by >> seed_shift)) * seed_nz + (bz >> seed_shift);
+      }
+      const uint32_t slot = min(seed_in[sidx], mesh.n_tris - 1);
       const TriRec tr = mesh.tris[slot];
-      eval_triangle<MODE, SEEDPASS>(best, p, mk3(tr.ax, tr.ay, tr.az), mk3(tr.bx, tr.by, tr.bz), mk3(tr.cx, tr.cy, tr.cz),
-                                    tr.cls, tr.index, slot);
+      eval_triangle<MODE, SEEDPASS>(best, p, tr, slot);
     } else {
       // seed: greedy descent towards the packet's first point, evaluate that leaf for every lane
       const f3 c = {__shfl(p.x, 0), __shfl(p.y, 0), __shfl(p.z, 0)};
@@ -218,8 +227,7 @@ __global__ __launch_bounds__(256) void k_packet(DeviceMesh mesh, GridParams g, c
         nr = go_left ? nl : nrr;
       }
       const TriRec tr = mesh.tris[nr.tri];
-      eval_triangle<MODE, SEEDPASS>(best, p, mk3(tr.ax, tr.ay, tr.az), mk3(tr.bx, tr.by, tr.bz), mk3(tr.cx, tr.cy, tr.cz),
-                                    tr.cls, tr.index, (uint32_t)nr.tri);
+      eval_triangle<MODE, SEEDPASS>(best, p, tr, (uint32_t)nr.tri);
     }
 
     float thr = prune_bound(best.d2, slack);
@@ -232,13 +240,13 @@ __global__ __launch_bounds__(256) void k_packet(DeviceMesh mesh, GridParams g, c
       node = __builtin_amdgcn_readfirstlane(node);
       const NodeExt nr = mesh.ext[node];
       ++st_box;
+      if (SEEDPASS && st_box > node_budget) break;   // a seed may be approximate: bound the wave's latency
       const float ed2 = ext_dist2(p, nr);
       if (__ballot(!(ed2 > thr)) == 0ull) { node = nr.skip; continue; }   // a NaN bound keeps the node
       if (nr.tri >= 0) {
         ++st_leaf;
         const TriRec tr = mesh.tris[nr.tri];
-        eval_triangle<MODE, SEEDPASS>(best, p, mk3(tr.ax, tr.ay, tr.az), mk3(tr.bx, tr.by, tr.bz),
-                                      mk3(tr.cx, tr.cy, tr.cz), tr.cls, tr.index, (uint32_t)nr.tri);
+        eval_triangle<MODE, SEEDPASS>(best, p, tr, (uint32_t)nr.tri);
         thr = prune_bound(best.d2, slack);
         node = nr.skip;
       } else {
@@ -271,6 +279,7 @@ __global__ __launch_bounds__(256) void k_packet(DeviceMesh mesh, GridParams g, c
   if (MODE == MODE_NORMAL_FOLD && best.nan) atomicOr(err, ERRF_NAN);
   if (store) out[out_index] = finish<MODE>(best, negate);
 }
+
 
 // ---- k_brute --------------------------------------------------------------------------------
 template <bool GRID, int MODE, int SIGN>
@@ -305,16 +314,16 @@ __global__ __launch_bounds__(256) void k_brute(DeviceMesh mesh, GridParams g, co
   for (uint32_t t0 = 0; t0 < mesh.n_tris; t0 += TILE) {
     const uint32_t nt = min((uint32_t)TILE, mesh.n_tris - t0);
     __syncthreads();
-    {  // 128 records x 64 B = 512 float4; 256 threads x 2
+    {  // 128 records x 96 B = 768 float4; 256 threads x 3
       const float4* src = reinterpret_cast<const float4*>(mesh.tris + t0);
       float4* dst = reinterpret_cast<float4*>(tile);
-      for (uint32_t i = threadIdx.x; i < nt * 4; i += 256) dst[i] = src[i];
+      for (uint32_t i = threadIdx.x; i < nt * 6; i += 256) dst[i] = src[i];
     }
     __syncthreads();
     for (uint32_t k = 0; k < nt; ++k) {
       const TriRec& tr = tile[k];
       const f3 a = mk3(tr.ax, tr.ay, tr.az), b = mk3(tr.bx, tr.by, tr.bz), c = mk3(tr.cx, tr.cy, tr.cz);
-      eval_triangle<MODE>(best, p, a, b, c, tr.cls, tr.index);
+      eval_triangle<MODE>(best, p, tr);
       if (MODE == MODE_UNSIGNED && SIGN == SIGN_XRAY_ALL) {
         float t;
         hits[0] += ray_triangle_aligned<0>(p, a, b, c, &t) ? 1u : 0u;   // default.rs:35-37: every triangle
@@ -407,12 +416,14 @@ __global__ __launch_bounds__(256) void k_qgather(const float* __restrict__ q, co
 template <bool GRID, int MODE, int SIGN, bool SEEDPASS = false>
 void launch_packet(hipStream_t st, const DeviceMesh& mesh, const GridParams& g, const float4* qs, const uint32_t* perm,
                    uint32_t n_q, const uint32_t* plane, float* out, int* err, uint32_t n_packets,
-                   const uint32_t* seed_in = nullptr, uint32_t* seed_out = nullptr) {
+                   const uint32_t* seed_in = nullptr, uint32_t* seed_out = nullptr, uint32_t seed_shift = 0,
+                   uint32_t seed_ny = 0, uint32_t seed_nz = 0) {
+  static const uint32_t node_budget = getenv("M2S_SEED_BUDGET") ? (uint32_t)atoi(getenv("M2S_SEED_BUDGET")) : 0xffffffffu;
   const uint32_t blocks = (n_packets + 3) / 4;
   static const bool remap = !(getenv("M2S_XCD_REMAP") && atoi(getenv("M2S_XCD_REMAP")) == 0);
   const uint32_t chunk = remap ? (blocks + 7) / 8 : 0;
   hipLaunchKernelGGL((k_packet<GRID, MODE, SIGN, SEEDPASS>), dim3(remap ? chunk * 8 : blocks), dim3(256), 0, st, mesh, g,
-                     qs, perm, n_q, plane, out, err, n_packets, chunk, seed_in, seed_out);
+                     qs, perm, n_q, plane, out, err, n_packets, chunk, seed_in, seed_out, seed_shift, seed_ny, seed_nz, node_budget);
 }
 template <bool GRID, int MODE, int SIGN>
 void launch_brute(hipStream_t st, const DeviceMesh& mesh, const GridParams& g, const float* q, uint32_t n_q,
@@ -444,7 +455,7 @@ static GridParams coarse_level(const GridParams& fine, uint32_t stride, uint32_t
 
 size_t grid_distance_workspace_bytes(const GridParams& g) {
   const size_t bricks = (size_t)host_brick_count(g);
-  return bricks * 4 + bricks / 16 + 4096;
+  return bricks * 4 + bricks + 8192;
 }
 
 int launch_grid_distance(Arena& ws, hipStream_t st, const DeviceMesh& mesh, const GridParams& g, int mode,
@@ -461,36 +472,46 @@ int launch_grid_distance(Arena& ws, hipStream_t st, const DeviceMesh& mesh, cons
   // point per 4^3 brick seeded from level 2; every fine packet then starts from the nearest triangle of
   // its own brick centre.  ~1.6 % extra points; halves the nodes visited by the fine pass.
   const uint32_t* seed1 = nullptr;
-  static const bool use_seeds = !(getenv("M2S_SEEDS") && atoi(getenv("M2S_SEEDS")) == 0);
-  if (!brute && mesh.n_tris && packets >= 64 && use_seeds) {
-    const GridParams g1 = coarse_level(g, 4, g.xb);
+  uint32_t sh1 = 0, s1ny = 0, s1nz = 0;
+  static const int seed_stride = getenv("M2S_SEED_STRIDE") ? atoi(getenv("M2S_SEED_STRIDE")) : 4;   // 0 = off, 4, 8, 16
+  static const int seed_top = getenv("M2S_SEED_TOP") ? atoi(getenv("M2S_SEED_TOP")) : 0;            // seed the seed pass too
+  if (!brute && mesh.n_tris && packets >= 64 && seed_stride >= 4) {
+    const uint32_t S1 = (uint32_t)seed_stride;
+    sh1 = S1 == 4 ? 0 : (S1 == 8 ? 1 : 2);
+    const GridParams g1 = coarse_level(g, S1, g.xb);
     const uint32_t packets1 = host_brick_count(g1);
-    uint32_t* s1 = ws.take<uint32_t>(packets);
+    const size_t points1 = (size_t)g1.n[0] * g1.n[1] * g1.n[2];
+    uint32_t* s1 = ws.take<uint32_t>(points1);
     if (!s1) { set_error("internal: seed workspace too small"); return M2S_ERR_HIP_INTERNAL; }
     const uint32_t* seed2 = nullptr;
-    if (packets1 >= 64) {
-      const GridParams g2 = coarse_level(g, 16, g.xb);
-      uint32_t* s2 = ws.take<uint32_t>(packets1);
+    uint32_t s2ny = 0, s2nz = 0;
+    if (seed_top && packets1 >= 64) {
+      const GridParams g2 = coarse_level(g, 4 * S1, g.xb);   // one point per packet of level 1
+      uint32_t* s2 = ws.take<uint32_t>((size_t)g2.n[0] * g2.n[1] * g2.n[2]);
       if (!s2) { set_error("internal: seed workspace too small"); return M2S_ERR_HIP_INTERNAL; }
       launch_packet<true, MODE_UNSIGNED, SIGN_NONE, true>(st, mesh, g2, nullptr, nullptr, 0, nullptr, nullptr, d_err,
                                                           host_brick_count(g2), nullptr, s2);
       seed2 = s2;
+      s2ny = g2.n[1];
+      s2nz = g2.n[2];
     }
     launch_packet<true, MODE_UNSIGNED, SIGN_NONE, true>(st, mesh, g1, nullptr, nullptr, 0, nullptr, nullptr, d_err, packets1,
-                                                        seed2, s1);
+                                                        seed2, s1, 0, s2ny, s2nz);
     seed1 = s1;
+    s1ny = g1.n[1];
+    s1nz = g1.n[2];
   }
   if (ev_before_final) M2S_HIP_CHECK(hipEventRecord(ev_before_final, st));
 
   if (mode == MODE_UNSIGNED && d_inside_plane) {
     if (brute) launch_brute<true, MODE_UNSIGNED, SIGN_GRID_PLANE>(st, mesh, g, nullptr, 0, d_inside_plane, d_out, d_err, packets);
-    else launch_packet<true, MODE_UNSIGNED, SIGN_GRID_PLANE>(st, mesh, g, nullptr, nullptr, 0, d_inside_plane, d_out, d_err, packets, seed1);
+    else launch_packet<true, MODE_UNSIGNED, SIGN_GRID_PLANE>(st, mesh, g, nullptr, nullptr, 0, d_inside_plane, d_out, d_err, packets, seed1, nullptr, sh1, s1ny, s1nz);
   } else if (mode == MODE_UNSIGNED) {
     if (brute) launch_brute<true, MODE_UNSIGNED, SIGN_NONE>(st, mesh, g, nullptr, 0, nullptr, d_out, d_err, packets);
-    else launch_packet<true, MODE_UNSIGNED, SIGN_NONE>(st, mesh, g, nullptr, nullptr, 0, nullptr, d_out, d_err, packets, seed1);
+    else launch_packet<true, MODE_UNSIGNED, SIGN_NONE>(st, mesh, g, nullptr, nullptr, 0, nullptr, d_out, d_err, packets, seed1, nullptr, sh1, s1ny, s1nz);
   } else {
     if (brute) launch_brute<true, MODE_NORMAL_FOLD, SIGN_NONE>(st, mesh, g, nullptr, 0, nullptr, d_out, d_err, packets);
-    else launch_packet<true, MODE_NORMAL_FOLD, SIGN_NONE>(st, mesh, g, nullptr, nullptr, 0, nullptr, d_out, d_err, packets, seed1);
+    else launch_packet<true, MODE_NORMAL_FOLD, SIGN_NONE>(st, mesh, g, nullptr, nullptr, 0, nullptr, d_out, d_err, packets, seed1, nullptr, sh1, s1ny, s1nz);
   }
   M2S_HIP_CHECK(hipGetLastError());
   return 0;

@@ -52,8 +52,7 @@ M2S_HD uint32_t tri_class(f3 a, f3 b, f3 c) {
 }
 
 // geo.rs:141-151
-M2S_HD f3 closest_point_segment(f3 p, f3 a, f3 b) {
-  f3 ab = sub3(b, a);
+M2S_HD f3 closest_point_segment(f3 p, f3 a, f3 ab /* = b.sub(a) */) {
   float m = dot3(ab, ab);
   f3 ap = sub3(p, a);
   float s12 = dot3(ab, ap) / m;
@@ -63,9 +62,7 @@ M2S_HD f3 closest_point_segment(f3 p, f3 a, f3 b) {
 
 // geo.rs:90-137 for a non-degenerate-class triangle.  One IEEE division per call, as in the
 // reference (each region divides once; the numerator / denominator pair is selected first).
-M2S_HD f3 closest_point_regular(f3 p, f3 a, f3 b, f3 c) {
-  const f3 ab = sub3(b, a);
-  const f3 ac = sub3(c, a);
+M2S_HD f3 closest_point_regular(f3 p, f3 a, f3 b, f3 c, f3 ab, f3 ac, f3 bc) {
   const f3 ap = sub3(p, a);
   const float d1 = dot3(ab, ap);
   const float d2 = dot3(ac, ap);
@@ -92,7 +89,7 @@ M2S_HD f3 closest_point_regular(f3 p, f3 a, f3 b, f3 c) {
   //   AB: d1/(d1-d3)   AC: d2/(d2-d6)   BC: (d4-d3)/((d4-d3)+(d5-d6))   interior: 1/(va+vb+vc)
   float num = 1.0f, den = va + vb + vc;
   f3 base = a, dir = ab;
-  if (rBC) { num = d43; den = d43 + d56; base = b; dir = sub3(c, b); }
+  if (rBC) { num = d43; den = d43 + d56; base = b; dir = bc; }
   if (rAC) { num = d2; den = d2 - d6; base = a; dir = ac; }
   if (rAB) { num = d1; den = d1 - d3; base = a; dir = ab; }
   const float r = num / den;
@@ -109,28 +106,34 @@ M2S_HD f3 closest_point_regular(f3 p, f3 a, f3 b, f3 c) {
 }
 
 // Closest point for any triangle class (cls is wave-uniform: one triangle per wave step).
-M2S_HD f3 closest_point_triangle(f3 p, f3 a, f3 b, f3 c, uint32_t cls) {
-  if (cls == TRI_REGULAR) return closest_point_regular(p, a, b, c);
+// ab = b.sub(a), ac = c.sub(a), bc = c.sub(b): the edge vectors geo.rs forms inside each call.
+struct TriEdges {
+  f3 ab, ac, bc;
+};
+M2S_HD TriEdges tri_edges(f3 a, f3 b, f3 c) { return {sub3(b, a), sub3(c, a), sub3(c, b)}; }
+
+M2S_HD f3 closest_point_triangle(f3 p, f3 a, f3 b, f3 c, const TriEdges& e, uint32_t cls) {
+  if (cls == TRI_REGULAR) return closest_point_regular(p, a, b, c, e.ab, e.ac, e.bc);
   if (cls == TRI_POINT) return a;
-  if (cls == TRI_SEG_AC) return closest_point_segment(p, a, c);
-  return closest_point_segment(p, a, b);
+  if (cls == TRI_SEG_AC) return closest_point_segment(p, a, e.ac);
+  return closest_point_segment(p, a, e.ab);
 }
 
 // geo.rs:33-37 — squared distance dot(p-n, p-n).  sqrt is monotone, so the minimum over
 // triangles of geo.rs:26-30's sqrt(dot) is sqrt(min dot): kernels minimise d2 and take ONE
 // correctly rounded sqrt at the end, which gives the identical f32.
-M2S_HD float point_triangle_dist2(f3 p, f3 a, f3 b, f3 c, uint32_t cls) {
-  const f3 n = closest_point_triangle(p, a, b, c, cls);
+M2S_HD float point_triangle_dist2(f3 p, f3 a, f3 b, f3 c, const TriEdges& e, uint32_t cls) {
+  const f3 n = closest_point_triangle(p, a, b, c, e, cls);
   const f3 d = sub3(p, n);
   return dot3(d, d);
 }
 
 // geo.rs:43-56 — returns d2 and whether the reference's signed distance is positive
 // (direction . ((b-a) x (c-a)) > 0, normal not normalised; == 0 counts as negative).
-M2S_HD float point_triangle_dist2_signed(f3 p, f3 a, f3 b, f3 c, uint32_t cls, bool* positive) {
-  const f3 n = closest_point_triangle(p, a, b, c, cls);
+M2S_HD float point_triangle_dist2_signed(f3 p, f3 a, f3 b, f3 c, const TriEdges& e, uint32_t cls, bool* positive) {
+  const f3 n = closest_point_triangle(p, a, b, c, e, cls);
   const f3 d = sub3(p, n);
-  const f3 nrm = cross3(sub3(b, a), sub3(c, a));
+  const f3 nrm = cross3(e.ab, e.ac);
   *positive = dot3(d, nrm) > 0.0f;
   return dot3(d, d);
 }

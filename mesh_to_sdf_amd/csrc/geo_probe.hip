@@ -7,12 +7,12 @@ using namespace m2s;
 extern "C" {
 float probe_dist2(const float* p, const float* a, const float* b, const float* c) {
   f3 A = mk3(a[0], a[1], a[2]), B = mk3(b[0], b[1], b[2]), Cc = mk3(c[0], c[1], c[2]);
-  return point_triangle_dist2(mk3(p[0], p[1], p[2]), A, B, Cc, tri_class(A, B, Cc));
+  return point_triangle_dist2(mk3(p[0], p[1], p[2]), A, B, Cc, tri_edges(A, B, Cc), tri_class(A, B, Cc));
 }
 float probe_dist2_signed(const float* p, const float* a, const float* b, const float* c, int* positive) {
   f3 A = mk3(a[0], a[1], a[2]), B = mk3(b[0], b[1], b[2]), Cc = mk3(c[0], c[1], c[2]);
   bool pos;
-  float d2 = point_triangle_dist2_signed(mk3(p[0], p[1], p[2]), A, B, Cc, tri_class(A, B, Cc), &pos);
+  float d2 = point_triangle_dist2_signed(mk3(p[0], p[1], p[2]), A, B, Cc, tri_edges(A, B, Cc), tri_class(A, B, Cc), &pos);
   *positive = pos ? 1 : 0;
   return d2;
 }
