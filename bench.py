@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--sign", default="Raycast", choices=["Raycast", "Normal"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=25.0, help="budget for the CPU baseline sample")
+    ap.add_argument("--chunks", type=int, default=0, help="x-chunks per step whose all-gathers overlap compute (0 = auto)")
     return ap.parse_args()
 
 
@@ -104,19 +105,29 @@ def main():
     out = torch.empty(n ** 3, dtype=torch.float32, device=dev)
     x0, x1 = slab_bounds(n, world, rank)
 
-    def step(t=None):
-        generate_grid_sdf_sharded(dv, topo, grid, sign, out=out, timings=t)
+    chunks = args.chunks if args.chunks > 0 else (4 if world > 1 else 1)
+
+    def step():
+        # one complete call: LBVH build, sign planes, seed passes, nearest-triangle launches for this rank's
+        # pieces, and the all-gathers (asynchronous per chunk, overlapping the next chunk's compute)
+        _, mesh = generate_grid_sdf_sharded(dv, topo, grid, sign, out=out, chunks=chunks, return_mesh=True)
+        return mesh
+
+    def finish(mesh):
+        t = mesh.drain_timings()   # waits for the launches of this step, reads their HIP-event durations
+        mesh.close()
+        return t
 
     for _ in range(args.warmup):
-        step()
+        finish(step())
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    tims = [M2STimings() for _ in range(args.steps)]
+    tims = []
     t0 = time.perf_counter()
     for k in range(args.steps):
-        step(tims[k])
+        tims.append(finish(step()))
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -127,17 +138,20 @@ def main():
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = float(te.item())
 
+    # phase breakdown of one extra, untimed, synchronous one-shot call on this rank's whole slab
+    ph = M2STimings()
+    generate_grid_sdf(dv, topo, grid, sign, x_slab=(x0, x1), out=out, timings=ph)
+
     if rank == 0:
         ms_per_step = elapsed * 1e3 / args.steps
         voxels = n ** 3
         value = voxels * args.steps / elapsed / 1e6
-        dist_ms = float(np.mean([t.distance_ms for t in tims]))
+        launches = int(sum(t.distance_launches for t in tims))
+        dist_ms = float(sum(t.distance_ms for t in tims)) / max(launches, 1)   # average launch of the dominant kernel
         build_ms = float(np.mean([t.accel_build_ms for t in tims]))
-        sign_ms = float(np.mean([t.sign_ms for t in tims]))
-        seed_ms = float(np.mean([t.seed_ms for t in tims]))
-        total_ms = float(np.mean([t.total_ms for t in tims]))
+        sign_ms, seed_ms, total_ms = float(ph.sign_ms), float(ph.seed_ms), float(ph.total_ms)
         n_tris = int(tims[0].n_triangles)
-        slab_voxels = (x1 - x0) * n * n
+        slab_voxels = float(sum(t.n_units for t in tims)) / max(launches, 1)      # voxels one launch processes
         # algorithmic bytes of one launch of the dominant kernel:
         # 4 B per voxel written + the mesh read once (12 B per vertex + 12 B per triangle)
         b_alg = 4.0 * slab_voxels + 12.0 * v.shape[0] + 12.0 * n_tris
@@ -169,9 +183,11 @@ def main():
                 "mesh": args.mesh,
                 "sign_method": args.sign,
                 "parallelism": f"xslab{world}",
+                "gather_chunks": chunks,
             },
             "phases_ms": {"accel_build": round(build_ms, 4), "sign_planes": round(sign_ms, 4), "seed_passes": round(seed_ms, 4),
-                          "distance": round(dist_ms, 4), "device_total": round(total_ms, 4)},
+                          "distance_per_launch": round(dist_ms, 4), "launches_per_step": launches // max(args.steps, 1),
+                          "one_shot_device_total": round(total_ms, 4)},
             "roofline": {
                 "bound": "hbm",
                 "kernel": "k_packet<GRID, MODE_UNSIGNED, SIGN_GRID_PLANE>",

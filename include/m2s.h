@@ -123,6 +123,26 @@ int m2s_generate_grid_sdf(const float* vertices, size_t n_vertices, const void* 
                           int index_bytes, int topology, const m2s_grid* grid, int sign_method, float* out,
                           const m2s_opts* opts);
 
+/* ---- persistent mesh (optional) ------------------------------------------------------------------
+ * The reference rebuilds its acceleration structures inside every call (generate/grid.rs:95-111,
+ * generic/rtree_bvh.rs:109-119).  A caller that queries the same mesh repeatedly — the reference's
+ * own client regenerates the grid on every parameter change, mesh_to_sdf_client/src/sdf.rs:32-137 —
+ * or that splits one grid into several x-slab calls can build once and reuse:
+ * triangle records + LBVH stay resident on `opts->device`; the sign planes of the last grid are cached.
+ * Results are identical to the one-shot entry points. */
+typedef struct m2s_mesh m2s_mesh;
+int m2s_mesh_create(const float* vertices, size_t n_vertices, const void* indices, size_t n_indices, int index_bytes,
+                    int topology, const m2s_opts* opts, m2s_mesh** out_mesh);
+void m2s_mesh_destroy(m2s_mesh* mesh);
+size_t m2s_mesh_triangle_count(const m2s_mesh* mesh);
+int m2s_mesh_generate_grid_sdf(m2s_mesh* mesh, const m2s_grid* grid, int sign_method, float* out, const m2s_opts* opts);
+int m2s_mesh_generate_sdf(m2s_mesh* mesh, const float* queries, size_t n_queries, int accel, int sign_method, float* out,
+                          size_t* n_out, const m2s_opts* opts);
+/* Device-memory calls made with opts->synchronous == 0 return before the GPU has finished and report no
+ * per-call timings; this sums the dominant-kernel durations of all such calls since the last drain
+ * (distance_ms, distance_launches, n_units; accel_build_ms = the mesh build).  Blocks until they finished. */
+int m2s_mesh_drain_timings(m2s_mesh* mesh, m2s_timings* timings);
+
 /* Grid helpers with the reference's exact f32 arithmetic (so callers need not re-derive it).
  * m2s_grid_from_bounding_box — Grid::from_bounding_box, grid.rs:59-74.
  * m2s_grid_cell_center      — Grid::get_cell_center,   grid.rs:135-141.

@@ -63,6 +63,12 @@ EXPORTS = [
     "m2s_device_count",
     "m2s_last_error",
     "m2s_release_workspace",
+    "m2s_mesh_create",
+    "m2s_mesh_destroy",
+    "m2s_mesh_triangle_count",
+    "m2s_mesh_generate_grid_sdf",
+    "m2s_mesh_generate_sdf",
+    "m2s_mesh_drain_timings",
 ]
 
 
@@ -112,6 +118,20 @@ def lib():
         L.m2s_device_count.restype = C.c_int
         L.m2s_last_error.restype = C.c_char_p
         L.m2s_release_workspace.restype = None
+        L.m2s_mesh_create.restype = C.c_int
+        L.m2s_mesh_create.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.POINTER(M2SOpts),
+                                      C.POINTER(C.c_void_p)]
+        L.m2s_mesh_destroy.restype = None
+        L.m2s_mesh_destroy.argtypes = [C.c_void_p]
+        L.m2s_mesh_triangle_count.restype = C.c_size_t
+        L.m2s_mesh_triangle_count.argtypes = [C.c_void_p]
+        L.m2s_mesh_generate_grid_sdf.restype = C.c_int
+        L.m2s_mesh_generate_grid_sdf.argtypes = [C.c_void_p, C.POINTER(M2SGrid), C.c_int, C.c_void_p, C.POINTER(M2SOpts)]
+        L.m2s_mesh_generate_sdf.restype = C.c_int
+        L.m2s_mesh_generate_sdf.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p,
+                                            C.POINTER(C.c_size_t), C.POINTER(M2SOpts)]
+        L.m2s_mesh_drain_timings.restype = C.c_int
+        L.m2s_mesh_drain_timings.argtypes = [C.c_void_p, C.POINTER(M2STimings)]
         _lib = L
     return _lib
 

@@ -215,12 +215,12 @@ class _Args:
                 self.keep.append(q)
         self.topology = topology.kind
 
-    def opts(self, timings=None, algorithm=0, x_begin=0, x_end=0):
+    def opts(self, timings=None, algorithm=0, x_begin=0, x_end=0, synchronous=True):
         o = M2SOpts()
         o.struct_size = C.sizeof(M2SOpts)
         o.algorithm = int(algorithm)
         o.x_begin, o.x_end = int(x_begin), int(x_end)
-        o.synchronous = 1
+        o.synchronous = 1 if synchronous else 0
         if timings is not None:
             o.timings = C.pointer(timings)
         if self.device:
@@ -285,3 +285,90 @@ def generate_grid_sdf(vertices, indices: Topology, grid: Grid, sign_method: Sign
     if rc != _lib.M2S_OK:
         _raise(rc)
     return out
+
+
+class Mesh:
+    """Persistent mesh (include/m2s.h `m2s_mesh`): triangle records + LBVH built once and kept on the
+    device; `generate_grid_sdf` / `generate_sdf` then skip the build, and the sign planes of the last
+    grid are cached.  Results are identical to the one-shot functions.  The reference rebuilds its
+    trees in every call (generate/grid.rs:95-111); its client regenerates on every parameter change
+    (mesh_to_sdf_client/src/sdf.rs:32-137), which is what this object is for."""
+
+    def __init__(self, vertices, indices: Topology):
+        self._a = _Args(vertices, indices)
+        self._h = C.c_void_p()
+        o = self._a.opts()
+        rc = _lib.lib().m2s_mesh_create(self._a.p_verts, self._a.n_verts, self._a.p_idx, self._a.n_idx, self._a.index_bytes,
+                                        self._a.topology, C.byref(o), C.byref(self._h))
+        if rc != _lib.M2S_OK:
+            self._h = C.c_void_p()
+            _raise(rc)
+
+    @property
+    def device(self):
+        return self._a.device
+
+    def triangle_count(self):
+        return int(_lib.lib().m2s_mesh_triangle_count(self._h))
+
+    def generate_grid_sdf(self, grid: Grid, sign_method: SignMethod = SignMethod.Raycast, *, timings: M2STimings = None,
+                          algorithm: int = 0, x_slab: Sequence[int] = None, out=None, synchronous: bool = True):
+        a = self._a
+        total = grid.get_total_cell_count()
+        if out is None:
+            out = a.torch.empty(total, dtype=a.torch.float32, device=a.dev) if a.device else np.empty(total, np.float32)
+        p_out = (out.data_ptr() if a.device else out.ctypes.data) if total else None
+        xb, xe = (0, 0) if x_slab is None else (int(x_slab[0]), int(x_slab[1]))
+        if x_slab is not None and xb == xe:
+            return out
+        o = a.opts(timings, algorithm, xb, xe, synchronous or not a.device)
+        rc = _lib.lib().m2s_mesh_generate_grid_sdf(self._h, C.byref(grid._g), int(sign_method), p_out, C.byref(o))
+        if rc != _lib.M2S_OK:
+            _raise(rc)
+        return out
+
+    def generate_sdf(self, query_points, acceleration_method: AccelerationMethod = None, *, timings: M2STimings = None,
+                     algorithm: int = 0):
+        am = acceleration_method if acceleration_method is not None else AccelerationMethod.RtreeBvh
+        a = self._a
+        if a.device:
+            q = query_points if _is_torch(query_points) else a.torch.as_tensor(np.asarray(query_points, np.float32), device=a.dev)
+            q = q.detach().to(device=a.dev, dtype=a.torch.float32).contiguous().reshape(-1, 3)
+            n_q, p_q = q.shape[0], (q.data_ptr() if q.numel() else None)
+            out = a.torch.empty(n_q, dtype=a.torch.float32, device=a.dev)
+            p_out = out.data_ptr() if n_q else None
+        else:
+            q = np.ascontiguousarray(np.asarray(query_points, np.float32)).reshape(-1, 3)
+            n_q, p_q = q.shape[0], (q.ctypes.data if q.size else None)
+            out = np.empty(n_q, np.float32)
+            p_out = out.ctypes.data if n_q else None
+        n_out = C.c_size_t(0)
+        o = a.opts(timings, algorithm)
+        rc = _lib.lib().m2s_mesh_generate_sdf(self._h, p_q, n_q, int(am.kind), int(am.sign), p_out, C.byref(n_out), C.byref(o))
+        if rc != _lib.M2S_OK:
+            _raise(rc)
+        return out[: n_out.value]
+
+    def drain_timings(self) -> M2STimings:
+        t = M2STimings()
+        rc = _lib.lib().m2s_mesh_drain_timings(self._h, C.byref(t))
+        if rc != _lib.M2S_OK:
+            _raise(rc)
+        return t
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            _lib.lib().m2s_mesh_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()

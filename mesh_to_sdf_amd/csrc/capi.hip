@@ -6,6 +6,7 @@
 #include <cstring>
 #include <map>
 #include <mutex>
+#include <vector>
 
 #include "../../include/m2s.h"
 #include "common.h"
@@ -29,6 +30,8 @@ struct DeviceState {
   hipStream_t stream = nullptr;
   hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   int* h_err = nullptr;  // pinned
+  char* spare_mesh = nullptr;  // last destroyed m2s_mesh block, recycled by the next m2s_mesh_create
+  size_t spare_mesh_bytes = 0;
 };
 
 std::mutex g_mu;
@@ -179,8 +182,97 @@ int finish_call(const CallCtx& c, DeviceState& st, int* d_err, m2s_timings* t, s
   return M2S_OK;
 }
 
+
+// Seed passes + dominant launch (+ optional M2S_STATS counters); records ev[4] before and ev[3] after
+// the dominant launch.
+int run_grid_distance(Arena& ws, const CallCtx& c, DeviceState& st, DeviceMesh mesh, const GridParams& g, int sign_method,
+                      const uint32_t* plane, float* d_out, int* d_err) {
+  unsigned long long* d_stats = nullptr;
+  if (getenv("M2S_STATS")) {
+    d_stats = ws.take<unsigned long long>(8);
+    unsigned long long init[8] = {0, 0, 0, 0, 0, 0, 0, (unsigned long long)atoi(getenv("M2S_STATS"))};
+    M2S_HIP_CHECK(hipMemcpyAsync(d_stats, init, 64, hipMemcpyHostToDevice, c.stream));
+    M2S_HIP_CHECK(hipStreamSynchronize(c.stream));
+    mesh.stats = d_stats;
+  }
+  int rc = launch_grid_distance(ws, c.stream, mesh, g, sign_method == M2S_SIGN_RAYCAST ? MODE_UNSIGNED : MODE_NORMAL_FOLD,
+                                plane, c.algorithm, d_out, d_err, st.ev[4]);
+  if (rc) return rc;
+  M2S_HIP_CHECK(hipEventRecord(st.ev[3], c.stream));
+  if (d_stats) {
+    unsigned long long h[8];
+    M2S_HIP_CHECK(hipMemcpyAsync(h, d_stats, 64, hipMemcpyDeviceToHost, c.stream));
+    M2S_HIP_CHECK(hipStreamSynchronize(c.stream));
+    const double w = h[3] ? (double)h[3] : 1.0;
+    fprintf(stderr, "[m2s stats] packets %llu: per packet node tests %.1f, exact triangle tests %.1f\n", h[3], h[0] / w, h[2] / w);
+  }
+  return 0;
+}
+
+
+// AccelerationMethod + SignMethod -> kernel mode, sign source, algorithm (include/m2s.h lists the rules).
+void select_generic_mode(int accel, int sign_method, int req_algorithm, int* mode, int* sign_src, int* algorithm) {
+  *mode = MODE_UNSIGNED;
+  *sign_src = SIGN_NONE;
+  *algorithm = req_algorithm;
+  switch (accel) {
+    case M2S_ACCEL_NONE:   // no acceleration structure in the reference either: literal brute force
+      *algorithm = 1;
+      if (sign_method == M2S_SIGN_RAYCAST) { *mode = MODE_UNSIGNED; *sign_src = SIGN_XRAY_ALL; }
+      else *mode = MODE_NORMAL_FOLD;
+      break;
+    case M2S_ACCEL_BVH:
+      if (sign_method == M2S_SIGN_RAYCAST) { *mode = MODE_UNSIGNED; *sign_src = SIGN_RAYS3; }
+      else *mode = MODE_NORMAL_FOLD;
+      break;
+    case M2S_ACCEL_RTREE: *mode = MODE_NEAREST_NORMAL; break;
+    default: *mode = MODE_UNSIGNED; *sign_src = SIGN_RAYS3; break;
+  }
+}
+
+int fill_grid_params(const m2s_grid* grid, const m2s_opts* opts, GridParams* g, size_t* slab_cells) {
+  const uint64_t gx = grid->cell_count[0], gy = grid->cell_count[1], gz = grid->cell_count[2];
+  if (gx >= 0x7fffffffull || gy >= 0x7fffffffull || gz >= 0x7fffffffull) return fail(M2S_ERR_BAD_ARG, "cell_count too large");
+  const uint64_t xb = opts ? opts->x_begin : 0, xe = (opts && opts->x_end) ? opts->x_end : gx;
+  if (xb > xe || xe > gx) return fail(M2S_ERR_BAD_ARG, "x-slab [%llu,%llu) outside [0,%llu)", (unsigned long long)xb, (unsigned long long)xe, (unsigned long long)gx);
+  for (int k = 0; k < 3; ++k) {
+    g->first[k] = grid->first_cell[k];
+    g->size[k] = grid->cell_size[k];
+    g->n[k] = (uint32_t)grid->cell_count[k];
+  }
+  g->xb = (uint32_t)xb;
+  g->xe = (uint32_t)xe;
+  g->nzw = (uint32_t)((gz + 31) / 32);
+  g->out_off = 0;
+  *slab_cells = (size_t)(xe - xb) * gy * gz;
+  return 0;
+}
+
 }  // namespace
 }  // namespace m2s
+
+// Persistent mesh: triangle records + LBVH resident on one device, reusable across calls
+// (it also lets one step be split into several slab calls whose all-gathers
+// overlap the next slab's compute).  Caches the sign planes of the last grid it was used with.
+struct m2s_mesh {
+  int device = -1;
+  char* mem = nullptr;
+  size_t mem_bytes = 0;
+  m2s::DeviceMesh dm{};
+  size_t n_tris = 0;
+  float build_ms = 0.0f;
+  bool plane_valid = false;
+  m2s_grid plane_grid{};
+  char* plane_mem = nullptr;
+  size_t plane_bytes = 0;
+  const uint32_t* plane = nullptr;
+  struct Pending {
+    hipEvent_t a, b;
+    uint64_t units;
+  };
+  std::vector<Pending> pending;  // dominant-launch event pairs of asynchronous calls, not yet read
+  std::vector<hipEvent_t> free_events;
+};
 
 using namespace m2s;
 
@@ -210,6 +302,9 @@ void m2s_release_workspace(void) {
     if (kv.second.base) (void)hipFree(kv.second.base);
     kv.second.base = nullptr;
     kv.second.cap = 0;
+    if (kv.second.spare_mesh) (void)hipFree(kv.second.spare_mesh);
+    kv.second.spare_mesh = nullptr;
+    kv.second.spare_mesh_bytes = 0;
   }
 }
 
@@ -246,13 +341,12 @@ int m2s_generate_grid_sdf(const float* vertices, size_t n_vertices, const void* 
   if (sign_method != M2S_SIGN_RAYCAST && sign_method != M2S_SIGN_NORMAL) return fail(M2S_ERR_BAD_ARG, "bad sign_method %d", sign_method);
   int rc = check_mesh_args(vertices, n_vertices, indices, n_indices, index_bytes, topology);
   if (rc) return rc;
-  const uint64_t nx = grid->cell_count[0], ny = grid->cell_count[1], nz = grid->cell_count[2];
-  if (nx >= 0x7fffffffull || ny >= 0x7fffffffull || nz >= 0x7fffffffull) return fail(M2S_ERR_BAD_ARG, "cell_count too large");
   const size_t n_tris = m2s_triangle_count(n_vertices, n_indices, indices != nullptr, topology);
-
-  const uint64_t xb = opts ? opts->x_begin : 0, xe = (opts && opts->x_end) ? opts->x_end : nx;
-  if (xb > xe || xe > nx) return fail(M2S_ERR_BAD_ARG, "x-slab [%llu,%llu) outside [0,%llu)", (unsigned long long)xb, (unsigned long long)xe, (unsigned long long)nx);
-  const size_t slab_cells = (size_t)(xe - xb) * ny * nz;
+  GridParams g;
+  size_t slab_cells = 0;
+  rc = fill_grid_params(grid, opts, &g, &slab_cells);
+  if (rc) return rc;
+  const uint64_t ny = grid->cell_count[1], nz = grid->cell_count[2], xb = g.xb;
   if (slab_cells == 0) {  // a grid without cells: the reference returns an empty Vec
     if (opts && opts->timings) memset(opts->timings, 0, sizeof(*opts->timings));
     return M2S_OK;
@@ -263,17 +357,6 @@ int m2s_generate_grid_sdf(const float* vertices, size_t n_vertices, const void* 
   DeviceState* st = nullptr;
   rc = resolve_ctx(opts, &c, &st);
   if (rc) return rc;
-
-  GridParams g;
-  for (int k = 0; k < 3; ++k) {
-    g.first[k] = grid->first_cell[k];
-    g.size[k] = grid->cell_size[k];
-    g.n[k] = (uint32_t)grid->cell_count[k];
-  }
-  g.xb = (uint32_t)xb;
-  g.xe = (uint32_t)xe;
-  g.nzw = (uint32_t)((nz + 31) / 32);
-  g.out_off = 0;
 
   size_t need = bvh_workspace_bytes(n_tris) + 4096;
   if (sign_method == M2S_SIGN_RAYCAST) need += sign_workspace_bytes(g);
@@ -302,14 +385,6 @@ int m2s_generate_grid_sdf(const float* vertices, size_t n_vertices, const void* 
   DeviceMesh mesh;
   rc = build_device_mesh(ws, c.stream, sm.d_verts, n_vertices, sm.d_indices, n_indices, index_bytes, topology, n_tris, d_err, &mesh);
   if (rc) return rc;
-  unsigned long long* d_stats = nullptr;
-  if (getenv("M2S_STATS")) {
-    d_stats = ws.take<unsigned long long>(8);
-    unsigned long long init[8] = {0, 0, 0, 0, 0, 0, 0, (unsigned long long)atoi(getenv("M2S_STATS"))};
-    M2S_HIP_CHECK(hipMemcpyAsync(d_stats, init, 64, hipMemcpyHostToDevice, c.stream));
-    M2S_HIP_CHECK(hipStreamSynchronize(c.stream));
-    mesh.stats = d_stats;
-  }
   M2S_HIP_CHECK(hipEventRecord(st->ev[1], c.stream));
   const uint32_t* plane = nullptr;
   if (sign_method == M2S_SIGN_RAYCAST) {
@@ -317,20 +392,10 @@ int m2s_generate_grid_sdf(const float* vertices, size_t n_vertices, const void* 
     if (rc) return rc;
   }
   M2S_HIP_CHECK(hipEventRecord(st->ev[2], c.stream));
-  rc = launch_grid_distance(ws, c.stream, mesh, g, sign_method == M2S_SIGN_RAYCAST ? MODE_UNSIGNED : MODE_NORMAL_FOLD, plane,
-                            c.algorithm, d_out, d_err, st->ev[4]);
+  rc = run_grid_distance(ws, c, *st, mesh, g, sign_method, plane, d_out, d_err);
   if (rc) return rc;
-  M2S_HIP_CHECK(hipEventRecord(st->ev[3], c.stream));
   if (c.mem_kind == M2S_MEM_HOST)
     M2S_HIP_CHECK(hipMemcpyAsync(out + (size_t)xb * ny * nz, d_slab, slab_cells * 4, hipMemcpyDeviceToHost, c.stream));
-  if (d_stats) {
-    unsigned long long h[8];
-    M2S_HIP_CHECK(hipMemcpyAsync(h, d_stats, 64, hipMemcpyDeviceToHost, c.stream));
-    M2S_HIP_CHECK(hipStreamSynchronize(c.stream));
-    const double w = h[3] ? (double)h[3] : 1.0;
-    fprintf(stderr, "[m2s stats] packets %llu: per packet box tests %.1f, oriented-bound tests %.1f, exact triangle tests %.1f\n",
-            h[3], h[0] / w, h[1] / w, h[2] / w);
-  }
   return finish_call(c, *st, d_err, c.timings, n_tris, slab_cells, sign_method == M2S_SIGN_RAYCAST, true);
 }
 
@@ -357,20 +422,8 @@ int m2s_generate_sdf(const float* vertices, size_t n_vertices, const void* indic
   rc = resolve_ctx(opts, &c, &st);
   if (rc) return rc;
 
-  int mode = MODE_UNSIGNED, sign_src = SIGN_NONE, algorithm = c.algorithm;
-  switch (accel) {
-    case M2S_ACCEL_NONE:   // no acceleration structure in the reference either: literal brute force
-      algorithm = 1;
-      if (sign_method == M2S_SIGN_RAYCAST) { mode = MODE_UNSIGNED; sign_src = SIGN_XRAY_ALL; }
-      else mode = MODE_NORMAL_FOLD;
-      break;
-    case M2S_ACCEL_BVH:
-      if (sign_method == M2S_SIGN_RAYCAST) { mode = MODE_UNSIGNED; sign_src = SIGN_RAYS3; }
-      else mode = MODE_NORMAL_FOLD;
-      break;
-    case M2S_ACCEL_RTREE: mode = MODE_NEAREST_NORMAL; break;
-    default: mode = MODE_UNSIGNED; sign_src = SIGN_RAYS3; break;
-  }
+  int mode, sign_src, algorithm;
+  select_generic_mode(accel, sign_method, c.algorithm, &mode, &sign_src, &algorithm);
 
   size_t need = bvh_workspace_bytes(n_tris) + query_workspace_bytes(n_queries) + 4096;
   if (c.mem_kind == M2S_MEM_HOST)
@@ -405,6 +458,231 @@ int m2s_generate_sdf(const float* vertices, size_t n_vertices, const void* indic
     M2S_HIP_CHECK(hipMemcpyAsync(out, d_out, n_queries * 4, hipMemcpyDeviceToHost, c.stream));
   if (n_out) *n_out = n_queries;
   return finish_call(c, *st, d_err, c.timings, n_tris, n_queries, false);
+}
+
+
+// ---- persistent mesh ---------------------------------------------------------------------------
+int m2s_mesh_create(const float* vertices, size_t n_vertices, const void* indices, size_t n_indices, int index_bytes,
+                    int topology, const m2s_opts* opts, m2s_mesh** out_mesh) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  g_err[0] = 0;
+  if (!out_mesh) return fail(M2S_ERR_BAD_ARG, "out_mesh is NULL");
+  *out_mesh = nullptr;
+  int rc = check_mesh_args(vertices, n_vertices, indices, n_indices, index_bytes, topology);
+  if (rc) return rc;
+  const size_t n_tris = m2s_triangle_count(n_vertices, n_indices, indices != nullptr, topology);
+  CallCtx c;
+  DeviceState* st = nullptr;
+  rc = resolve_ctx(opts, &c, &st);
+  if (rc) return rc;
+  m2s_mesh* m = new m2s_mesh();
+  m->device = c.device;
+  m->n_tris = n_tris;
+  m->mem_bytes = bvh_workspace_bytes(n_tris) + 8192;
+  if (c.mem_kind == M2S_MEM_HOST) m->mem_bytes += align_up(n_vertices * 12) + align_up(n_indices * (size_t)(indices ? index_bytes : 0)) + 1024;
+  if (st->spare_mesh && st->spare_mesh_bytes >= m->mem_bytes) {   // recycle (steady-state: no hipMalloc per call)
+    m->mem = st->spare_mesh;
+    m->mem_bytes = st->spare_mesh_bytes;
+    st->spare_mesh = nullptr;
+    st->spare_mesh_bytes = 0;
+  } else if (hipMalloc((void**)&m->mem, m->mem_bytes) != hipSuccess) {
+    const size_t want = m->mem_bytes;
+    delete m;
+    return fail(M2S_ERR_HIP, "hipMalloc of %zu bytes for the mesh failed", want);
+  }
+  Arena ws{m->mem, m->mem_bytes, 0};
+  int* d_err = ws.take<int>(16);
+  auto bail = [&](int code) { (void)hipFree(m->mem); delete m; return code; };
+  if (hipMemsetAsync(d_err, 0, 64, c.stream) != hipSuccess) return bail(fail(M2S_ERR_HIP, "memset failed"));
+  StagedMesh sm;
+  rc = stage_mesh(ws, c, vertices, n_vertices, indices, n_indices, index_bytes, &sm);
+  if (rc) return bail(rc);
+  (void)hipEventRecord(st->ev[0], c.stream);
+  rc = build_device_mesh(ws, c.stream, sm.d_verts, n_vertices, sm.d_indices, n_indices, index_bytes, topology, n_tris, d_err, &m->dm);
+  if (rc) return bail(rc);
+  (void)hipEventRecord(st->ev[1], c.stream);
+  if (hipMemcpyAsync(st->h_err, d_err, sizeof(int), hipMemcpyDeviceToHost, c.stream) != hipSuccess ||
+      hipStreamSynchronize(c.stream) != hipSuccess)
+    return bail(fail(M2S_ERR_HIP, "mesh build failed: %s", hipGetErrorString(hipGetLastError())));
+  (void)hipEventElapsedTime(&m->build_ms, st->ev[0], st->ev[1]);
+  if (*st->h_err & ERRF_INDEX_OOB) return bail(fail(M2S_ERR_BAD_ARG, "vertex index out of range (the reference panics indexing `vertices`)"));
+  *out_mesh = m;
+  return M2S_OK;
+}
+
+void m2s_mesh_destroy(m2s_mesh* m) {
+  if (!m) return;
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (hipSetDevice(m->device) == hipSuccess) {
+    (void)hipDeviceSynchronize();
+    DeviceState& ds = g_dev[m->device];
+    if (m->mem && !ds.spare_mesh) { ds.spare_mesh = m->mem; ds.spare_mesh_bytes = m->mem_bytes; }
+    else if (m->mem) (void)hipFree(m->mem);
+    if (m->plane_mem) (void)hipFree(m->plane_mem);
+    for (auto& p : m->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+    for (auto e : m->free_events) (void)hipEventDestroy(e);
+  }
+  delete m;
+}
+
+size_t m2s_mesh_triangle_count(const m2s_mesh* m) { return m ? m->n_tris : 0; }
+
+static bool same_grid(const m2s_grid& a, const m2s_grid& b) { return memcmp(&a, &b, sizeof(m2s_grid)) == 0; }
+
+int m2s_mesh_generate_grid_sdf(m2s_mesh* m, const m2s_grid* grid, int sign_method, float* out, const m2s_opts* opts) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  g_err[0] = 0;
+  if (!m) return fail(M2S_ERR_BAD_ARG, "mesh is NULL");
+  if (!grid) return fail(M2S_ERR_BAD_ARG, "grid is NULL");
+  if (sign_method != M2S_SIGN_RAYCAST && sign_method != M2S_SIGN_NORMAL) return fail(M2S_ERR_BAD_ARG, "bad sign_method %d", sign_method);
+  GridParams g;
+  size_t slab_cells = 0;
+  int rc = fill_grid_params(grid, opts, &g, &slab_cells);
+  if (rc) return rc;
+  if (slab_cells == 0) {
+    if (opts && opts->timings) memset(opts->timings, 0, sizeof(*opts->timings));
+    return M2S_OK;
+  }
+  if (!out) return fail(M2S_ERR_BAD_ARG, "out is NULL");
+  m2s_opts o{};
+  if (opts) o = *opts;
+  if (o.device < 0) o.device = m->device;
+  if (o.device != m->device) return fail(M2S_ERR_BAD_ARG, "mesh lives on device %d, call asked for %d", m->device, o.device);
+  if (!opts) o.synchronous = 1;
+  CallCtx c;
+  DeviceState* st = nullptr;
+  rc = resolve_ctx(&o, &c, &st);
+  if (rc) return rc;
+  const uint64_t ny = grid->cell_count[1], nz = grid->cell_count[2], xb = g.xb;
+
+  size_t need = grid_distance_workspace_bytes(g) + 8192;
+  if (c.mem_kind == M2S_MEM_HOST) need += align_up(slab_cells * 4) + 1024;
+  rc = ensure_capacity(*st, need);
+  if (rc) return rc;
+  Arena ws{st->base, st->cap, 0};
+  int* d_err = ws.take<int>(16);
+  M2S_HIP_CHECK(hipMemsetAsync(d_err, 0, 64, c.stream));
+  float* d_out = out;
+  float* d_slab = nullptr;
+  if (c.mem_kind == M2S_MEM_HOST) {
+    d_slab = ws.take<float>(slab_cells);
+    if (!d_slab) return fail(M2S_ERR_HIP, "internal: workspace");
+    d_out = d_slab;
+    g.out_off = (uint64_t)xb * ny * nz;
+  }
+  M2S_HIP_CHECK(hipEventRecord(st->ev[0], c.stream));
+  M2S_HIP_CHECK(hipEventRecord(st->ev[1], c.stream));
+  bool built_planes = false;
+  const uint32_t* plane = nullptr;
+  if (sign_method == M2S_SIGN_RAYCAST) {
+    if (!m->plane_valid || !same_grid(m->plane_grid, *grid)) {
+      const size_t bytes = sign_workspace_bytes(g);
+      if (bytes > m->plane_bytes) {
+        if (m->plane_mem) { M2S_HIP_CHECK(hipDeviceSynchronize()); M2S_HIP_CHECK(hipFree(m->plane_mem)); m->plane_mem = nullptr; }
+        M2S_HIP_CHECK(hipMalloc((void**)&m->plane_mem, bytes));
+        m->plane_bytes = bytes;
+      }
+      Arena pw{m->plane_mem, m->plane_bytes, 0};
+      rc = build_grid_sign_plane(pw, c.stream, m->dm, g, &m->plane);
+      if (rc) return rc;
+      m->plane_grid = *grid;
+      m->plane_valid = true;
+      built_planes = true;
+    }
+    plane = m->plane;
+  }
+  M2S_HIP_CHECK(hipEventRecord(st->ev[2], c.stream));
+  rc = run_grid_distance(ws, c, *st, m->dm, g, sign_method, plane, d_out, d_err);
+  if (rc) return rc;
+  if (c.mem_kind == M2S_MEM_HOST)
+    M2S_HIP_CHECK(hipMemcpyAsync(out + (size_t)xb * ny * nz, d_slab, slab_cells * 4, hipMemcpyDeviceToHost, c.stream));
+  if (!c.sync) {
+    // Asynchronous call: no host sync now.  Keep the event pair around the dominant launch so that its
+    // duration can be read later (m2s_mesh_drain_timings): ev[4] was recorded just before that launch;
+    // it moves into `pending` and the device state gets a fresh event for the next call.
+    hipEvent_t stop, fresh;
+    for (hipEvent_t* e : {&stop, &fresh}) {
+      if (!m->free_events.empty()) { *e = m->free_events.back(); m->free_events.pop_back(); }
+      else M2S_HIP_CHECK(hipEventCreate(e));
+    }
+    M2S_HIP_CHECK(hipEventRecord(stop, c.stream));
+    m->pending.push_back({st->ev[4], stop, (uint64_t)slab_cells});
+    st->ev[4] = fresh;
+    return M2S_OK;
+  }
+  return finish_call(c, *st, d_err, c.timings, m->n_tris, slab_cells, built_planes, true);
+}
+
+int m2s_mesh_drain_timings(m2s_mesh* m, m2s_timings* t) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (!m || !t) return fail(M2S_ERR_BAD_ARG, "NULL argument");
+  memset(t, 0, sizeof(*t));
+  t->accel_build_ms = m->build_ms;
+  t->n_triangles = m->n_tris;
+  for (auto& p : m->pending) {
+    M2S_HIP_CHECK(hipEventSynchronize(p.b));
+    float ms = 0.0f;
+    (void)hipEventElapsedTime(&ms, p.a, p.b);
+    t->distance_ms += ms;
+    t->n_units += p.units;
+    t->distance_launches += 1;
+    m->free_events.push_back(p.a);
+    m->free_events.push_back(p.b);
+  }
+  m->pending.clear();
+  return M2S_OK;
+}
+
+int m2s_mesh_generate_sdf(m2s_mesh* m, const float* queries, size_t n_queries, int accel, int sign_method, float* out,
+                          size_t* n_out, const m2s_opts* opts) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  g_err[0] = 0;
+  if (n_out) *n_out = 0;
+  if (!m) return fail(M2S_ERR_BAD_ARG, "mesh is NULL");
+  if (accel < M2S_ACCEL_NONE || accel > M2S_ACCEL_RTREE_BVH) return fail(M2S_ERR_BAD_ARG, "bad accel %d", accel);
+  if (sign_method != M2S_SIGN_RAYCAST && sign_method != M2S_SIGN_NORMAL) return fail(M2S_ERR_BAD_ARG, "bad sign_method %d", sign_method);
+  if (n_queries && !queries) return fail(M2S_ERR_BAD_ARG, "queries is NULL");
+  if (n_queries >= 0xffffffc0ull) return fail(M2S_ERR_BAD_ARG, "too many queries for one call");
+  if (m->n_tris == 0 && accel == M2S_ACCEL_RTREE_BVH) return M2S_OK;
+  if (m->n_tris == 0 && accel == M2S_ACCEL_RTREE && n_queries) return fail(M2S_ERR_EMPTY_MESH, "Rtree on a mesh without triangles (rtree.rs:117 unwrap on None)");
+  if (n_queries == 0) return M2S_OK;
+  if (!out) return fail(M2S_ERR_BAD_ARG, "out is NULL");
+  m2s_opts o{};
+  if (opts) o = *opts;
+  if (o.device < 0) o.device = m->device;
+  if (o.device != m->device) return fail(M2S_ERR_BAD_ARG, "mesh lives on device %d, call asked for %d", m->device, o.device);
+  if (!opts) o.synchronous = 1;
+  CallCtx c;
+  DeviceState* st = nullptr;
+  int rc = resolve_ctx(&o, &c, &st);
+  if (rc) return rc;
+  int mode, sign_src, algorithm;
+  select_generic_mode(accel, sign_method, c.algorithm, &mode, &sign_src, &algorithm);
+  size_t need = query_workspace_bytes(n_queries) + 8192;
+  if (c.mem_kind == M2S_MEM_HOST) need += align_up(n_queries * 12) + align_up(n_queries * 4) + 1024;
+  rc = ensure_capacity(*st, need);
+  if (rc) return rc;
+  Arena ws{st->base, st->cap, 0};
+  int* d_err = ws.take<int>(16);
+  M2S_HIP_CHECK(hipMemsetAsync(d_err, 0, 64, c.stream));
+  const float* d_q = queries;
+  float* d_out = out;
+  if (c.mem_kind == M2S_MEM_HOST) {
+    float* dq = ws.take<float>(n_queries * 3);
+    d_out = ws.take<float>(n_queries);
+    if (!dq || !d_out) return fail(M2S_ERR_HIP, "internal: workspace");
+    M2S_HIP_CHECK(hipMemcpyAsync(dq, queries, n_queries * 12, hipMemcpyHostToDevice, c.stream));
+    d_q = dq;
+  }
+  M2S_HIP_CHECK(hipEventRecord(st->ev[0], c.stream));
+  M2S_HIP_CHECK(hipEventRecord(st->ev[1], c.stream));
+  M2S_HIP_CHECK(hipEventRecord(st->ev[2], c.stream));
+  rc = launch_query_distance(ws, c.stream, m->dm, d_q, n_queries, mode, sign_src, algorithm, d_out, d_err);
+  if (rc) return rc;
+  M2S_HIP_CHECK(hipEventRecord(st->ev[3], c.stream));
+  if (c.mem_kind == M2S_MEM_HOST) M2S_HIP_CHECK(hipMemcpyAsync(out, d_out, n_queries * 4, hipMemcpyDeviceToHost, c.stream));
+  if (n_out) *n_out = n_queries;
+  return finish_call(c, *st, d_err, c.timings, m->n_tris, n_queries, false);
 }
 
 }  // extern "C"

@@ -1,65 +1,127 @@
-"""Multi-GPU generate_grid_sdf: one process per GPU, x-slab shards, one RCCL all-gather.
+"""Multi-GPU generate_grid_sdf: one process per GPU, x-slab shards, RCCL all-gather over xGMI.
 
 Every voxel depends only on the (replicated) mesh, so the grid shards with no data-path
 exchange.  The reference's output layout is x-slowest (`idx = z + y*nz + x*ny*nz`, grid.rs:122-124),
-so a slab of cells along cell-axis 0 is one CONTIGUOUS range of the output and the final gather is
-an in-place `all_gather_into_tensor` (backend "nccl" == RCCL over xGMI on ROCm).  Each rank marks
-the sign planes for the whole grid (hits are slab independent: t is measured from cell 0 of the
-line, generate/grid.rs:570-617) — O(T) work, no halo, no exchange.
-"""
-from typing import Callable, Optional, Tuple
+so a slab of cells along cell-axis 0 is one CONTIGUOUS range of the output and the gather is an
+in-place `all_gather_into_tensor` (backend "nccl" == RCCL on ROCm).  Each rank marks the sign planes
+for the whole grid (hits are slab independent: t is measured from cell 0 of the line,
+generate/grid.rs:570-617) — O(T) work, no halo, no exchange.
 
-from .api import Grid, SignMethod, Topology, generate_grid_sdf
+Overlap: the grid is cut into `chunks` contiguous x-ranges; inside chunk c rank r owns the r-th
+sub-slab, so the all-gather of chunk c is an in-place collective on ONE contiguous range and runs
+(asynchronously, on RCCL's stream) while the ranks already compute chunk c+1.  xGMI is
+point-to-point, so the gather is per-link bound; hiding it under compute is what keeps strong
+scaling alive once the kernel is fast.  The mesh (LBVH + sign planes) is built once per call.
+"""
+from typing import Callable, List, Optional, Tuple
+
+from .api import Grid, Mesh, SignMethod, Topology, generate_grid_sdf
 
 
 def slab_bounds(nx: int, world: int, rank: int) -> Tuple[int, int]:
-    """Contiguous x-slab [x0, x1) of rank `rank`; sizes differ by at most one cell layer."""
+    """Contiguous x-slab [x0, x1) of rank `rank` out of `world`; sizes differ by at most one layer."""
     base, rem = divmod(nx, world)
     x0 = rank * base + min(rank, rem)
     return x0, x0 + base + (1 if rank < rem else 0)
 
 
-def gather_slabs(out, nx: int, row_cells: int, group=None):
-    """Make every rank's `out` (the whole grid, flat) complete: rank r has filled its slab."""
+def chunk_plan(nx: int, world: int, chunks: int) -> List[Tuple[int, int]]:
+    """Contiguous x-ranges [c0, c1) that are gathered one after the other.  Every chunk is a multiple
+    of `world` layers (so the in-place all-gather applies) except possibly the last one."""
+    chunks = max(1, min(chunks, max(1, nx // max(world, 1))))
+    per = (nx // chunks) // world * world if nx >= chunks * world else nx
+    if per == 0:
+        return [(0, nx)]
+    plan, x = [], 0
+    for c in range(chunks):
+        x1 = nx if c == chunks - 1 else x + per
+        plan.append((x, x1))
+        x = x1
+    return [p for p in plan if p[1] > p[0]]
+
+
+def piece_bounds(chunk: Tuple[int, int], world: int, rank: int) -> Tuple[int, int]:
+    c0, c1 = chunk
+    a, b = slab_bounds(c1 - c0, world, rank)
+    return c0 + a, c0 + b
+
+
+def gather_chunk(out, chunk: Tuple[int, int], row_cells: int, group=None, async_op: bool = False):
+    """Completes `out[chunk]` on every rank; rank r has filled its piece of the chunk."""
     import torch.distributed as dist
 
     world = dist.get_world_size(group)
     if world == 1:
-        return out
+        return None
     rank = dist.get_rank(group)
-    if nx % world == 0:
-        x0, x1 = slab_bounds(nx, world, rank)
-        dist.all_gather_into_tensor(out, out[x0 * row_cells : x1 * row_cells], group=group)  # in place
-    else:  # uneven slabs: one broadcast per slab
-        for r in range(world):
-            x0, x1 = slab_bounds(nx, world, r)
-            if x1 > x0:
-                dist.broadcast(out[x0 * row_cells : x1 * row_cells], src=dist.get_global_rank(group, r) if group else r, group=group)
+    c0, c1 = chunk
+    if (c1 - c0) % world == 0:
+        a, b = piece_bounds(chunk, world, rank)
+        return dist.all_gather_into_tensor(out[c0 * row_cells : c1 * row_cells], out[a * row_cells : b * row_cells],
+                                           group=group, async_op=async_op)  # in place
+    works = []  # uneven pieces: one broadcast per piece
+    for r in range(world):
+        a, b = piece_bounds(chunk, world, r)
+        if b > a:
+            src = dist.get_global_rank(group, r) if group is not None else r
+            works.append(dist.broadcast(out[a * row_cells : b * row_cells], src=src, group=group, async_op=async_op))
+    return works
+
+
+def gather_slabs(out, nx: int, row_cells: int, group=None):
+    """Single-chunk gather (every rank filled slab_bounds(nx, world, rank))."""
+    gather_chunk(out, (0, nx), row_cells, group)
     return out
 
 
-def generate_grid_sdf_sharded(vertices, indices: Topology, grid: Grid, sign_method: SignMethod = SignMethod.Raycast, *,
-                              group=None, out=None, compute_slab: Optional[Callable] = None, timings=None,
-                              gather: bool = True):
-    """generate_grid_sdf over all ranks of `group` (default: the world).  `vertices`/`indices` are
-    this rank's copies (CUDA tensors for the HIP path); returns the full grid on every rank.
+def _wait(work):
+    if work is None:
+        return
+    for w in work if isinstance(work, list) else [work]:
+        if w is not None:
+            w.wait()
 
-    compute_slab(out, x0, x1) may replace the slab computation (the CPU tests inject the oracle
-    there so the sharding/gather logic runs under gloo without a GPU)."""
+
+def generate_grid_sdf_sharded(vertices, indices: Topology, grid: Grid, sign_method: SignMethod = SignMethod.Raycast, *,
+                              group=None, out=None, compute_slab: Optional[Callable] = None, chunks: int = 1,
+                              mesh: Optional[Mesh] = None, gather: bool = True, return_mesh: bool = False):
+    """generate_grid_sdf over all ranks of `group` (default: the world).  `vertices`/`indices` are this
+    rank's copies (CUDA tensors for the HIP path); returns the full grid on every rank.
+
+    compute_slab(out, x0, x1) may replace the slab computation (the CPU tests inject the oracle there
+    so the partition / overlap / gather logic runs under gloo without a GPU)."""
     import torch
     import torch.distributed as dist
 
     nx, ny, nz = grid.get_cell_count()
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
-    rank = dist.get_rank(group) if dist.is_initialized() else 0
-    x0, x1 = slab_bounds(nx, world, rank)
+    inited = dist.is_available() and dist.is_initialized()
+    world = dist.get_world_size(group) if inited else 1
+    rank = dist.get_rank(group) if inited else 0
+    row = ny * nz
     if out is None:
         dev = vertices.device if hasattr(vertices, "device") else "cpu"
-        out = torch.empty(nx * ny * nz, dtype=torch.float32, device=dev)
-    if compute_slab is not None:
-        compute_slab(out, x0, x1)
-    elif x1 > x0:
-        generate_grid_sdf(vertices, indices, grid, sign_method, x_slab=(x0, x1), out=out, timings=timings)
-    if gather and world > 1:
-        gather_slabs(out, nx, ny * nz, group)
-    return out
+        out = torch.empty(nx * row, dtype=torch.float32, device=dev)
+    plan = chunk_plan(nx, world, chunks if world > 1 else 1)
+    own_mesh = None
+    if compute_slab is None and mesh is None:
+        mesh = own_mesh = Mesh(vertices, indices)   # LBVH built once for all pieces of this call
+    pending = []
+    try:
+        for ci, chunk in enumerate(plan):
+            a, b = piece_bounds(chunk, world, rank)
+            if compute_slab is not None:
+                compute_slab(out, a, b)
+            elif b > a:
+                # asynchronous: the kernels are only enqueued, so the collective of the previous chunk
+                # (already running on RCCL's stream) overlaps them
+                mesh.generate_grid_sdf(grid, sign_method, x_slab=(a, b), out=out, synchronous=False)
+            if gather and world > 1:
+                pending.append(gather_chunk(out, chunk, row, group, async_op=True))
+        for w in pending:
+            _wait(w)
+    finally:
+        if own_mesh is not None and not return_mesh:
+            if out.is_cuda:
+                torch.cuda.current_stream(out.device).synchronize()
+            own_mesh.close()
+    return (out, mesh) if return_mesh else out

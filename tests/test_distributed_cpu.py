@@ -12,7 +12,7 @@ import torch.multiprocessing as mp
 
 import oracle as orc
 from mesh_to_sdf_amd import Grid, SignMethod, Topology, meshes
-from mesh_to_sdf_amd.distributed import gather_slabs, generate_grid_sdf_sharded, slab_bounds
+from mesh_to_sdf_amd.distributed import chunk_plan, generate_grid_sdf_sharded, piece_bounds, slab_bounds
 
 
 def test_slab_bounds_cover_and_are_contiguous():
@@ -29,6 +29,25 @@ def test_slab_bounds_cover_and_are_contiguous():
     assert [slab_bounds(512, 8, r) for r in (0, 7)] == [(0, 64), (448, 512)]
 
 
+def test_chunk_plan_partitions_every_layer_once():
+    for nx in (1, 5, 16, 15, 64, 512, 513, 1024):
+        for world in (1, 2, 3, 8):
+            for chunks in (1, 2, 4, 7):
+                plan = chunk_plan(nx, world, chunks)
+                assert plan[0][0] == 0 and plan[-1][1] == nx
+                owner = [-1] * nx
+                for (c0, c1), nxt in zip(plan, plan[1:] + [(nx, nx)]):
+                    assert c1 == nxt[0] and c1 > c0
+                    for r in range(world):
+                        a, b = piece_bounds((c0, c1), world, r)
+                        for x in range(a, b):
+                            assert owner[x] == -1
+                            owner[x] = r
+                assert all(o >= 0 for o in owner)
+                if world > 1 and nx >= chunks * world:
+                    assert all((c1 - c0) % world == 0 for c0, c1 in plan[:-1])  # in-place all-gather applies
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -37,7 +56,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, nx, q):
+def _worker(rank, world, port, nx, chunks, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -49,31 +68,29 @@ def _worker(rank, world, port, nx, q):
         whole = orc.generate_grid_sdf(v, idx, first, size, cnt, sign=0, semantics=orc.EXACT, threads=1)
         row = cnt[1] * cnt[2]
 
-        def compute_slab(out, x0, x1):
-            out.fill_(float("nan"))
+        full = torch.full((nx * row,), float("nan"))
+
+        def compute_slab(out, x0, x1):   # writes ONLY this rank's piece, like the HIP slab call
             out[x0 * row : x1 * row] = torch.from_numpy(whole[x0 * row : x1 * row].copy())
 
         out = generate_grid_sdf_sharded(torch.from_numpy(v), Topology.TriangleList(idx), grid, SignMethod.Raycast,
-                                        compute_slab=compute_slab)
+                                        compute_slab=compute_slab, chunks=chunks, out=full)
         ok = np.array_equal(out.numpy().view(np.uint32), whole.view(np.uint32))
-        x0, x1 = slab_bounds(nx, world, rank)
-        q.put((rank, bool(ok), x0, x1))
+        q.put((rank, bool(ok)))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,nx", [(2, 16), (2, 15), (3, 16)])
-def test_sharded_grid_gloo(world, nx):
+@pytest.mark.parametrize("world,nx,chunks", [(2, 16, 1), (2, 16, 4), (2, 15, 2), (3, 16, 2)])
+def test_sharded_grid_gloo(world, nx, chunks):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, nx, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, nx, chunks, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=120) for _ in range(world)]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    assert all(ok for _, ok, _, _ in res), res
-    covered = sorted((x0, x1) for _, _, x0, x1 in res)
-    assert covered[0][0] == 0 and covered[-1][1] == nx
+    assert all(ok for _, ok in res), res

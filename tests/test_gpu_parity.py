@@ -334,3 +334,45 @@ def test_full_size_512_properties():
         assert np.array_equal(np.signbit(s3[x].cpu().numpy()), inside[x]), f"sign plane x={x}"
     again = generate_grid_sdf(dv, Topology.TriangleList(di), g, SignMethod.Raycast)
     assert torch.equal(sdf, again)
+
+
+# ---- persistent mesh (include/m2s.h m2s_mesh) -----------------------------------------------------
+def test_persistent_mesh_matches_one_shot(suzanne):
+    import torch
+
+    from mesh_to_sdf_amd import Mesh
+
+    v, idx = suzanne
+    q = meshes.uniform_queries(*meshes.extended_bbox(v, 0.2), 8000)
+    g1, g2 = grid_of(v, [40, 28, 36]), grid_of(v, [33, 33, 33], 0.3)
+    with Mesh(v, Topology.TriangleList(idx)) as m:                      # host pointers
+        assert m.triangle_count() == 968
+        for g in (g1, g2, g1):                                           # sign-plane cache: miss, miss, miss(g1 again after g2)
+            for sign in (SignMethod.Raycast, SignMethod.Normal):
+                assert_bit_equal(m.generate_grid_sdf(g, sign), generate_grid_sdf(v, Topology.TriangleList(idx), g, sign), "mesh grid")
+        assert_bit_equal(m.generate_grid_sdf(g1, SignMethod.Raycast), generate_grid_sdf(v, Topology.TriangleList(idx), g1), "cached planes")
+        for name, am, accel, sign in ACCELS:
+            assert_bit_equal(m.generate_sdf(q, am), generate_sdf(v, Topology.TriangleList(idx), q, am), name)
+    dv, di = torch.as_tensor(v, device="cuda"), torch.as_tensor(idx.astype(np.int64), device="cuda")
+    with Mesh(dv, Topology.TriangleList(di)) as m:                       # device pointers, asynchronous slab calls
+        out = torch.full((g1.get_total_cell_count(),), float("nan"), device="cuda")
+        for x0, x1 in ((0, 7), (7, 8), (8, 40)):
+            m.generate_grid_sdf(g1, SignMethod.Raycast, x_slab=(x0, x1), out=out, synchronous=False)
+        t = m.drain_timings()
+        assert t.distance_launches == 3 and t.n_units == g1.get_total_cell_count() and t.distance_ms > 0
+        assert_bit_equal(out.cpu().numpy(), generate_grid_sdf(v, Topology.TriangleList(idx), g1), "async slabs")
+    with pytest.raises(M2SPanic):
+        Mesh(v, Topology.TriangleList([0, 1, 99999]))
+
+
+def test_sharded_driver_single_process(suzanne):
+    # the multi-GPU driver with world size 1 (no process group): chunk plan + persistent mesh + async calls
+    import torch
+
+    from mesh_to_sdf_amd.distributed import generate_grid_sdf_sharded
+
+    v, idx = suzanne
+    g = grid_of(v, [36, 20, 28])
+    dv, di = torch.as_tensor(v, device="cuda"), torch.as_tensor(idx.astype(np.int64), device="cuda")
+    out = generate_grid_sdf_sharded(dv, Topology.TriangleList(di), g, SignMethod.Raycast, chunks=4)
+    assert_bit_equal(out.cpu().numpy(), generate_grid_sdf(v, Topology.TriangleList(idx), g), "sharded driver")
