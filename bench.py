@@ -53,25 +53,33 @@ def cpu_baseline(v, idx, lo, hi, sign, budget_s):
 
     cores = orc.hardware_threads()
 
-    def run(n):
+    def run(n, th):
         first, size, cnt = meshes.grid_from_bounding_box(lo, hi, [n, n, n])
         t0 = time.perf_counter()
-        orc.generate_grid_sdf(v, idx, first, size, cnt, sign=sign, semantics=orc.PROPAGATE, heaps=cores, threads=cores)
+        # heaps == threads: the reference makes one heap per rayon thread (generate/grid.rs:318-339)
+        orc.generate_grid_sdf(v, idx, first, size, cnt, sign=sign, semantics=orc.PROPAGATE, heaps=th, threads=th)
         return time.perf_counter() - t0
 
-    n, dt = 128, run(128)
-    rate = n ** 3 / dt
+    # The port does not scale to every core count (more heaps = more redundant propagation, and the
+    # algorithm has serial O(N^3) passes, as the reference does): probe a few thread counts on 128^3 and
+    # report the FASTEST configuration, so the baseline is the strongest CPU number, not the weakest.
+    probe = {}
+    for th in sorted({min(cores, t) for t in (16, 32, 64, cores)}):
+        probe[th] = run(128, th)
+    best_th = min(probe, key=probe.get)
+    rate = 128 ** 3 / probe[best_th]
+    n, dt = 128, probe[best_th]
     for cand in (256, 224, 192, 160):
         if cand ** 3 / rate <= budget_s:
-            n, dt = cand, run(cand)
+            n, dt = cand, run(cand, best_th)
             break
     return {
         "value": round(n ** 3 / dt / 1e6, 4),
         "unit": "Mvoxels/s",
-        "cores": cores,
+        "cores": best_th,
         "kind": "port",
-        "sample": f"{n}^3 grid (1/{(512 // n) ** 3 if 512 % n == 0 else round(512 ** 3 / n ** 3, 1)} of the voxels), same mesh and bbox, "
-                  f"C++ restatement of the reference's 3-phase propagation algorithm, {cores} threads, {dt:.2f} s",
+        "sample": f"{n}^3 grid ({n ** 3 / 512 ** 3:.4f} of the 512^3 voxels), same mesh and bbox, C++ restatement of the reference's "
+                  f"3-phase propagation algorithm (oracle/), {best_th} threads = fastest of {sorted(probe)} on this {cores}-thread host, {dt:.2f} s",
     }
 
 
