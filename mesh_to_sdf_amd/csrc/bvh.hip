@@ -51,7 +51,7 @@ __device__ __forceinline__ uint32_t load_index(const void* idx, int index_bytes,
 __global__ __launch_bounds__(256) void k_tri_setup(const float* __restrict__ verts, uint32_t n_verts,
                                                    const void* __restrict__ indices, int index_bytes, int topology,
                                                    uint32_t n_tris, TriRec* __restrict__ raw, Box* __restrict__ boxes,
-                                                   int* __restrict__ scene /*6 ordered ints*/, int* __restrict__ err) {
+                                                   int* __restrict__ scene /*6 final + 6 per block*/, int* __restrict__ err) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   int lo[3] = {INT32_MAX, INT32_MAX, INT32_MAX}, hi[3] = {INT32_MIN, INT32_MIN, INT32_MIN};
   if (t < n_tris) {
@@ -84,17 +84,51 @@ __global__ __launch_bounds__(256) void k_tri_setup(const float* __restrict__ ver
     for (int k = 0; k < 3; ++k)
       if (cen[k] == cen[k] && fabsf(cen[k]) < 3.0e38f) { lo[k] = ord(cen[k]); hi[k] = lo[k]; }
   }
-  // wave reduce, one atomic per wave and bound
+  // block reduce (wave shuffles, then LDS); one partial per block, folded by k_scene_reduce:
+  // no atomics, no serialisation on six hot addresses
+  __shared__ int part[6][4];
+  const int wv = threadIdx.x >> 6;
   for (int k = 0; k < 3; ++k) {
     int l = lo[k], h = hi[k];
     for (int off = 32; off > 0; off >>= 1) {
       l = min(l, __shfl_xor(l, off));
       h = max(h, __shfl_xor(h, off));
     }
-    if ((threadIdx.x & 63) == 0) {
-      if (l != INT32_MAX) atomicMin(&scene[k], l);
-      if (h != INT32_MIN) atomicMax(&scene[3 + k], h);
+    if ((threadIdx.x & 63) == 0) { part[k][wv] = l; part[3 + k][wv] = h; }
+  }
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    const int k = threadIdx.x;
+    int v = part[k][0];
+    for (int w = 1; w < 4; ++w) v = k < 3 ? min(v, part[k][w]) : max(v, part[k][w]);
+    scene[6 + blockIdx.x * 6 + k] = v;   // partials live behind the 6 final values
+  }
+}
+
+// Folds the per-block partials into scene[0..5] (order-encoded min xyz / max xyz of the box centres).
+__global__ __launch_bounds__(256) void k_scene_reduce(int* __restrict__ scene, uint32_t n_blocks) {
+  __shared__ int part[6][4];
+  int lo[3] = {INT32_MAX, INT32_MAX, INT32_MAX}, hi[3] = {INT32_MIN, INT32_MIN, INT32_MIN};
+  for (uint32_t b = threadIdx.x; b < n_blocks; b += 256)
+    for (int k = 0; k < 3; ++k) {
+      lo[k] = min(lo[k], scene[6 + b * 6 + k]);
+      hi[k] = max(hi[k], scene[6 + b * 6 + 3 + k]);
     }
+  const int wv = threadIdx.x >> 6;
+  for (int k = 0; k < 3; ++k) {
+    int l = lo[k], h = hi[k];
+    for (int off = 32; off > 0; off >>= 1) {
+      l = min(l, __shfl_xor(l, off));
+      h = max(h, __shfl_xor(h, off));
+    }
+    if ((threadIdx.x & 63) == 0) { part[k][wv] = l; part[3 + k][wv] = h; }
+  }
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    const int k = threadIdx.x;
+    int v = part[k][0];
+    for (int w = 1; w < 4; ++w) v = k < 3 ? min(v, part[k][w]) : max(v, part[k][w]);
+    scene[k] = v;
   }
 }
 
@@ -174,13 +208,38 @@ __global__ __launch_bounds__(256) void k_seg_level0(const Box* __restrict__ boxe
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k < n) seg[k] = boxes[order[k]];
 }
-__global__ __launch_bounds__(256) void k_seg_level(const Box* __restrict__ below, int n_below, Box* __restrict__ here,
-                                                   int n_here) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= n_here) return;
-  Box b = below[2 * j];
-  if (2 * j + 1 < n_below) b = box_union(b, below[2 * j + 1]);
-  here[j] = b;
+// Builds levels l+1, l+2, l+3 of the segment tree from level l in one launch: thread j owns entry j of
+// level l+3 = the union of (up to) 8 entries of level l, and writes the intermediate entries on the way.
+__global__ __launch_bounds__(256) void k_seg_level3(Box* __restrict__ seg, uint32_t off0, uint32_t n0, uint32_t off1,
+                                                    uint32_t n1, uint32_t off2, uint32_t n2, uint32_t off3, uint32_t n3) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;   // index at level l+3 (or the deepest level present)
+  Box b1[4];
+  bool have1[4];
+  for (uint32_t a = 0; a < 4; ++a) {
+    const uint32_t i1 = 4 * j + a;          // entry at level l+1
+    have1[a] = i1 < n1;
+    if (!have1[a]) continue;
+    Box b = seg[off0 + 2 * i1];
+    if (2 * i1 + 1 < n0) b = box_union(b, seg[off0 + 2 * i1 + 1]);
+    b1[a] = b;
+    seg[off1 + i1] = b;
+  }
+  if (n2 == 0) return;
+  Box b2[2];
+  bool have2[2];
+  for (uint32_t a = 0; a < 2; ++a) {
+    const uint32_t i2 = 2 * j + a;          // entry at level l+2
+    have2[a] = i2 < n2;
+    if (!have2[a]) continue;
+    Box b = b1[2 * a];
+    if (have1[2 * a + 1]) b = box_union(b, b1[2 * a + 1]);
+    b2[a] = b;
+    seg[off2 + i2] = b;
+  }
+  if (n3 == 0 || j >= n3) return;
+  Box b = b2[0];
+  if (have2[1]) b = box_union(b, b2[1]);
+  seg[off3 + j] = b;
 }
 
 struct SegLevels {
@@ -252,6 +311,56 @@ __device__ __forceinline__ float wave_max(float v) {
 // Oriented bound (NodeExt) of every node: one wave per pre-order slot, lanes stride over the
 // triangles of the subtree (contiguous in Morton order).  Pass 1: area-weighted mean normal.
 // Pass 2: extent along it and lateral radius about the AABB centre.  All roundings go outwards.
+constexpr uint32_t EXT_THREAD_BELOW = 16;   // subtrees up to this many triangles: one THREAD per node
+
+// Serial version of the same computation for small subtrees (most nodes: half of them are leaves).
+__global__ __launch_bounds__(256) void k_node_ext_small(const NodeRec* __restrict__ nodes,
+                                                        const uint32_t* __restrict__ slot_first,
+                                                        const TriRec* __restrict__ tris, uint32_t n_nodes,
+                                                        NodeExt* __restrict__ ext) {
+  const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+  if (slot >= n_nodes) return;
+  const NodeRec nr = nodes[slot];
+  const uint32_t cnt = (nr.skip - slot + 1u) >> 1;
+  if (cnt > EXT_THREAD_BELOW) return;
+  const uint32_t first = slot_first[slot];
+  float sx = 0.0f, sy = 0.0f, sz = 0.0f;
+  for (uint32_t i = 0; i < cnt; ++i) {
+    const TriRec& t = tris[first + i];
+    const f3 n = cross3(mk3(t.abx, t.aby, t.abz), mk3(t.acx, t.acy, t.acz));
+    if (fabsf(n.x) < 3.0e38f && fabsf(n.y) < 3.0e38f && fabsf(n.z) < 3.0e38f) { sx += n.x; sy += n.y; sz += n.z; }
+  }
+  const float len = sqrtf(sx * sx + sy * sy + sz * sz);
+  float nx = 1.0f, ny = 0.0f, nz = 0.0f;
+  if (len > 1.0e-30f && len < 3.0e38f) { nx = sx / len; ny = sy / len; nz = sz / len; }
+  float cx = 0.5f * (nr.mnx + nr.mxx), cy = 0.5f * (nr.mny + nr.mxy), cz = 0.5f * (nr.mnz + nr.mxz);
+  if (!(fabsf(cx) < 3.0e38f)) cx = 0.0f;
+  if (!(fabsf(cy) < 3.0e38f)) cy = 0.0f;
+  if (!(fabsf(cz) < 3.0e38f)) cz = 0.0f;
+  const float inf = __builtin_inff();
+  float dlo = inf, dhi = -inf, r2 = 0.0f, w2max = 0.0f;
+  for (uint32_t i = 0; i < cnt; ++i) {
+    const TriRec& t = tris[first + i];
+    const float vx[3] = {t.ax, t.bx, t.cx}, vy[3] = {t.ay, t.by, t.cy}, vz[3] = {t.az, t.bz, t.cz};
+    for (int k = 0; k < 3; ++k) {
+      const float wx = vx[k] - cx, wy = vy[k] - cy, wz = vz[k] - cz;
+      const float tt = nx * wx + ny * wy + nz * wz;
+      const float w2 = wx * wx + wy * wy + wz * wz;
+      dlo = fminf(dlo, tt);
+      dhi = fmaxf(dhi, tt);
+      r2 = fmaxf(r2, w2 - tt * tt);
+      w2max = fmaxf(w2max, w2);
+    }
+  }
+  const float R = sqrtf(fmaxf(r2, 0.0f) + 1.0e-6f * w2max) * 1.00001f + 1.0e-30f;
+  const float e = 1.0e-5f * (fabsf(dlo) + fabsf(dhi)) + 2.0e-6f * sqrtf(w2max) + 1.0e-30f;
+  NodeExt x;
+  x.cx = cx; x.cy = cy; x.cz = cz; x.R = R;
+  x.nx = nx; x.ny = ny; x.nz = nz; x.dlo = dlo - e;
+  x.dhi = dhi + e; x.skip = nr.skip; x.tri = nr.tri; x.pad = 0;
+  ext[slot] = x;
+}
+
 __global__ __launch_bounds__(256) void k_node_ext(const NodeRec* __restrict__ nodes,
                                                   const uint32_t* __restrict__ slot_first,
                                                   const TriRec* __restrict__ tris, uint32_t n_nodes,
@@ -260,8 +369,9 @@ __global__ __launch_bounds__(256) void k_node_ext(const NodeRec* __restrict__ no
   const int lane = threadIdx.x & 63;
   if (slot >= n_nodes) return;
   const NodeRec nr = nodes[slot];
-  const uint32_t first = slot_first[slot];
   const uint32_t cnt = (nr.skip - slot + 1u) >> 1;
+  if (cnt <= EXT_THREAD_BELOW) return;   // done by k_node_ext_small
+  const uint32_t first = slot_first[slot];
   float cx = 0.5f * (nr.mnx + nr.mxx), cy = 0.5f * (nr.mny + nr.mxy), cz = 0.5f * (nr.mnz + nr.mxz);
   if (!(fabsf(cx) < 3.0e38f)) cx = 0.0f;
   if (!(fabsf(cy) < 3.0e38f)) cy = 0.0f;
@@ -335,7 +445,7 @@ size_t bvh_workspace_bytes(size_t n_tris) {
   size_t b = 0;
   b += n * sizeof(TriRec) * 2 + n * sizeof(Box) * 3 + n * (8 + 4) * 2 + sort_tmp;
   b += n * (sizeof(int2) * 2) + 2 * n * sizeof(int) + 2 * n * sizeof(NodeRec) + 2 * n * (sizeof(NodeExt) + 4);
-  return b + 64 * 256 + 4096;
+  return b + 64 * 256 + 4096 + 24 * ((n + 255) / 256) + 256;
 }
 
 int build_device_mesh(Arena& ws, hipStream_t st, const float* d_verts, size_t n_verts, const void* d_indices,
@@ -365,7 +475,7 @@ int build_device_mesh(Arena& ws, hipStream_t st, const float* d_verts, size_t n_
   NodeRec* nodes = ws.take<NodeRec>(2 * n_tris);
   NodeExt* ext = ws.take<NodeExt>(2 * n_tris);
   uint32_t* slot_first = ws.take<uint32_t>(2 * n_tris);
-  int* scene = ws.take<int>(8);
+  int* scene = ws.take<int>(8 + 6 * ((n_tris + 255) / 256));
   size_t sort_tmp = 0;
   (void)rocprim::radix_sort_pairs(nullptr, sort_tmp, keys, keys2, vals, order, n_tris, 0, 64, st);
   void* tmp = ws.take<char>(sort_tmp ? sort_tmp : 1);
@@ -379,6 +489,7 @@ int build_device_mesh(Arena& ws, hipStream_t st, const float* d_verts, size_t n_
   hipLaunchKernelGGL(k_init_scene, dim3(cdiv(2 * n_tris, B)), dim3(B), 0, st, scene, parent, 2 * n - 1);
   hipLaunchKernelGGL(k_tri_setup, dim3(cdiv(n_tris, B)), dim3(B), 0, st, d_verts, (uint32_t)n_verts, d_indices,
                      index_bytes, topology, (uint32_t)n_tris, raw, boxes, scene, d_err);
+  hipLaunchKernelGGL(k_scene_reduce, dim3(1), dim3(256), 0, st, scene, (uint32_t)cdiv(n_tris, B));
   hipLaunchKernelGGL(k_morton, dim3(cdiv(n_tris, B)), dim3(B), 0, st, boxes, (uint32_t)n_tris, scene, keys, vals);
   M2S_HIP_CHECK(rocprim::radix_sort_pairs(tmp, sort_tmp, keys, keys2, vals, order, n_tris, 0, 64, st));
   if (n > 1) hipLaunchKernelGGL(k_karras, dim3(cdiv(n_tris - 1, B)), dim3(B), 0, st, keys2, n, range, child, parent);
@@ -397,11 +508,18 @@ int build_device_mesh(Arena& ws, hipStream_t st, const float* d_verts, size_t n_
     }
   }
   hipLaunchKernelGGL(k_seg_level0, dim3(cdiv(n_tris, B)), dim3(B), 0, st, boxes, order, n, seg);
-  for (int l = 1; l < lv.levels; ++l)
-    hipLaunchKernelGGL(k_seg_level, dim3(cdiv(lv.cnt[l], B)), dim3(B), 0, st, seg + lv.off[l - 1], (int)lv.cnt[l - 1],
-                       seg + lv.off[l], (int)lv.cnt[l]);
+  for (int l = 0; l + 1 < lv.levels; l += 3) {
+    const uint32_t n1 = lv.cnt[l + 1];
+    const uint32_t n2 = l + 2 < lv.levels ? lv.cnt[l + 2] : 0, n3 = l + 3 < lv.levels ? lv.cnt[l + 3] : 0;
+    const uint32_t o2 = l + 2 < lv.levels ? lv.off[l + 2] : 0, o3 = l + 3 < lv.levels ? lv.off[l + 3] : 0;
+    const uint32_t threads = (n1 + 3) / 4;
+    hipLaunchKernelGGL(k_seg_level3, dim3(cdiv(threads, B)), dim3(B), 0, st, seg, lv.off[l], lv.cnt[l], lv.off[l + 1], n1, o2,
+                       n2, o3, n3);
+  }
   hipLaunchKernelGGL(k_emit, dim3(cdiv(2 * n_tris - 1, B)), dim3(B), 0, st, n, range, parent, seg, lv, order, raw,
                      nodes, tris, slot_first);
+  hipLaunchKernelGGL(k_node_ext_small, dim3(cdiv(2 * n_tris - 1, B)), dim3(B), 0, st, nodes, slot_first, tris,
+                     (uint32_t)(2 * n_tris - 1), ext);
   hipLaunchKernelGGL(k_node_ext, dim3(cdiv(2 * n_tris - 1, 4)), dim3(B), 0, st, nodes, slot_first, tris,
                      (uint32_t)(2 * n_tris - 1), ext);
   M2S_HIP_CHECK(hipGetLastError());

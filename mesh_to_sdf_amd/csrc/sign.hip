@@ -19,7 +19,7 @@ namespace m2s {
 
 namespace {
 
-constexpr int SMALL_WINDOW = 32;  // lines a lane handles alone; larger windows are spread over the wave
+constexpr int SMALL_WINDOW = 64;  // lines a lane handles alone; larger windows are spread over the wave
 
 struct Window {
   uint32_t ulo, uhi, wlo, whi;  // inclusive index ranges on the two free axes; empty if ulo > uhi
@@ -32,8 +32,11 @@ __device__ __forceinline__ void axis_range(float bmn, float bmx, float first, fl
   if (i0 > i1) { float t = i0; i0 = i1; i1 = t; }
   const bool bad = !(i0 == i0) || !(i1 == i1) || !(fabsf(i0) < 3.0e38f) || !(fabsf(i1) < 3.0e38f);
   if (bad) { *lo = 0; *hi = n - 1; return; }
-  const float l = floorf(i0) - 1.0f, h = ceilf(i1) + 1.0f;
-  if (h < 0.0f || l > (float)(n - 1)) { *lo = 1; *hi = 0; return; }
+  // cells whose centre index lies in [i0, i1], widened by a tolerance that covers the f32 rounding of
+  // the index computation (the exact closed-interval test on the true centres decides membership)
+  const float tol = 1.0e-3f + 4.0e-6f * fmaxf(fabsf(i0), fabsf(i1)) + 1.0e-6f * (fabsf(bmn) + fabsf(bmx) + fabsf(first)) / fabsf(cs);
+  const float l = ceilf(i0 - tol), h = floorf(i1 + tol);
+  if (h < 0.0f || l > (float)(n - 1) || h < l) { *lo = 1; *hi = 0; return; }
   *lo = l < 0.0f ? 0u : (uint32_t)l;
   *hi = h >= (float)(n - 1) ? n - 1 : (uint32_t)h;
 }
@@ -179,6 +182,30 @@ __global__ __launch_bounds__(256) void k_scan_z_combine(const uint32_t* __restri
   }
 }
 
+// Same as k_scan_z_combine with one LANE per 32-bit word (coalesced): the nzw words of a row sit in
+// nzw consecutive lanes (nzw a power of two <= 64), the carry from the higher words of the row is a
+// segmented suffix-XOR of the word parities done with shuffles.
+__global__ __launch_bounds__(256) void k_scan_z_combine_rows(const uint32_t* __restrict__ px,
+                                                             const uint32_t* __restrict__ py, uint32_t* __restrict__ pz,
+                                                             size_t words, uint32_t nzw) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool valid = i < words;
+  uint32_t z = valid ? pz[i] : 0u;
+  z ^= z >> 1; z ^= z >> 2; z ^= z >> 4; z ^= z >> 8; z ^= z >> 16;     // bit b = XOR of marker bits >= b
+  const uint32_t zw = (uint32_t)(i & (nzw - 1));                          // word index inside the row
+  uint32_t par = z & 1u;                                                  // parity of the whole word
+  uint32_t c = par;                                                       // inclusive suffix XOR over the row
+  for (uint32_t off = 1; off < nzw; off <<= 1) {
+    const uint32_t t = __shfl_down(c, off);
+    if (zw + off < nzw) c ^= t;
+  }
+  if ((c ^ par) & 1u) z = ~z;                                             // exclusive: words above this one
+  if (valid) {
+    const uint32_t x = px[i], y = py[i];
+    pz[i] = (x & y) | (x & z) | (y & z);
+  }
+}
+
 }  // namespace
 
 size_t sign_workspace_bytes(const GridParams& g) {
@@ -208,7 +235,10 @@ int build_grid_sign_plane(Arena& ws, hipStream_t st, const DeviceMesh& mesh, con
     const size_t ycols = (size_t)g.n[0] * g.nzw;
     hipLaunchKernelGGL(k_scan_y, dim3((unsigned)((ycols + B - 1) / B)), dim3(B), 0, st, py, g.n[0], g.n[1], g.nzw);
     const size_t rows = (size_t)g.n[0] * g.n[1];
-    hipLaunchKernelGGL(k_scan_z_combine, dim3((unsigned)((rows + B - 1) / B)), dim3(B), 0, st, px, py, pz, rows, g.nzw);
+    if (g.nzw <= 64 && (g.nzw & (g.nzw - 1)) == 0)
+      hipLaunchKernelGGL(k_scan_z_combine_rows, dim3((unsigned)((words + B - 1) / B)), dim3(B), 0, st, px, py, pz, words, g.nzw);
+    else
+      hipLaunchKernelGGL(k_scan_z_combine, dim3((unsigned)((rows + B - 1) / B)), dim3(B), 0, st, px, py, pz, rows, g.nzw);
   }
   M2S_HIP_CHECK(hipGetLastError());
   return 0;

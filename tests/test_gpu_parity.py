@@ -376,3 +376,56 @@ def test_sharded_driver_single_process(suzanne):
     dv, di = torch.as_tensor(v, device="cuda"), torch.as_tensor(idx.astype(np.int64), device="cuda")
     out = generate_grid_sdf_sharded(dv, Topology.TriangleList(di), g, SignMethod.Raycast, chunks=4)
     assert_bit_equal(out.cpu().numpy(), generate_grid_sdf(v, Topology.TriangleList(idx), g), "sharded driver")
+
+
+# ---- nastier inputs ---------------------------------------------------------------------------------
+def test_huge_and_tiny_triangles_mixed():
+    # two triangles spanning far beyond the grid (k_ray_mark's wave-cooperative window path) + a small blob
+    v, idx = meshes.blob(20, 11)
+    big = np.array([[-50, -50, 0.3], [50, -50, 0.31], [0, 60, 0.29], [-40, 0.2, -45], [45, 0.21, -44], [0.5, 0.19, 70]], F)
+    vv = np.concatenate([v, big]).astype(F)
+    ii = np.concatenate([idx, len(v) + np.arange(6, dtype=np.uint32)])
+    g = Grid.from_bounding_box([-2, -2, -2], [2, 2, 2], [44, 40, 36])
+    for sign in (SignMethod.Raycast, SignMethod.Normal):
+        got = generate_grid_sdf(vv, Topology.TriangleList(ii), g, sign)
+        assert_bit_equal(got, oracle_grid(vv, ii, g, sign, semantics=orc.EXACT), f"huge triangles {sign.name}")
+    q = meshes.uniform_queries([-3, -3, -3], [3, 3, 3], 6000)
+    for name, am, accel, sign in ACCELS:
+        assert_bit_equal(generate_sdf(vv, Topology.TriangleList(ii), q, am), orc.generate_sdf(vv, ii, q, accel=accel, sign=sign), name)
+
+
+@pytest.mark.parametrize("ntri", [1, 2, 3, 5])
+def test_tiny_meshes(ntri):
+    rng = np.random.default_rng(ntri)
+    v = rng.uniform(-1, 1, (3 * ntri, 3)).astype(F)
+    g = Grid.from_bounding_box([-1.5, -1.5, -1.5], [1.5, 1.5, 1.5], [17, 19, 23])
+    for sign in (SignMethod.Raycast, SignMethod.Normal):
+        got = generate_grid_sdf(v, Topology.TriangleList(None), g, sign)
+        assert_bit_equal(got, oracle_grid(v, None, g, sign, semantics=orc.EXACT), f"{ntri} tris {sign.name}")
+    q = meshes.uniform_queries([-2, -2, -2], [2, 2, 2], 3000)
+    for name, am, accel, sign in ACCELS:
+        assert_bit_equal(generate_sdf(v, Topology.TriangleList(None), q, am), orc.generate_sdf(v, None, q, accel=accel, sign=sign), name)
+
+
+def test_grid_large_coordinates():
+    v, idx = meshes.blob(50, 31)
+    v = (v * F(3.0) + np.array([1000.0, -2000.0, 500.0], F)).astype(F)
+    g = grid_of(v, [40, 40, 40])
+    for sign in (SignMethod.Raycast, SignMethod.Normal):
+        assert_bit_equal(generate_grid_sdf(v, Topology.TriangleList(idx), g, sign), oracle_grid(v, idx, g, sign), f"offset grid {sign.name}")
+
+
+def test_nonfinite_vertices_raycast():
+    # f32::min drops NaN distances (default.rs:47) and NaN never passes the strict ray test (geo.rs:203):
+    # in Raycast mode a triangle with a NaN / inf vertex must simply not matter, also through the BVH.
+    v, idx = meshes.blob(24, 13)
+    bad = np.array([[np.nan, 0.1, 0.2], [0.3, np.inf, 0.1], [0.2, 0.2, -np.inf], [0.1, 0.0, 0.3]], F)
+    vv = np.concatenate([v, bad]).astype(F)
+    n = len(v)
+    ii = np.concatenate([idx, np.array([n, 0, 1, n + 1, 2, 3, 4, n + 2, 5, n + 3, n, 6], np.uint32)])
+    g = grid_of(v, [24, 24, 24], 0.2)
+    got = generate_grid_sdf(vv, Topology.TriangleList(ii), g, SignMethod.Raycast)
+    assert_bit_equal(got, oracle_grid(vv, ii, g, SignMethod.Raycast, semantics=orc.EXACT), "non-finite grid")
+    q = meshes.uniform_queries(*meshes.extended_bbox(v, 0.3), 4000)
+    for name, am, accel, sign in (ACCELS[0], ACCELS[2], ACCELS[5]):
+        assert_bit_equal(generate_sdf(vv, Topology.TriangleList(ii), q, am), orc.generate_sdf(vv, ii, q, accel=accel, sign=sign), name)
