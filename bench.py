@@ -94,10 +94,16 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus}")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+    local_dev = local_rank % max(torch.cuda.device_count(), 1)   # one rank per GPU; the modulo only matters in 1-GPU tests
+    torch.cuda.set_device(local_dev)
+    dev = torch.device("cuda", local_dev)
+    force_pg = os.environ.get("M2S_FORCE_COLLECTIVES", "0") == "1"   # test hook: 1-rank RCCL group
+    if world > 1 or (force_pg and "MASTER_ADDR" in os.environ):
+        backend = os.environ.get("M2S_DIST_BACKEND", "nccl")   # "nccl" == RCCL over xGMI; gloo only for 1-GPU logic tests
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from mesh_to_sdf_amd import Grid, M2STimings, SignMethod, Topology, generate_grid_sdf, meshes
     from mesh_to_sdf_amd.distributed import generate_grid_sdf_sharded, slab_bounds
@@ -113,7 +119,7 @@ def main():
     out = torch.empty(n ** 3, dtype=torch.float32, device=dev)
     x0, x1 = slab_bounds(n, world, rank)
 
-    chunks = args.chunks if args.chunks > 0 else (4 if world > 1 else 1)
+    chunks = args.chunks if args.chunks > 0 else (4 if (world > 1 or force_pg) else 1)
 
     def step():
         # one complete call: LBVH build, sign planes, seed passes, nearest-triangle launches for this rank's
@@ -215,7 +221,7 @@ def main():
             generate_grid_sdf(v, Topology.TriangleList(idx), grid, sign)
             res["host_pointer_call_ms"] = round((time.perf_counter() - t1) * 1e3, 2)
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

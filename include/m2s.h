@@ -106,7 +106,10 @@ typedef struct m2s_opts {
   uint64_t x_end;
   m2s_timings* timings; /* filled when non-NULL (forces a stream sync before returning) */
   int32_t synchronous;  /* device-memory calls: 1 (default when opts==NULL) = sync before return; 0 = leave work enqueued */
-  int32_t reserved;
+  int32_t stream_mode;  /* 0: stream == NULL selects the library's own (non-blocking) stream;
+                           1: `stream` is used exactly as given, and NULL means the device's default (null) stream —
+                              needed by callers whose "current stream" IS the default stream (torch does this) and who
+                              order other work (e.g. an RCCL collective) after this call without a host sync */
 } m2s_opts;
 
 /* generate_sdf — lib.rs:291-311.

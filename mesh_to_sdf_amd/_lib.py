@@ -47,7 +47,7 @@ class M2SOpts(C.Structure):
         ("x_end", C.c_uint64),
         ("timings", C.POINTER(M2STimings)),
         ("synchronous", C.c_int32),
-        ("reserved", C.c_int32),
+        ("stream_mode", C.c_int32),
     ]
 
 

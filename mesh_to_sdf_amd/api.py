@@ -225,7 +225,10 @@ class _Args:
             o.timings = C.pointer(timings)
         if self.device:
             o.device = self.dev.index if self.dev.index is not None else self.torch.cuda.current_device()
+            # torch's current stream, exactly: its default stream has handle 0, which must NOT be read as
+            # "pick your own stream" or work torch orders after this call (collectives!) would race with it
             o.stream = self.torch.cuda.current_stream(self.dev).cuda_stream
+            o.stream_mode = 1
             o.mem_kind = _lib.MEM_DEVICE
         else:
             o.device = -1

@@ -267,7 +267,7 @@ __global__ __launch_bounds__(256) void k_emit(int n, const int2* __restrict__ ra
                                               const Box* __restrict__ seg, SegLevels lv,
                                               const uint32_t* __restrict__ order, const TriRec* __restrict__ raw,
                                               NodeRec* __restrict__ nodes, TriRec* __restrict__ tris,
-                                              uint32_t* __restrict__ slot_first) {
+                                              uint32_t* __restrict__ slot_first, float4* __restrict__ cen) {
   const int id = blockIdx.x * blockDim.x + threadIdx.x;
   if (id >= 2 * n - 1) return;
   const bool leaf = id >= n - 1;
@@ -292,7 +292,12 @@ __global__ __launch_bounds__(256) void k_emit(int n, const int2* __restrict__ ra
   nr.tri = leaf ? first : -1;
   nodes[slot] = nr;
   slot_first[slot] = (uint32_t)first;
-  if (leaf) tris[first] = raw[order[first]];
+  if (leaf) {
+    const TriRec r = raw[order[first]];
+    tris[first] = r;
+    cen[first] = make_float4((r.ax + r.bx + r.cx) * (1.0f / 3.0f), (r.ay + r.by + r.cy) * (1.0f / 3.0f),
+                             (r.az + r.bz + r.cz) * (1.0f / 3.0f), 0.0f);
+  }
 }
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -443,7 +448,7 @@ size_t bvh_workspace_bytes(size_t n_tris) {
   (void)rocprim::radix_sort_pairs(nullptr, sort_tmp, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr,
                             (uint32_t*)nullptr, n, 0, 64, (hipStream_t)0);
   size_t b = 0;
-  b += n * sizeof(TriRec) * 2 + n * sizeof(Box) * 3 + n * (8 + 4) * 2 + sort_tmp;
+  b += n * sizeof(TriRec) * 2 + n * 16 + 256 + n * sizeof(Box) * 3 + n * (8 + 4) * 2 + sort_tmp;
   b += n * (sizeof(int2) * 2) + 2 * n * sizeof(int) + 2 * n * sizeof(NodeRec) + 2 * n * (sizeof(NodeExt) + 4);
   return b + 64 * 256 + 4096 + 24 * ((n + 255) / 256) + 256;
 }
@@ -452,6 +457,7 @@ int build_device_mesh(Arena& ws, hipStream_t st, const float* d_verts, size_t n_
                       size_t n_indices, int index_bytes, int topology, size_t n_tris, int* d_err, DeviceMesh* out) {
   (void)n_indices;
   out->tris = nullptr;
+  out->cen = nullptr;
   out->nodes = nullptr;
   out->ext = nullptr;
   out->stats = nullptr;
@@ -463,6 +469,7 @@ int build_device_mesh(Arena& ws, hipStream_t st, const float* d_verts, size_t n_
 
   TriRec* raw = ws.take<TriRec>(n_tris);
   TriRec* tris = ws.take<TriRec>(n_tris);
+  float4* cen = ws.take<float4>(n_tris);
   Box* boxes = ws.take<Box>(n_tris);
   Box* seg = ws.take<Box>(2 * n_tris + 64);
   uint64_t* keys = ws.take<uint64_t>(n_tris);
@@ -480,7 +487,7 @@ int build_device_mesh(Arena& ws, hipStream_t st, const float* d_verts, size_t n_
   (void)rocprim::radix_sort_pairs(nullptr, sort_tmp, keys, keys2, vals, order, n_tris, 0, 64, st);
   void* tmp = ws.take<char>(sort_tmp ? sort_tmp : 1);
   if (!raw || !tris || !boxes || !seg || !keys || !keys2 || !vals || !order || !range || !child || !parent || !nodes ||
-      !scene || !tmp || !ext || !slot_first) {
+      !scene || !tmp || !ext || !slot_first || !cen) {
     set_error("internal: BVH workspace too small");
     return M2S_ERR_HIP_INTERNAL;
   }
@@ -517,13 +524,14 @@ int build_device_mesh(Arena& ws, hipStream_t st, const float* d_verts, size_t n_
                        n2, o3, n3);
   }
   hipLaunchKernelGGL(k_emit, dim3(cdiv(2 * n_tris - 1, B)), dim3(B), 0, st, n, range, parent, seg, lv, order, raw,
-                     nodes, tris, slot_first);
+                     nodes, tris, slot_first, cen);
   hipLaunchKernelGGL(k_node_ext_small, dim3(cdiv(2 * n_tris - 1, B)), dim3(B), 0, st, nodes, slot_first, tris,
                      (uint32_t)(2 * n_tris - 1), ext);
   hipLaunchKernelGGL(k_node_ext, dim3(cdiv(2 * n_tris - 1, 4)), dim3(B), 0, st, nodes, slot_first, tris,
                      (uint32_t)(2 * n_tris - 1), ext);
   M2S_HIP_CHECK(hipGetLastError());
   out->tris = tris;
+  out->cen = cen;
   out->nodes = nodes;
   out->ext = ext;
   out->scene = scene;

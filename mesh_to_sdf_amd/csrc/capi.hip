@@ -103,7 +103,7 @@ int resolve_ctx(const m2s_opts* opts, CallCtx* c, DeviceState** st) {
   c->device = dev;
   int rc = get_state(dev, st);
   if (rc) return rc;
-  c->stream = (opts && opts->stream) ? (hipStream_t)opts->stream : (*st)->stream;
+  c->stream = (opts && (opts->stream || opts->stream_mode == 1)) ? (hipStream_t)opts->stream : (*st)->stream;
   return 0;
 }
 

@@ -62,6 +62,7 @@ static_assert(sizeof(NodeExt) == 48, "NodeExt must be 48 bytes");
 
 struct DeviceMesh {
   const TriRec* tris;   // n_tris records, Morton order
+  const float4* cen;    // n_tris triangle centroids (same order), for the jump-flooding seed pass
   const NodeRec* nodes; // n_nodes = 2*n_tris - 1 (0 if n_tris == 0)
   const NodeExt* ext;   // n_nodes oriented bounds
   unsigned long long* stats;  // optional traversal counters (M2S_STATS=1), else nullptr

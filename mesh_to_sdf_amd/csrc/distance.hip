@@ -69,19 +69,17 @@ struct Best {
   float d2 = __builtin_inff();      // min d2 over all triangles
   float d2pos = __builtin_inff();   // MODE_NORMAL_FOLD: min d2 over triangles with positive signed distance
   uint32_t idx = 0xffffffffu;       // MODE_NEAREST_NORMAL: triangle achieving d2 (lowest index on ties)
-  uint32_t slot = 0;                // seed passes: TriRec slot (Morton order) achieving d2
   bool pos = false;                 // MODE_NEAREST_NORMAL: its sign
   bool nan = false;
 };
 
-template <int MODE, bool TRACK = false>
-__device__ __forceinline__ void eval_triangle(Best<MODE>& best, f3 p, const TriRec& tr, uint32_t slot = 0) {
+template <int MODE>
+__device__ __forceinline__ void eval_triangle(Best<MODE>& best, f3 p, const TriRec& tr) {
   const f3 a = mk3(tr.ax, tr.ay, tr.az), b = mk3(tr.bx, tr.by, tr.bz), c = mk3(tr.cx, tr.cy, tr.cz);
   const TriEdges e = {mk3(tr.abx, tr.aby, tr.abz), mk3(tr.acx, tr.acy, tr.acz), mk3(tr.bcx, tr.bcy, tr.bcz)};
   const uint32_t cls = tr.cls, index = tr.index;
   if (MODE == MODE_UNSIGNED) {
     const float d2 = point_triangle_dist2(p, a, b, c, e, cls);
-    if (TRACK && d2 < best.d2) best.slot = slot;
     best.d2 = fminf(best.d2, d2);  // f32::min drops a NaN operand (default.rs:47)
   } else {
     bool positive;
@@ -160,17 +158,15 @@ __device__ __forceinline__ uint32_t stab_count(const DeviceMesh& mesh, f3 p) {
 }
 
 // ---- k_packet -------------------------------------------------------------------------------
-// SEEDPASS: instead of a distance, write for every point the TriRec slot of its nearest triangle
-// (`seed_out`, same indexing as `out`); used on coarse lattices whose points are the brick
-// centres of the next finer level.  `seed_in` (one slot per packet, may be null) replaces the
-// greedy descent: the packet starts from the nearest triangle of its own centre.
-template <bool GRID, int MODE, int SIGN, bool SEEDPASS = false>
+// `seed_in` (one TriRec slot per 2^seed_shift bricks per axis, may be null) replaces the greedy descent:
+// the packet starts from a triangle near its own centre (jump-flooding seed pass below).
+template <bool GRID, int MODE, int SIGN>
 __global__ __launch_bounds__(256) void k_packet(DeviceMesh mesh, GridParams g, const float4* __restrict__ qsorted,
                                                 const uint32_t* __restrict__ perm, uint32_t n_q,
                                                 const uint32_t* __restrict__ plane, float* __restrict__ out,
                                                 int* __restrict__ err, uint32_t n_packets, uint32_t chunk,
-                                                const uint32_t* __restrict__ seed_in, uint32_t* __restrict__ seed_out,
-                                                uint32_t seed_shift, uint32_t seed_ny, uint32_t seed_nz, uint32_t node_budget) {
+                                                const uint32_t* __restrict__ seed_in, uint32_t seed_shift,
+                                                uint32_t seed_ny, uint32_t seed_nz) {
   const int lane = threadIdx.x & 63;
   const uint32_t block = xcd_remap(blockIdx.x, chunk);
   const uint32_t packet = block * 4 + (threadIdx.x >> 6);
@@ -200,7 +196,7 @@ __global__ __launch_bounds__(256) void k_packet(DeviceMesh mesh, GridParams g, c
     const float slack = 4.0e-6f * scale + (MODE == MODE_NORMAL_FOLD ? 2.5e-6f : 0.0f);
 
     if (seed_in != nullptr) {
-      // seed: nearest triangle of this packet's centre, found by the coarser pass
+      // seed: a triangle near this packet's centre, from the seed pass
       uint32_t sidx = packet;
       if (GRID) {  // 2^seed_shift bricks per axis share one seed point
         const uint32_t nby = (g.n[1] + 3) >> 2, nbz = (g.n[2] + 3) >> 2;
@@ -209,7 +205,7 @@ __global__ __launch_bounds__(256) void k_packet(DeviceMesh mesh, GridParams g, c
       }
       const uint32_t slot = min(seed_in[sidx], mesh.n_tris - 1);
       const TriRec tr = mesh.tris[slot];
-      eval_triangle<MODE, SEEDPASS>(best, p, tr, slot);
+      eval_triangle<MODE>(best, p, tr);
     } else {
       // seed: greedy descent towards the packet's first point, evaluate that leaf for every lane
       const f3 c = {__shfl(p.x, 0), __shfl(p.y, 0), __shfl(p.z, 0)};
@@ -227,7 +223,7 @@ __global__ __launch_bounds__(256) void k_packet(DeviceMesh mesh, GridParams g, c
         nr = go_left ? nl : nrr;
       }
       const TriRec tr = mesh.tris[nr.tri];
-      eval_triangle<MODE, SEEDPASS>(best, p, tr, (uint32_t)nr.tri);
+      eval_triangle<MODE>(best, p, tr);
     }
 
     float thr = prune_bound(best.d2, slack);
@@ -240,13 +236,12 @@ __global__ __launch_bounds__(256) void k_packet(DeviceMesh mesh, GridParams g, c
       node = __builtin_amdgcn_readfirstlane(node);
       const NodeExt nr = mesh.ext[node];
       ++st_box;
-      if (SEEDPASS && st_box > node_budget) break;   // a seed may be approximate: bound the wave's latency
       const float ed2 = ext_dist2(p, nr);
       if (__ballot(!(ed2 > thr)) == 0ull) { node = nr.skip; continue; }   // a NaN bound keeps the node
       if (nr.tri >= 0) {
         ++st_leaf;
         const TriRec tr = mesh.tris[nr.tri];
-        eval_triangle<MODE, SEEDPASS>(best, p, tr, (uint32_t)nr.tri);
+        eval_triangle<MODE>(best, p, tr);
         thr = prune_bound(best.d2, slack);
         node = nr.skip;
       } else {
@@ -255,10 +250,7 @@ __global__ __launch_bounds__(256) void k_packet(DeviceMesh mesh, GridParams g, c
     }
     }
   }
-  if (SEEDPASS) {
-    if (store) seed_out[out_index] = best.slot;
-    return;
-  }
+
   if (mesh.stats != nullptr && lane == 0) {
     atomicAdd(&mesh.stats[0], (unsigned long long)st_box);
     atomicAdd(&mesh.stats[1], (unsigned long long)st_ext);
@@ -280,6 +272,63 @@ __global__ __launch_bounds__(256) void k_packet(DeviceMesh mesh, GridParams g, c
   if (store) out[out_index] = finish<MODE>(best, negate);
 }
 
+
+
+// ---- jump-flooding seed pass ------------------------------------------------------------------
+// Seeds only have to be GOOD, never exact (they bound the first prune, nothing else), so the seed
+// lattice (one point per 4^3 brick) is filled by jump flooding (Rong & Tan 2006) over triangle
+// CENTROIDS instead of a second exact tree walk: fully data parallel, cost proportional to the
+// lattice (no long-running waves), ~10 ops per candidate.  k_jfa_splat drops every triangle into
+// the lattice cell of its centroid (clamped, so triangles outside an x-slab still enter at the
+// border); each k_jfa_pass lets a cell adopt the best candidate of its 26 neighbours at +-step.
+__device__ __forceinline__ f3 lattice_point(const GridParams& g, uint32_t x, uint32_t y, uint32_t z) {
+  return {cell_center(g.first[0], g.size[0], x), cell_center(g.first[1], g.size[1], y), cell_center(g.first[2], g.size[2], z)};
+}
+
+__global__ __launch_bounds__(256) void k_jfa_splat(DeviceMesh mesh, GridParams g, uint32_t* __restrict__ ids) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= mesh.n_tris) return;
+  const float4 c = mesh.cen[t];
+  const float cc[3] = {c.x, c.y, c.z};
+  uint32_t cell[3];
+  for (int k = 0; k < 3; ++k) {
+    float f = (cc[k] - g.first[k]) / g.size[k] + 0.5f;
+    if (!(f == f)) return;                                   // NaN centroid: not a useful seed
+    f = fminf(fmaxf(f, 0.0f), (float)(g.n[k] - 1));
+    cell[k] = min((uint32_t)f, g.n[k] - 1);
+  }
+  atomicMin(&ids[((size_t)cell[0] * g.n[1] + cell[1]) * g.n[2] + cell[2]], t);
+}
+
+__global__ __launch_bounds__(256) void k_jfa_pass(DeviceMesh mesh, GridParams g, const uint32_t* __restrict__ in,
+                                                  uint32_t* __restrict__ out, int step) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)g.n[0] * g.n[1] * g.n[2];
+  if (i >= total) return;
+  const int z = (int)(i % g.n[2]), y = (int)((i / g.n[2]) % g.n[1]), x = (int)(i / ((size_t)g.n[2] * g.n[1]));
+  const f3 p = lattice_point(g, (uint32_t)x, (uint32_t)y, (uint32_t)z);
+  uint32_t best = 0xffffffffu;
+  float bd = __builtin_inff();
+  for (int dx = -1; dx <= 1; ++dx) {
+    const int xx = x + dx * step;
+    if (xx < 0 || xx >= (int)g.n[0]) continue;
+    for (int dy = -1; dy <= 1; ++dy) {
+      const int yy = y + dy * step;
+      if (yy < 0 || yy >= (int)g.n[1]) continue;
+      for (int dz = -1; dz <= 1; ++dz) {
+        const int zz = z + dz * step;
+        if (zz < 0 || zz >= (int)g.n[2]) continue;
+        const uint32_t cand = in[((size_t)xx * g.n[1] + yy) * g.n[2] + zz];
+        if (cand == 0xffffffffu) continue;
+        const float4 c = mesh.cen[cand];
+        const float ex = p.x - c.x, ey = p.y - c.y, ez = p.z - c.z;
+        const float d = __builtin_fmaf(ex, ex, __builtin_fmaf(ey, ey, ez * ez));
+        if (d < bd || (d == bd && cand < best)) { bd = d; best = cand; }
+      }
+    }
+  }
+  out[i] = best;
+}
 
 // ---- k_brute --------------------------------------------------------------------------------
 template <bool GRID, int MODE, int SIGN>
@@ -413,17 +462,16 @@ __global__ __launch_bounds__(256) void k_qgather(const float* __restrict__ q, co
   sorted[i] = make_float4(q[3 * s], q[3 * s + 1], q[3 * s + 2], 0.0f);
 }
 
-template <bool GRID, int MODE, int SIGN, bool SEEDPASS = false>
+template <bool GRID, int MODE, int SIGN>
 void launch_packet(hipStream_t st, const DeviceMesh& mesh, const GridParams& g, const float4* qs, const uint32_t* perm,
                    uint32_t n_q, const uint32_t* plane, float* out, int* err, uint32_t n_packets,
-                   const uint32_t* seed_in = nullptr, uint32_t* seed_out = nullptr, uint32_t seed_shift = 0,
-                   uint32_t seed_ny = 0, uint32_t seed_nz = 0) {
-  static const uint32_t node_budget = getenv("M2S_SEED_BUDGET") ? (uint32_t)atoi(getenv("M2S_SEED_BUDGET")) : 0xffffffffu;
+                   const uint32_t* seed_in = nullptr, uint32_t seed_shift = 0, uint32_t seed_ny = 0,
+                   uint32_t seed_nz = 0) {
   const uint32_t blocks = (n_packets + 3) / 4;
   static const bool remap = !(getenv("M2S_XCD_REMAP") && atoi(getenv("M2S_XCD_REMAP")) == 0);
   const uint32_t chunk = remap ? (blocks + 7) / 8 : 0;
-  hipLaunchKernelGGL((k_packet<GRID, MODE, SIGN, SEEDPASS>), dim3(remap ? chunk * 8 : blocks), dim3(256), 0, st, mesh, g,
-                     qs, perm, n_q, plane, out, err, n_packets, chunk, seed_in, seed_out, seed_shift, seed_ny, seed_nz, node_budget);
+  hipLaunchKernelGGL((k_packet<GRID, MODE, SIGN>), dim3(remap ? chunk * 8 : blocks), dim3(256), 0, st, mesh, g,
+                     qs, perm, n_q, plane, out, err, n_packets, chunk, seed_in, seed_shift, seed_ny, seed_nz);
 }
 template <bool GRID, int MODE, int SIGN>
 void launch_brute(hipStream_t st, const DeviceMesh& mesh, const GridParams& g, const float* q, uint32_t n_q,
@@ -455,7 +503,7 @@ static GridParams coarse_level(const GridParams& fine, uint32_t stride, uint32_t
 
 size_t grid_distance_workspace_bytes(const GridParams& g) {
   const size_t bricks = (size_t)host_brick_count(g);
-  return bricks * 4 + bricks + 8192;
+  return bricks * 8 + bricks + 8192;
 }
 
 int launch_grid_distance(Arena& ws, hipStream_t st, const DeviceMesh& mesh, const GridParams& g, int mode,
@@ -468,36 +516,30 @@ int launch_grid_distance(Arena& ws, hipStream_t st, const DeviceMesh& mesh, cons
   const uint32_t packets = host_brick_count(g);
   const bool brute = algorithm == 1;
 
-  // Hierarchical seeding (BVH path): level 2 = one point per 16^3 voxels (greedy seeds), level 1 = one
-  // point per 4^3 brick seeded from level 2; every fine packet then starts from the nearest triangle of
-  // its own brick centre.  ~1.6 % extra points; halves the nodes visited by the fine pass.
+  // Seeding: every 4^3 brick starts its walk from a triangle near its own centre (jump flooding over
+  // the lattice of brick centres, below); that halves the nodes visited compared with a greedy descent.
   const uint32_t* seed1 = nullptr;
   uint32_t sh1 = 0, s1ny = 0, s1nz = 0;
-  static const int seed_stride = getenv("M2S_SEED_STRIDE") ? atoi(getenv("M2S_SEED_STRIDE")) : 4;   // 0 = off, 4, 8, 16
-  static const int seed_top = getenv("M2S_SEED_TOP") ? atoi(getenv("M2S_SEED_TOP")) : 0;            // seed the seed pass too
-  if (!brute && mesh.n_tris && packets >= 64 && seed_stride >= 4) {
-    const uint32_t S1 = (uint32_t)seed_stride;
-    sh1 = S1 == 4 ? 0 : (S1 == 8 ? 1 : 2);
-    const GridParams g1 = coarse_level(g, S1, g.xb);
-    const uint32_t packets1 = host_brick_count(g1);
+  static const bool use_seeds = !(getenv("M2S_SEEDS") && atoi(getenv("M2S_SEEDS")) == 0);
+  if (!brute && mesh.n_tris && packets >= 8 && use_seeds) {
+    const GridParams g1 = coarse_level(g, 4, g.xb);
     const size_t points1 = (size_t)g1.n[0] * g1.n[1] * g1.n[2];
     uint32_t* s1 = ws.take<uint32_t>(points1);
-    if (!s1) { set_error("internal: seed workspace too small"); return M2S_ERR_HIP_INTERNAL; }
-    const uint32_t* seed2 = nullptr;
-    uint32_t s2ny = 0, s2nz = 0;
-    if (seed_top && packets1 >= 64) {
-      const GridParams g2 = coarse_level(g, 4 * S1, g.xb);   // one point per packet of level 1
-      uint32_t* s2 = ws.take<uint32_t>((size_t)g2.n[0] * g2.n[1] * g2.n[2]);
-      if (!s2) { set_error("internal: seed workspace too small"); return M2S_ERR_HIP_INTERNAL; }
-      launch_packet<true, MODE_UNSIGNED, SIGN_NONE, true>(st, mesh, g2, nullptr, nullptr, 0, nullptr, nullptr, d_err,
-                                                          host_brick_count(g2), nullptr, s2);
-      seed2 = s2;
-      s2ny = g2.n[1];
-      s2nz = g2.n[2];
+    uint32_t* s1b = ws.take<uint32_t>(points1);
+    if (!s1 || !s1b) { set_error("internal: seed workspace too small"); return M2S_ERR_HIP_INTERNAL; }
+    M2S_HIP_CHECK(hipMemsetAsync(s1, 0xff, points1 * 4, st));
+    hipLaunchKernelGGL(k_jfa_splat, dim3((mesh.n_tris + 255) / 256), dim3(256), 0, st, mesh, g1, s1);
+    const uint32_t maxdim = max(g1.n[0], max(g1.n[1], g1.n[2]));
+    int step = 1;
+    while ((uint32_t)step * 2 < maxdim) step *= 2;
+    uint32_t *src = s1, *dst = s1b;
+    const unsigned nb = (unsigned)((points1 + 255) / 256);
+    for (; step >= 1; step /= 2) {
+      hipLaunchKernelGGL(k_jfa_pass, dim3(nb), dim3(256), 0, st, mesh, g1, src, dst, step);
+      uint32_t* t = src; src = dst; dst = t;
     }
-    launch_packet<true, MODE_UNSIGNED, SIGN_NONE, true>(st, mesh, g1, nullptr, nullptr, 0, nullptr, nullptr, d_err, packets1,
-                                                        seed2, s1, 0, s2ny, s2nz);
-    seed1 = s1;
+    hipLaunchKernelGGL(k_jfa_pass, dim3(nb), dim3(256), 0, st, mesh, g1, src, dst, 1);   // "JFA+1": one more unit pass
+    seed1 = dst;
     s1ny = g1.n[1];
     s1nz = g1.n[2];
   }
@@ -505,13 +547,13 @@ int launch_grid_distance(Arena& ws, hipStream_t st, const DeviceMesh& mesh, cons
 
   if (mode == MODE_UNSIGNED && d_inside_plane) {
     if (brute) launch_brute<true, MODE_UNSIGNED, SIGN_GRID_PLANE>(st, mesh, g, nullptr, 0, d_inside_plane, d_out, d_err, packets);
-    else launch_packet<true, MODE_UNSIGNED, SIGN_GRID_PLANE>(st, mesh, g, nullptr, nullptr, 0, d_inside_plane, d_out, d_err, packets, seed1, nullptr, sh1, s1ny, s1nz);
+    else launch_packet<true, MODE_UNSIGNED, SIGN_GRID_PLANE>(st, mesh, g, nullptr, nullptr, 0, d_inside_plane, d_out, d_err, packets, seed1, sh1, s1ny, s1nz);
   } else if (mode == MODE_UNSIGNED) {
     if (brute) launch_brute<true, MODE_UNSIGNED, SIGN_NONE>(st, mesh, g, nullptr, 0, nullptr, d_out, d_err, packets);
-    else launch_packet<true, MODE_UNSIGNED, SIGN_NONE>(st, mesh, g, nullptr, nullptr, 0, nullptr, d_out, d_err, packets, seed1, nullptr, sh1, s1ny, s1nz);
+    else launch_packet<true, MODE_UNSIGNED, SIGN_NONE>(st, mesh, g, nullptr, nullptr, 0, nullptr, d_out, d_err, packets, seed1, sh1, s1ny, s1nz);
   } else {
     if (brute) launch_brute<true, MODE_NORMAL_FOLD, SIGN_NONE>(st, mesh, g, nullptr, 0, nullptr, d_out, d_err, packets);
-    else launch_packet<true, MODE_NORMAL_FOLD, SIGN_NONE>(st, mesh, g, nullptr, nullptr, 0, nullptr, d_out, d_err, packets, seed1, nullptr, sh1, s1ny, s1nz);
+    else launch_packet<true, MODE_NORMAL_FOLD, SIGN_NONE>(st, mesh, g, nullptr, nullptr, 0, nullptr, d_out, d_err, packets, seed1, sh1, s1ny, s1nz);
   }
   M2S_HIP_CHECK(hipGetLastError());
   return 0;

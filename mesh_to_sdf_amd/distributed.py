@@ -18,6 +18,12 @@ from typing import Callable, List, Optional, Tuple
 from .api import Grid, Mesh, SignMethod, Topology, generate_grid_sdf
 
 
+import os
+
+# Test hook: run the collectives even in a 1-rank group (exercises the RCCL calls on a 1-GPU box).
+_FORCE_COLLECTIVES = os.environ.get("M2S_FORCE_COLLECTIVES", "0") == "1"
+
+
 def slab_bounds(nx: int, world: int, rank: int) -> Tuple[int, int]:
     """Contiguous x-slab [x0, x1) of rank `rank` out of `world`; sizes differ by at most one layer."""
     base, rem = divmod(nx, world)
@@ -51,7 +57,7 @@ def gather_chunk(out, chunk: Tuple[int, int], row_cells: int, group=None, async_
     import torch.distributed as dist
 
     world = dist.get_world_size(group)
-    if world == 1:
+    if world == 1 and not _FORCE_COLLECTIVES:
         return None
     rank = dist.get_rank(group)
     c0, c1 = chunk
@@ -101,7 +107,7 @@ def generate_grid_sdf_sharded(vertices, indices: Topology, grid: Grid, sign_meth
     if out is None:
         dev = vertices.device if hasattr(vertices, "device") else "cpu"
         out = torch.empty(nx * row, dtype=torch.float32, device=dev)
-    plan = chunk_plan(nx, world, chunks if world > 1 else 1)
+    plan = chunk_plan(nx, world, chunks if (world > 1 or _FORCE_COLLECTIVES) else 1)
     own_mesh = None
     if compute_slab is None and mesh is None:
         mesh = own_mesh = Mesh(vertices, indices)   # LBVH built once for all pieces of this call
@@ -115,7 +121,7 @@ def generate_grid_sdf_sharded(vertices, indices: Topology, grid: Grid, sign_meth
                 # asynchronous: the kernels are only enqueued, so the collective of the previous chunk
                 # (already running on RCCL's stream) overlaps them
                 mesh.generate_grid_sdf(grid, sign_method, x_slab=(a, b), out=out, synchronous=False)
-            if gather and world > 1:
+            if gather and (world > 1 or (_FORCE_COLLECTIVES and inited)):
                 pending.append(gather_chunk(out, chunk, row, group, async_op=True))
         for w in pending:
             _wait(w)

@@ -429,3 +429,52 @@ def test_nonfinite_vertices_raycast():
     q = meshes.uniform_queries(*meshes.extended_bbox(v, 0.3), 4000)
     for name, am, accel, sign in (ACCELS[0], ACCELS[2], ACCELS[5]):
         assert_bit_equal(generate_sdf(vv, Topology.TriangleList(ii), q, am), orc.generate_sdf(vv, ii, q, accel=accel, sign=sign), name)
+
+
+def _two_rank_worker(rank, world, port, q):
+    import os
+
+    import torch
+    import torch.distributed as dist
+
+    from mesh_to_sdf_amd.distributed import generate_grid_sdf_sharded
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)   # RCCL refuses two ranks on one GPU; gloo moves CUDA tensors
+    try:
+        v, idx = meshes.blob(40, 21)
+        g = grid_of(v, [48, 20, 28])
+        dv, di = torch.as_tensor(v, device="cuda:0"), torch.as_tensor(idx.astype(np.int64), device="cuda:0")
+        out = generate_grid_sdf_sharded(dv, Topology.TriangleList(di), g, SignMethod.Raycast, chunks=3)
+        q.put((rank, out.cpu().numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_share_one_gpu_gloo():
+    """The complete N=2 driver flow (piece partition, asynchronous slab calls through the persistent mesh,
+    chunked in-place gathers) with both ranks on cuda:0: every rank must end with the full, exact grid."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_two_rank_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(timeout=120)
+    codes = [p.exitcode for p in procs]
+    assert codes == [0, 0], f"worker exit codes {codes}"
+    v, idx = meshes.blob(40, 21)
+    g = grid_of(v, [48, 20, 28])
+    want = oracle_grid(v, idx, g, SignMethod.Raycast)
+    for r in range(2):
+        assert_bit_equal(res[r], want, f"rank {r}")
