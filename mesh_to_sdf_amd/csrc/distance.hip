@@ -285,7 +285,7 @@ __device__ __forceinline__ f3 lattice_point(const GridParams& g, uint32_t x, uin
   return {cell_center(g.first[0], g.size[0], x), cell_center(g.first[1], g.size[1], y), cell_center(g.first[2], g.size[2], z)};
 }
 
-__global__ __launch_bounds__(256) void k_jfa_splat(DeviceMesh mesh, GridParams g, uint32_t* __restrict__ ids) {
+__global__ __launch_bounds__(256) void k_jfa_splat(DeviceMesh mesh, GridParams g, unsigned long long* __restrict__ keys) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= mesh.n_tris) return;
   const float4 c = mesh.cen[t];
@@ -297,7 +297,20 @@ __global__ __launch_bounds__(256) void k_jfa_splat(DeviceMesh mesh, GridParams g
     f = fminf(fmaxf(f, 0.0f), (float)(g.n[k] - 1));
     cell[k] = min((uint32_t)f, g.n[k] - 1);
   }
-  atomicMin(&ids[((size_t)cell[0] * g.n[1] + cell[1]) * g.n[2] + cell[2]], t);
+  // several triangles land in one cell (all those clamped onto a border cell in particular): keep the one
+  // whose centroid is nearest to the cell centre — 64-bit min over (distance bits, slot)
+  const f3 p = lattice_point(g, cell[0], cell[1], cell[2]);
+  const float ex = p.x - c.x, ey = p.y - c.y, ez = p.z - c.z;
+  const float d2 = __builtin_fmaf(ex, ex, __builtin_fmaf(ey, ey, ez * ez));
+  if (!(d2 == d2)) return;
+  const unsigned long long key = ((unsigned long long)__float_as_uint(d2) << 32) | t;
+  atomicMin(&keys[((size_t)cell[0] * g.n[1] + cell[1]) * g.n[2] + cell[2]], key);
+}
+
+__global__ __launch_bounds__(256) void k_jfa_unpack(const unsigned long long* __restrict__ keys, size_t n,
+                                                    uint32_t* __restrict__ ids) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) ids[i] = (uint32_t)(keys[i] & 0xffffffffull);   // untouched cells hold ~0: id 0xffffffff = none
 }
 
 __global__ __launch_bounds__(256) void k_jfa_pass(DeviceMesh mesh, GridParams g, const uint32_t* __restrict__ in,
@@ -503,7 +516,7 @@ static GridParams coarse_level(const GridParams& fine, uint32_t stride, uint32_t
 
 size_t grid_distance_workspace_bytes(const GridParams& g) {
   const size_t bricks = (size_t)host_brick_count(g);
-  return bricks * 8 + bricks + 8192;
+  return bricks * 16 + bricks + 16384;
 }
 
 int launch_grid_distance(Arena& ws, hipStream_t st, const DeviceMesh& mesh, const GridParams& g, int mode,
@@ -527,8 +540,12 @@ int launch_grid_distance(Arena& ws, hipStream_t st, const DeviceMesh& mesh, cons
     uint32_t* s1 = ws.take<uint32_t>(points1);
     uint32_t* s1b = ws.take<uint32_t>(points1);
     if (!s1 || !s1b) { set_error("internal: seed workspace too small"); return M2S_ERR_HIP_INTERNAL; }
-    M2S_HIP_CHECK(hipMemsetAsync(s1, 0xff, points1 * 4, st));
-    hipLaunchKernelGGL(k_jfa_splat, dim3((mesh.n_tris + 255) / 256), dim3(256), 0, st, mesh, g1, s1);
+    unsigned long long* keys = ws.take<unsigned long long>(points1);
+    if (!keys) { set_error("internal: seed workspace too small"); return M2S_ERR_HIP_INTERNAL; }
+    const unsigned nb1 = (unsigned)((points1 + 255) / 256);
+    M2S_HIP_CHECK(hipMemsetAsync(keys, 0xff, points1 * 8, st));
+    hipLaunchKernelGGL(k_jfa_splat, dim3((mesh.n_tris + 255) / 256), dim3(256), 0, st, mesh, g1, keys);
+    hipLaunchKernelGGL(k_jfa_unpack, dim3(nb1), dim3(256), 0, st, keys, points1, s1);
     const uint32_t maxdim = max(g1.n[0], max(g1.n[1], g1.n[2]));
     int step = 1;
     while ((uint32_t)step * 2 < maxdim) step *= 2;
