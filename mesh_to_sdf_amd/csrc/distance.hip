@@ -166,7 +166,8 @@ __global__ __launch_bounds__(256) void k_packet(DeviceMesh mesh, GridParams g, c
                                                 const uint32_t* __restrict__ plane, float* __restrict__ out,
                                                 int* __restrict__ err, uint32_t n_packets, uint32_t chunk,
                                                 const uint32_t* __restrict__ seed_in, uint32_t seed_shift,
-                                                uint32_t seed_ny, uint32_t seed_nz) {
+                                                uint32_t seed_ny, uint32_t seed_nz,
+                                                const GridParams* __restrict__ seed_lattice) {
   const int lane = threadIdx.x & 63;
   const uint32_t block = xcd_remap(blockIdx.x, chunk);
   const uint32_t packet = block * 4 + (threadIdx.x >> 6);
@@ -202,6 +203,16 @@ __global__ __launch_bounds__(256) void k_packet(DeviceMesh mesh, GridParams g, c
         const uint32_t nby = (g.n[1] + 3) >> 2, nbz = (g.n[2] + 3) >> 2;
         const uint32_t bz = packet % nbz, by = (packet / nbz) % nby, bx = packet / (nbz * nby);
         sidx = ((bx >> seed_shift) * seed_ny + (by >> seed_shift)) * seed_nz + (bz >> seed_shift);
+      } else {     // generic queries: the lattice cell that holds the packet's first point
+        const GridParams L = *seed_lattice;
+        const float q0[3] = {__shfl(p.x, 0), __shfl(p.y, 0), __shfl(p.z, 0)};
+        uint32_t cell[3];
+        for (int k = 0; k < 3; ++k) {
+          float f = (q0[k] - L.first[k]) / L.size[k] + 0.5f;
+          f = (f == f) ? fminf(fmaxf(f, 0.0f), (float)(L.n[k] - 1)) : 0.0f;
+          cell[k] = min((uint32_t)f, L.n[k] - 1);
+        }
+        sidx = __builtin_amdgcn_readfirstlane((cell[0] * L.n[1] + cell[1]) * L.n[2] + cell[2]);
       }
       const uint32_t slot = min(seed_in[sidx], mesh.n_tris - 1);
       const TriRec tr = mesh.tris[slot];
@@ -285,7 +296,10 @@ __device__ __forceinline__ f3 lattice_point(const GridParams& g, uint32_t x, uin
   return {cell_center(g.first[0], g.size[0], x), cell_center(g.first[1], g.size[1], y), cell_center(g.first[2], g.size[2], z)};
 }
 
-__global__ __launch_bounds__(256) void k_jfa_splat(DeviceMesh mesh, GridParams g, unsigned long long* __restrict__ keys) {
+// `gp` (device pointer) overrides `g0` when the lattice is only known on the device (generic queries).
+__global__ __launch_bounds__(256) void k_jfa_splat(DeviceMesh mesh, GridParams g0, const GridParams* __restrict__ gp,
+                                                   unsigned long long* __restrict__ keys) {
+  const GridParams g = gp ? *gp : g0;
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= mesh.n_tris) return;
   const float4 c = mesh.cen[t];
@@ -313,8 +327,9 @@ __global__ __launch_bounds__(256) void k_jfa_unpack(const unsigned long long* __
   if (i < n) ids[i] = (uint32_t)(keys[i] & 0xffffffffull);   // untouched cells hold ~0: id 0xffffffff = none
 }
 
-__global__ __launch_bounds__(256) void k_jfa_pass(DeviceMesh mesh, GridParams g, const uint32_t* __restrict__ in,
-                                                  uint32_t* __restrict__ out, int step) {
+__global__ __launch_bounds__(256) void k_jfa_pass(DeviceMesh mesh, GridParams g0, const GridParams* __restrict__ gp,
+                                                  const uint32_t* __restrict__ in, uint32_t* __restrict__ out, int step) {
+  const GridParams g = gp ? *gp : g0;
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t total = (size_t)g.n[0] * g.n[1] * g.n[2];
   if (i >= total) return;
@@ -423,26 +438,39 @@ __device__ __forceinline__ int ordf(float f) {
 }
 __device__ __forceinline__ float unordf(int i) { return __int_as_float(i >= 0 ? i : i ^ 0x7fffffff); }
 
-__global__ void k_qbounds_init(int* b) {
-  if (threadIdx.x < 3) b[threadIdx.x] = INT32_MAX;
-  else if (threadIdx.x < 6) b[threadIdx.x] = INT32_MIN;
-}
-__global__ __launch_bounds__(256) void k_qbounds(const float* __restrict__ q, uint32_t n_q, int* __restrict__ b) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  int lo[3] = {INT32_MAX, INT32_MAX, INT32_MAX}, hi[3] = {INT32_MIN, INT32_MIN, INT32_MIN};
-  if (i < n_q)
-    for (int k = 0; k < 3; ++k) {
-      const float v = q[3 * (size_t)i + k];
-      if (v == v && fabsf(v) < 3.0e38f) { lo[k] = ordf(v); hi[k] = lo[k]; }
-    }
+// Bounding box of the queries (order-encoded ints): grid-stride partials per block, folded by a second
+// one-block launch — no atomics on six hot addresses.
+constexpr unsigned QB_BLOCKS = 1024;
+__device__ __forceinline__ void qb_block_reduce(int lo[3], int hi[3], int* __restrict__ dst) {
+  __shared__ int part[6][4];
+  const int wv = threadIdx.x >> 6;
   for (int k = 0; k < 3; ++k) {
     int l = lo[k], h = hi[k];
     for (int off = 32; off > 0; off >>= 1) { l = min(l, __shfl_xor(l, off)); h = max(h, __shfl_xor(h, off)); }
-    if ((threadIdx.x & 63) == 0) {
-      if (l != INT32_MAX) atomicMin(&b[k], l);
-      if (h != INT32_MIN) atomicMax(&b[3 + k], h);
-    }
+    if ((threadIdx.x & 63) == 0) { part[k][wv] = l; part[3 + k][wv] = h; }
   }
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    const int k = threadIdx.x;
+    int v = part[k][0];
+    for (int w = 1; w < 4; ++w) v = k < 3 ? min(v, part[k][w]) : max(v, part[k][w]);
+    dst[k] = v;
+  }
+}
+__global__ __launch_bounds__(256) void k_qbounds(const float* __restrict__ q, uint32_t n_q, int* __restrict__ partial) {
+  int lo[3] = {INT32_MAX, INT32_MAX, INT32_MAX}, hi[3] = {INT32_MIN, INT32_MIN, INT32_MIN};
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_q; i += (size_t)gridDim.x * blockDim.x)
+    for (int k = 0; k < 3; ++k) {
+      const float v = q[3 * i + k];
+      if (v == v && fabsf(v) < 3.0e38f) { const int o = ordf(v); lo[k] = min(lo[k], o); hi[k] = max(hi[k], o); }
+    }
+  qb_block_reduce(lo, hi, partial + 6 * blockIdx.x);
+}
+__global__ __launch_bounds__(256) void k_qbounds_final(const int* __restrict__ partial, uint32_t n_blocks, int* __restrict__ b) {
+  int lo[3] = {INT32_MAX, INT32_MAX, INT32_MAX}, hi[3] = {INT32_MIN, INT32_MIN, INT32_MIN};
+  for (uint32_t j = threadIdx.x; j < n_blocks; j += 256)
+    for (int k = 0; k < 3; ++k) { lo[k] = min(lo[k], partial[6 * j + k]); hi[k] = max(hi[k], partial[6 * j + 3 + k]); }
+  qb_block_reduce(lo, hi, b);
 }
 __device__ __forceinline__ uint64_t expand21q(uint32_t v) {
   uint64_t x = v & 0x1fffffu;
@@ -467,6 +495,23 @@ __global__ __launch_bounds__(256) void k_qkeys(const float* __restrict__ q, uint
   keys[i] = (expand21q(c[0]) << 2) | (expand21q(c[1]) << 1) | expand21q(c[2]);
   vals[i] = i;
 }
+// Seed lattice for generic queries: QL^3 cells over the query bounding box (description kept on the device).
+constexpr uint32_t QL = 64;
+__global__ void k_qlattice(const int* __restrict__ b, GridParams* __restrict__ L) {
+  if (threadIdx.x != 0) return;
+  GridParams g{};
+  for (int k = 0; k < 3; ++k) {
+    const float lo = unordf(b[k]), hi = unordf(b[3 + k]);
+    float cs = (hi - lo) / (float)QL;
+    if (!(cs > 0.0f) || !(cs < 3.0e38f)) cs = 1.0f;
+    g.n[k] = QL;
+    g.size[k] = cs;
+    g.first[k] = ((lo == lo && fabsf(lo) < 3.0e38f) ? lo : 0.0f) + 0.5f * cs;
+  }
+  g.xb = 0; g.xe = QL; g.nzw = 0; g.out_off = 0;
+  *L = g;
+}
+
 __global__ __launch_bounds__(256) void k_qgather(const float* __restrict__ q, const uint32_t* __restrict__ perm,
                                                  uint32_t n_q, float4* __restrict__ sorted) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -479,12 +524,12 @@ template <bool GRID, int MODE, int SIGN>
 void launch_packet(hipStream_t st, const DeviceMesh& mesh, const GridParams& g, const float4* qs, const uint32_t* perm,
                    uint32_t n_q, const uint32_t* plane, float* out, int* err, uint32_t n_packets,
                    const uint32_t* seed_in = nullptr, uint32_t seed_shift = 0, uint32_t seed_ny = 0,
-                   uint32_t seed_nz = 0) {
+                   uint32_t seed_nz = 0, const GridParams* seed_lattice = nullptr) {
   const uint32_t blocks = (n_packets + 3) / 4;
   static const bool remap = !(getenv("M2S_XCD_REMAP") && atoi(getenv("M2S_XCD_REMAP")) == 0);
   const uint32_t chunk = remap ? (blocks + 7) / 8 : 0;
   hipLaunchKernelGGL((k_packet<GRID, MODE, SIGN>), dim3(remap ? chunk * 8 : blocks), dim3(256), 0, st, mesh, g,
-                     qs, perm, n_q, plane, out, err, n_packets, chunk, seed_in, seed_shift, seed_ny, seed_nz);
+                     qs, perm, n_q, plane, out, err, n_packets, chunk, seed_in, seed_shift, seed_ny, seed_nz, seed_lattice);
 }
 template <bool GRID, int MODE, int SIGN>
 void launch_brute(hipStream_t st, const DeviceMesh& mesh, const GridParams& g, const float* q, uint32_t n_q,
@@ -544,7 +589,7 @@ int launch_grid_distance(Arena& ws, hipStream_t st, const DeviceMesh& mesh, cons
     if (!keys) { set_error("internal: seed workspace too small"); return M2S_ERR_HIP_INTERNAL; }
     const unsigned nb1 = (unsigned)((points1 + 255) / 256);
     M2S_HIP_CHECK(hipMemsetAsync(keys, 0xff, points1 * 8, st));
-    hipLaunchKernelGGL(k_jfa_splat, dim3((mesh.n_tris + 255) / 256), dim3(256), 0, st, mesh, g1, keys);
+    hipLaunchKernelGGL(k_jfa_splat, dim3((mesh.n_tris + 255) / 256), dim3(256), 0, st, mesh, g1, nullptr, keys);
     hipLaunchKernelGGL(k_jfa_unpack, dim3(nb1), dim3(256), 0, st, keys, points1, s1);
     const uint32_t maxdim = max(g1.n[0], max(g1.n[1], g1.n[2]));
     int step = 1;
@@ -552,10 +597,10 @@ int launch_grid_distance(Arena& ws, hipStream_t st, const DeviceMesh& mesh, cons
     uint32_t *src = s1, *dst = s1b;
     const unsigned nb = (unsigned)((points1 + 255) / 256);
     for (; step >= 1; step /= 2) {
-      hipLaunchKernelGGL(k_jfa_pass, dim3(nb), dim3(256), 0, st, mesh, g1, src, dst, step);
+      hipLaunchKernelGGL(k_jfa_pass, dim3(nb), dim3(256), 0, st, mesh, g1, nullptr, src, dst, step);
       uint32_t* t = src; src = dst; dst = t;
     }
-    hipLaunchKernelGGL(k_jfa_pass, dim3(nb), dim3(256), 0, st, mesh, g1, src, dst, 1);   // "JFA+1": one more unit pass
+    hipLaunchKernelGGL(k_jfa_pass, dim3(nb), dim3(256), 0, st, mesh, g1, nullptr, src, dst, 1);   // "JFA+1": one more unit pass
     seed1 = dst;
     s1ny = g1.n[1];
     s1nz = g1.n[2];
@@ -580,7 +625,7 @@ size_t query_workspace_bytes(size_t n_q) {
   size_t n = n_q ? n_q : 1, tmp = 0;
   (void)rocprim::radix_sort_pairs(nullptr, tmp, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr,
                             n, 0, 64, (hipStream_t)0);
-  return n * (8 + 8 + 4 + 4 + 16) + tmp + 16 * 256;
+  return n * (8 + 8 + 4 + 4 + 16) + tmp + 16 * 256 + (size_t)64 * 64 * 64 * 16 + 8192 + 24 * 1024 + 256;
 }
 
 int launch_query_distance(Arena& ws, hipStream_t st, const DeviceMesh& mesh, const float* d_queries, size_t n_q,
@@ -599,7 +644,7 @@ int launch_query_distance(Arena& ws, hipStream_t st, const DeviceMesh& mesh, con
     return 0;
   }
   // Morton order
-  int* qb = ws.take<int>(8);
+  int* qb = ws.take<int>(8 + 6 * QB_BLOCKS);
   uint64_t* keys = ws.take<uint64_t>(n_q);
   uint64_t* keys2 = ws.take<uint64_t>(n_q);
   uint32_t* vals = ws.take<uint32_t>(n_q);
@@ -613,15 +658,41 @@ int launch_query_distance(Arena& ws, hipStream_t st, const DeviceMesh& mesh, con
     return M2S_ERR_HIP_INTERNAL;
   }
   const unsigned B = 256, nb = (nq + B - 1) / B;
-  hipLaunchKernelGGL(k_qbounds_init, dim3(1), dim3(64), 0, st, qb);
-  hipLaunchKernelGGL(k_qbounds, dim3(nb), dim3(B), 0, st, d_queries, nq, qb);
+  const unsigned qblocks = nb < QB_BLOCKS ? nb : QB_BLOCKS;
+  hipLaunchKernelGGL(k_qbounds, dim3(qblocks), dim3(B), 0, st, d_queries, nq, qb + 8);
+  hipLaunchKernelGGL(k_qbounds_final, dim3(1), dim3(B), 0, st, qb + 8, qblocks, qb);
   hipLaunchKernelGGL(k_qkeys, dim3(nb), dim3(B), 0, st, d_queries, nq, qb, keys, vals);
   M2S_HIP_CHECK(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, keys2, vals, perm, n_q, 0, 63, st));
   hipLaunchKernelGGL(k_qgather, dim3(nb), dim3(B), 0, st, d_queries, perm, nq, sorted);
-  if (mode == MODE_UNSIGNED && sign_src == SIGN_RAYS3) launch_packet<false, MODE_UNSIGNED, SIGN_RAYS3>(st, mesh, g, sorted, perm, nq, nullptr, d_out, d_err, packets);
-  else if (mode == MODE_UNSIGNED) launch_packet<false, MODE_UNSIGNED, SIGN_NONE>(st, mesh, g, sorted, perm, nq, nullptr, d_out, d_err, packets);
-  else if (mode == MODE_NORMAL_FOLD) launch_packet<false, MODE_NORMAL_FOLD, SIGN_NONE>(st, mesh, g, sorted, perm, nq, nullptr, d_out, d_err, packets);
-  else launch_packet<false, MODE_NEAREST_NORMAL, SIGN_NONE>(st, mesh, g, sorted, perm, nq, nullptr, d_out, d_err, packets);
+  // seeds: jump flooding over a QL^3 lattice on the query bounding box (as for the grid path)
+  const uint32_t* seeds = nullptr;
+  const GridParams* d_lat = nullptr;
+  static const bool use_seeds = !(getenv("M2S_SEEDS") && atoi(getenv("M2S_SEEDS")) == 0);
+  if (use_seeds && mesh.n_tris && packets >= 8) {
+    const size_t cells = (size_t)QL * QL * QL;
+    GridParams* lat = ws.take<GridParams>(1);
+    unsigned long long* k64 = ws.take<unsigned long long>(cells);
+    uint32_t* s1 = ws.take<uint32_t>(cells);
+    uint32_t* s2 = ws.take<uint32_t>(cells);
+    if (!lat || !k64 || !s1 || !s2) { set_error("internal: query workspace too small"); return M2S_ERR_HIP_INTERNAL; }
+    hipLaunchKernelGGL(k_qlattice, dim3(1), dim3(64), 0, st, qb, lat);
+    M2S_HIP_CHECK(hipMemsetAsync(k64, 0xff, cells * 8, st));
+    hipLaunchKernelGGL(k_jfa_splat, dim3((mesh.n_tris + 255) / 256), dim3(256), 0, st, mesh, g, lat, k64);
+    const unsigned nbl = (unsigned)((cells + 255) / 256);
+    hipLaunchKernelGGL(k_jfa_unpack, dim3(nbl), dim3(256), 0, st, k64, cells, s1);
+    uint32_t *src = s1, *dst = s2;
+    for (int step = QL / 2; step >= 1; step /= 2) {
+      hipLaunchKernelGGL(k_jfa_pass, dim3(nbl), dim3(256), 0, st, mesh, g, lat, src, dst, step);
+      uint32_t* t = src; src = dst; dst = t;
+    }
+    hipLaunchKernelGGL(k_jfa_pass, dim3(nbl), dim3(256), 0, st, mesh, g, lat, src, dst, 1);
+    seeds = dst;
+    d_lat = lat;
+  }
+  if (mode == MODE_UNSIGNED && sign_src == SIGN_RAYS3) launch_packet<false, MODE_UNSIGNED, SIGN_RAYS3>(st, mesh, g, sorted, perm, nq, nullptr, d_out, d_err, packets, seeds, 0, 0, 0, d_lat);
+  else if (mode == MODE_UNSIGNED) launch_packet<false, MODE_UNSIGNED, SIGN_NONE>(st, mesh, g, sorted, perm, nq, nullptr, d_out, d_err, packets, seeds, 0, 0, 0, d_lat);
+  else if (mode == MODE_NORMAL_FOLD) launch_packet<false, MODE_NORMAL_FOLD, SIGN_NONE>(st, mesh, g, sorted, perm, nq, nullptr, d_out, d_err, packets, seeds, 0, 0, 0, d_lat);
+  else launch_packet<false, MODE_NEAREST_NORMAL, SIGN_NONE>(st, mesh, g, sorted, perm, nq, nullptr, d_out, d_err, packets, seeds, 0, 0, 0, d_lat);
   M2S_HIP_CHECK(hipGetLastError());
   return 0;
 }

@@ -478,3 +478,25 @@ def test_two_ranks_share_one_gpu_gloo():
     want = oracle_grid(v, idx, g, SignMethod.Raycast)
     for r in range(2):
         assert_bit_equal(res[r], want, f"rank {r}")
+
+
+def test_generic_10M_queries_subsample():
+    """BASELINE config 3 at full size: 10 M splitmix queries x blob-100k, RtreeBvh, resident on the GPU.
+    The oracle checks a strided subsample bit for bit; the rest is covered by a permutation property:
+    the same queries in reversed order must give the reversed result (the kernels Morton-sort internally)."""
+    import torch
+
+    v, idx = meshes.named("blob-100k")
+    lo, hi = meshes.extended_bbox(v, 0.1)
+    nq = 10_000_000
+    q = meshes.uniform_queries(lo, hi, nq)
+    dv, di = torch.as_tensor(v, device="cuda"), torch.as_tensor(idx.astype(np.int64), device="cuda")
+    dq = torch.as_tensor(q, device="cuda")
+    t = M2STimings()
+    got = generate_sdf(dv, Topology.TriangleList(di), dq, AccelerationMethod.RtreeBvh, timings=t)
+    print(f"\n[10M queries RtreeBvh] build {t.accel_build_ms:.2f} ms, distance {t.distance_ms:.2f} ms -> {nq / t.total_ms / 1e3:.0f} Mqueries/s")
+    sub = slice(0, nq, 251)
+    want = orc.generate_sdf(v, idx, q[sub], accel=3, fast=True)
+    assert_bit_equal(got[sub].cpu().numpy(), want, "10M RtreeBvh subsample")
+    rev = generate_sdf(dv, Topology.TriangleList(di), torch.flip(dq, dims=[0]), AccelerationMethod.RtreeBvh)
+    assert torch.equal(torch.flip(rev, dims=[0]), got)

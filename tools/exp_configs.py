@@ -1,6 +1,6 @@
 """Timing / sanity of the other BASELINE.json configs on one GPU."""
 import sys, time
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import numpy as np, torch
 from mesh_to_sdf_amd import *
 from mesh_to_sdf_amd import meshes

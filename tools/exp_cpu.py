@@ -1,5 +1,5 @@
 import sys, time
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import numpy as np, oracle as orc
 from mesh_to_sdf_amd import meshes
 v, idx = meshes.named('blob-100k'); lo, hi = meshes.extended_bbox(v, 0.1)

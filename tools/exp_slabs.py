@@ -1,6 +1,6 @@
 """Per-piece timings as an 8-GPU, 4-chunk run would issue them (rank r of 8), on one GPU."""
 import sys, time
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import numpy as np, torch
 from mesh_to_sdf_amd import *
 from mesh_to_sdf_amd import meshes
