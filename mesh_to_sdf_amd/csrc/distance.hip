@@ -33,17 +33,33 @@ constexpr int TILE = 128;  // triangles per LDS tile in k_brute (12 KiB)
 // ---- point sources -------------------------------------------------------------------------
 struct GridBrick {
   uint32_t x, y, z;
+  uint32_t bx, by, bz;
   bool in_range;
+  bool brick_in_grid;
 };
 
-__device__ __forceinline__ GridBrick grid_lane_voxel(const GridParams& g, uint32_t brick, int lane) {
+// Brick sequence number -> brick coordinates.  Bricks are walked in 8x8x8 super-bricks (z fastest inside
+// and between them), so that consecutive packets of an XCD keep touching the same part of the BVH while
+// its 4 MiB L2 still holds it; a plain z-y-x sweep returns to a node only after a whole z column.
+__device__ __forceinline__ void brick_coords(const GridParams& g, uint32_t brick, uint32_t* bx, uint32_t* by, uint32_t* bz) {
   const uint32_t nby = (g.n[1] + 3) >> 2, nbz = (g.n[2] + 3) >> 2;
-  const uint32_t bz = brick % nbz, by = (brick / nbz) % nby, bx = brick / (nbz * nby);
+  const uint32_t sy = (nby + 7) >> 3, sz = (nbz + 7) >> 3;
+  const uint32_t sb = brick >> 9, in = brick & 511u;          // super-brick index, position inside (padded grid)
+  const uint32_t sbz = sb % sz, sby = (sb / sz) % sy, sbx = sb / (sz * sy);
+  *bx = sbx * 8 + (in >> 6);
+  *by = sby * 8 + ((in >> 3) & 7u);
+  *bz = sbz * 8 + (in & 7u);
+}
+__device__ __forceinline__ GridBrick grid_lane_voxel(const GridParams& g, uint32_t brick, int lane) {
+  uint32_t bx, by, bz;
+  brick_coords(g, brick, &bx, &by, &bz);
   GridBrick v;
   v.x = g.xb + bx * 4 + (lane >> 4);
   v.y = by * 4 + ((lane >> 2) & 3);
   v.z = bz * 4 + (lane & 3);
   v.in_range = v.x < g.xe && v.y < g.n[1] && v.z < g.n[2];
+  v.brick_in_grid = (g.xb + bx * 4 < g.xe) && (by * 4 < g.n[1]) && (bz * 4 < g.n[2]);
+  v.bx = bx; v.by = by; v.bz = bz;
   v.x = min(v.x, g.xe - 1);
   v.y = min(v.y, g.n[1] - 1);
   v.z = min(v.z, g.n[2] - 1);
@@ -179,6 +195,7 @@ __global__ __launch_bounds__(256) void k_packet(DeviceMesh mesh, GridParams g, c
   GridBrick vox{};
   if (GRID) {
     vox = grid_lane_voxel(g, packet, lane);
+    if (!vox.brick_in_grid) return;      // padding of the super-brick order
     p = grid_point(g, vox);
     out_index = ((size_t)vox.x * g.n[1] + vox.y) * g.n[2] + vox.z - (size_t)g.out_off;
     store = vox.in_range;
@@ -200,9 +217,7 @@ __global__ __launch_bounds__(256) void k_packet(DeviceMesh mesh, GridParams g, c
       // seed: a triangle near this packet's centre, from the seed pass
       uint32_t sidx = packet;
       if (GRID) {  // 2^seed_shift bricks per axis share one seed point
-        const uint32_t nby = (g.n[1] + 3) >> 2, nbz = (g.n[2] + 3) >> 2;
-        const uint32_t bz = packet % nbz, by = (packet / nbz) % nby, bx = packet / (nbz * nby);
-        sidx = ((bx >> seed_shift) * seed_ny + (by >> seed_shift)) * seed_nz + (bz >> seed_shift);
+        sidx = ((vox.bx >> seed_shift) * seed_ny + (vox.by >> seed_shift)) * seed_nz + (vox.bz >> seed_shift);
       } else {     // generic queries: the lattice cell that holds the packet's first point
         const GridParams L = *seed_lattice;
         const float q0[3] = {__shfl(p.x, 0), __shfl(p.y, 0), __shfl(p.z, 0)};
@@ -538,8 +553,9 @@ void launch_brute(hipStream_t st, const DeviceMesh& mesh, const GridParams& g, c
                      out, err, n_packets);
 }
 
-uint32_t host_brick_count(const GridParams& g) {
-  return ((g.xe - g.xb + 3) >> 2) * ((g.n[1] + 3) >> 2) * ((g.n[2] + 3) >> 2);
+uint32_t host_brick_count(const GridParams& g) {   // padded to whole 8x8x8 super-bricks
+  const uint32_t nbx = (g.xe - g.xb + 3) >> 2, nby = (g.n[1] + 3) >> 2, nbz = (g.n[2] + 3) >> 2;
+  return ((nbx + 7) >> 3) * ((nby + 7) >> 3) * ((nbz + 7) >> 3) * 512u;
 }
 
 }  // namespace
