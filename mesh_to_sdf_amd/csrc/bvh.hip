@@ -267,7 +267,8 @@ __global__ __launch_bounds__(256) void k_emit(int n, const int2* __restrict__ ra
                                               const Box* __restrict__ seg, SegLevels lv,
                                               const uint32_t* __restrict__ order, const TriRec* __restrict__ raw,
                                               NodeRec* __restrict__ nodes, TriRec* __restrict__ tris,
-                                              uint32_t* __restrict__ slot_first, float4* __restrict__ cen) {
+                                              uint32_t* __restrict__ slot_first, float4* __restrict__ cen,
+                                              TriPlanes* __restrict__ planes) {
   const int id = blockIdx.x * blockDim.x + threadIdx.x;
   if (id >= 2 * n - 1) return;
   const bool leaf = id >= n - 1;
@@ -297,6 +298,40 @@ __global__ __launch_bounds__(256) void k_emit(int n, const int2* __restrict__ ra
     tris[first] = r;
     cen[first] = make_float4((r.ax + r.bx + r.cx) * (1.0f / 3.0f), (r.ay + r.by + r.cy) * (1.0f / 3.0f),
                              (r.az + r.bz + r.cz) * (1.0f / 3.0f), 0.0f);
+    // leaf pre-test planes (common.h TriPlanes); all zero (= always evaluate) unless everything is well defined
+    TriPlanes pl = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const f3 a = mk3(r.ax, r.ay, r.az), bq = mk3(r.bx, r.by, r.bz), cq = mk3(r.cx, r.cy, r.cz);
+    const f3 n = cross3(mk3(r.abx, r.aby, r.abz), mk3(r.acx, r.acy, r.acz));
+    const float nl = sqrtf(n.x * n.x + n.y * n.y + n.z * n.z);
+    if (r.cls == TRI_REGULAR && nl > 1.0e-30f && nl < 3.0e38f) {
+      const f3 nu = {n.x / nl, n.y / nl, n.z / nl};
+      const f3 v[3] = {a, bq, cq};
+      const f3 e[3] = {mk3(r.abx, r.aby, r.abz), mk3(r.bcx, r.bcy, r.bcz), mk3(a.x - cq.x, a.y - cq.y, a.z - cq.z)};  // ab, bc, ca
+      float m[3][4];
+      bool ok = true;
+      const float vmax = fmaxf(fmaxf(fabsf(a.x), fmaxf(fabsf(a.y), fabsf(a.z))),
+                               fmaxf(fmaxf(fabsf(bq.x), fmaxf(fabsf(bq.y), fabsf(bq.z))), fmaxf(fabsf(cq.x), fmaxf(fabsf(cq.y), fabsf(cq.z)))));
+      for (int k = 0; k < 3; ++k) {
+        f3 mk = cross3(e[k], nu);                                   // in the plane, perpendicular to edge k
+        const float ml = sqrtf(mk.x * mk.x + mk.y * mk.y + mk.z * mk.z);
+        if (!(ml > 1.0e-30f) || !(ml < 3.0e38f)) { ok = false; break; }
+        mk = {mk.x / ml, mk.y / ml, mk.z / ml};
+        const f3 opp = v[(k + 2) % 3];                               // the vertex not on edge k must be inside
+        const f3 w0 = v[k], w1 = v[(k + 1) % 3];
+        float o = fmaxf(mk.x * w0.x + mk.y * w0.y + mk.z * w0.z, mk.x * w1.x + mk.y * w1.y + mk.z * w1.z);
+        if (mk.x * opp.x + mk.y * opp.y + mk.z * opp.z > o) { mk = {-mk.x, -mk.y, -mk.z}; o = fmaxf(mk.x * w0.x + mk.y * w0.y + mk.z * w0.z, mk.x * w1.x + mk.y * w1.y + mk.z * w1.z); }
+        if (mk.x * opp.x + mk.y * opp.y + mk.z * opp.z > o) { ok = false; break; }
+        m[k][0] = mk.x; m[k][1] = mk.y; m[k][2] = mk.z;
+        m[k][3] = o + 8.0e-6f * vmax + 1.0e-30f;                     // outward: makes the bound smaller
+      }
+      if (ok) {
+        pl.nx = nu.x; pl.ny = nu.y; pl.nz = nu.z; pl.dn = nu.x * a.x + nu.y * a.y + nu.z * a.z;
+        pl.m0x = m[0][0]; pl.m0y = m[0][1]; pl.m0z = m[0][2]; pl.o0 = m[0][3];
+        pl.m1x = m[1][0]; pl.m1y = m[1][1]; pl.m1z = m[1][2]; pl.o1 = m[1][3];
+        pl.m2x = m[2][0]; pl.m2y = m[2][1]; pl.m2z = m[2][2]; pl.o2 = m[2][3];
+      }
+    }
+    planes[first] = pl;
   }
 }
 
@@ -448,7 +483,7 @@ size_t bvh_workspace_bytes(size_t n_tris) {
   (void)rocprim::radix_sort_pairs(nullptr, sort_tmp, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr,
                             (uint32_t*)nullptr, n, 0, 64, (hipStream_t)0);
   size_t b = 0;
-  b += n * sizeof(TriRec) * 2 + n * 16 + 256 + n * sizeof(Box) * 3 + n * (8 + 4) * 2 + sort_tmp;
+  b += n * sizeof(TriRec) * 2 + n * 16 + 256 + n * sizeof(TriPlanes) + 256 + n * sizeof(Box) * 3 + n * (8 + 4) * 2 + sort_tmp;
   b += n * (sizeof(int2) * 2) + 2 * n * sizeof(int) + 2 * n * sizeof(NodeRec) + 2 * n * (sizeof(NodeExt) + 4);
   return b + 64 * 256 + 4096 + 24 * ((n + 255) / 256) + 256;
 }
@@ -458,6 +493,7 @@ int build_device_mesh(Arena& ws, hipStream_t st, const float* d_verts, size_t n_
   (void)n_indices;
   out->tris = nullptr;
   out->cen = nullptr;
+  out->planes = nullptr;
   out->nodes = nullptr;
   out->ext = nullptr;
   out->stats = nullptr;
@@ -470,6 +506,7 @@ int build_device_mesh(Arena& ws, hipStream_t st, const float* d_verts, size_t n_
   TriRec* raw = ws.take<TriRec>(n_tris);
   TriRec* tris = ws.take<TriRec>(n_tris);
   float4* cen = ws.take<float4>(n_tris);
+  TriPlanes* planes = ws.take<TriPlanes>(n_tris);
   Box* boxes = ws.take<Box>(n_tris);
   Box* seg = ws.take<Box>(2 * n_tris + 64);
   uint64_t* keys = ws.take<uint64_t>(n_tris);
@@ -487,7 +524,7 @@ int build_device_mesh(Arena& ws, hipStream_t st, const float* d_verts, size_t n_
   (void)rocprim::radix_sort_pairs(nullptr, sort_tmp, keys, keys2, vals, order, n_tris, 0, 64, st);
   void* tmp = ws.take<char>(sort_tmp ? sort_tmp : 1);
   if (!raw || !tris || !boxes || !seg || !keys || !keys2 || !vals || !order || !range || !child || !parent || !nodes ||
-      !scene || !tmp || !ext || !slot_first || !cen) {
+      !scene || !tmp || !ext || !slot_first || !cen || !planes) {
     set_error("internal: BVH workspace too small");
     return M2S_ERR_HIP_INTERNAL;
   }
@@ -524,7 +561,7 @@ int build_device_mesh(Arena& ws, hipStream_t st, const float* d_verts, size_t n_
                        n2, o3, n3);
   }
   hipLaunchKernelGGL(k_emit, dim3(cdiv(2 * n_tris - 1, B)), dim3(B), 0, st, n, range, parent, seg, lv, order, raw,
-                     nodes, tris, slot_first, cen);
+                     nodes, tris, slot_first, cen, planes);
   hipLaunchKernelGGL(k_node_ext_small, dim3(cdiv(2 * n_tris - 1, B)), dim3(B), 0, st, nodes, slot_first, tris,
                      (uint32_t)(2 * n_tris - 1), ext);
   hipLaunchKernelGGL(k_node_ext, dim3(cdiv(2 * n_tris - 1, 4)), dim3(B), 0, st, nodes, slot_first, tris,
@@ -532,6 +569,7 @@ int build_device_mesh(Arena& ws, hipStream_t st, const float* d_verts, size_t n_
   M2S_HIP_CHECK(hipGetLastError());
   out->tris = tris;
   out->cen = cen;
+  out->planes = planes;
   out->nodes = nodes;
   out->ext = ext;
   out->scene = scene;

@@ -204,7 +204,7 @@ int run_grid_distance(Arena& ws, const CallCtx& c, DeviceState& st, DeviceMesh m
     M2S_HIP_CHECK(hipMemcpyAsync(h, d_stats, 64, hipMemcpyDeviceToHost, c.stream));
     M2S_HIP_CHECK(hipStreamSynchronize(c.stream));
     const double w = h[3] ? (double)h[3] : 1.0;
-    fprintf(stderr, "[m2s stats] packets %llu: per packet node tests %.1f, exact triangle tests %.1f\n", h[3], h[0] / w, h[2] / w);
+    fprintf(stderr, "[m2s stats] packets %llu: per packet node tests %.1f, leaf pre-tests %.1f, exact triangle tests %.1f\n", h[3], h[0] / w, h[1] / w, h[2] / w);
   }
   return 0;
 }

@@ -60,8 +60,23 @@ struct alignas(16) NodeExt {
 constexpr uint32_t EXT_TRIVIAL_ABOVE = 2048;
 static_assert(sizeof(NodeExt) == 48, "NodeExt must be 48 bytes");
 
+// Leaf pre-test record, 64 B, same index as TriRec: unit normal n with offset dn = n.a, and for each edge the
+// unit in-plane outward normal m_k with offset o_k (rounded outwards), so that for any point p
+//   lb^2 = (n.p - dn)^2 + max(m_0.p - o_0, m_1.p - o_1, m_2.p - o_2, 0)^2  <=  dist(p, triangle)^2
+// (equality in the face and edge regions, a slight underestimate in the vertex regions).  Much tighter than
+// the leaf's disc: a lane needs the 140-instruction exact evaluation only if this bound reaches its best.
+// Degenerate triangles carry an all-zero record (bound 0: always evaluated).
+struct alignas(64) TriPlanes {
+  float nx, ny, nz, dn;
+  float m0x, m0y, m0z, o0;
+  float m1x, m1y, m1z, o1;
+  float m2x, m2y, m2z, o2;
+};
+static_assert(sizeof(TriPlanes) == 64, "TriPlanes must be 64 bytes");
+
 struct DeviceMesh {
   const TriRec* tris;   // n_tris records, Morton order
+  const TriPlanes* planes;  // n_tris leaf pre-test records
   const float4* cen;    // n_tris triangle centroids (same order), for the jump-flooding seed pass
   const NodeRec* nodes; // n_nodes = 2*n_tris - 1 (0 if n_tris == 0)
   const NodeExt* ext;   // n_nodes oriented bounds

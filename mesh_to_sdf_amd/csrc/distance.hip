@@ -150,6 +150,16 @@ __device__ __forceinline__ float ext_dist2(f3 p, const NodeExt& e) {
   return __builtin_fmaf(s, s, lat * lat);
 }
 
+// Leaf pre-test (common.h TriPlanes): squared lower bound of the distance from p to the triangle itself.
+__device__ __forceinline__ float planes_dist2(f3 p, const TriPlanes& t) {
+  const float h = __builtin_fmaf(t.nz, p.z, __builtin_fmaf(t.ny, p.y, t.nx * p.x)) - t.dn;
+  const float e0 = __builtin_fmaf(t.m0z, p.z, __builtin_fmaf(t.m0y, p.y, t.m0x * p.x)) - t.o0;
+  const float e1 = __builtin_fmaf(t.m1z, p.z, __builtin_fmaf(t.m1y, p.y, t.m1x * p.x)) - t.o1;
+  const float e2 = __builtin_fmaf(t.m2z, p.z, __builtin_fmaf(t.m2y, p.y, t.m2x * p.x)) - t.o2;
+  const float e = fmaxf(fmaxf(e0, e1), fmaxf(e2, 0.0f));
+  return __builtin_fmaf(h, h, e * e);
+}
+
 template <int AXIS>
 __device__ __forceinline__ uint32_t stab_count(const DeviceMesh& mesh, f3 p) {
   uint32_t count = 0;
@@ -265,10 +275,14 @@ __global__ __launch_bounds__(256) void k_packet(DeviceMesh mesh, GridParams g, c
       const float ed2 = ext_dist2(p, nr);
       if (__ballot(!(ed2 > thr)) == 0ull) { node = nr.skip; continue; }   // a NaN bound keeps the node
       if (nr.tri >= 0) {
-        ++st_leaf;
+        ++st_ext;
+        const TriPlanes tp = mesh.planes[nr.tri];
         const TriRec tr = mesh.tris[nr.tri];
-        eval_triangle<MODE>(best, p, tr);
-        thr = prune_bound(best.d2, slack);
+        if (__ballot(!(planes_dist2(p, tp) > thr)) != 0ull) {   // some lane's bound reaches the triangle itself
+          ++st_leaf;
+          eval_triangle<MODE>(best, p, tr);
+          thr = prune_bound(best.d2, slack);
+        }
         node = nr.skip;
       } else {
         node = node + 1;
