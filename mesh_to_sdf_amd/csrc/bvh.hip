@@ -12,6 +12,7 @@
 //   k_karras      : Karras 2012 hierarchy over the sorted keys (ranges, children, parents)
 //   k_seg_level   : segment tree of leaf boxes, one launch per level (fence-free refit)
 //   k_emit        : node boxes by range query, pre-order index = 2*first + #left-turns, skip links
+#include <cstdlib>
 #include <cstring>
 
 #include <rocprim/rocprim.hpp>
@@ -268,7 +269,7 @@ __global__ __launch_bounds__(256) void k_emit(int n, const int2* __restrict__ ra
                                               const uint32_t* __restrict__ order, const TriRec* __restrict__ raw,
                                               NodeRec* __restrict__ nodes, TriRec* __restrict__ tris,
                                               uint32_t* __restrict__ slot_first, float4* __restrict__ cen,
-                                              TriPlanes* __restrict__ planes) {
+                                              TriPlanes* __restrict__ planes, uint32_t leaf_max) {
   const int id = blockIdx.x * blockDim.x + threadIdx.x;
   if (id >= 2 * n - 1) return;
   const bool leaf = id >= n - 1;
@@ -290,7 +291,9 @@ __global__ __launch_bounds__(256) void k_emit(int n, const int2* __restrict__ ra
   nr.mnx = b.mnx; nr.mny = b.mny; nr.mnz = b.mnz;
   nr.skip = slot + 2u * cnt - 1u;
   nr.mxx = b.mxx; nr.mxy = b.mxy; nr.mxz = b.mxz;
-  nr.tri = leaf ? first : -1;
+  // A subtree of at most `leaf_max` triangles is walked as ONE leaf: its triangles are contiguous in Morton
+  // order ([first, first+cnt), cnt = (skip - slot + 1)/2) and `skip` already jumps over its descendants.
+  nr.tri = cnt <= leaf_max ? first : -1;
   nodes[slot] = nr;
   slot_first[slot] = (uint32_t)first;
   if (leaf) {
@@ -530,6 +533,7 @@ int build_device_mesh(Arena& ws, hipStream_t st, const float* d_verts, size_t n_
   }
 
   const unsigned B = 256;
+  static const uint32_t leaf_max = getenv("M2S_LEAF_MAX") ? (uint32_t)atoi(getenv("M2S_LEAF_MAX")) : 2u;
   hipLaunchKernelGGL(k_init_scene, dim3(cdiv(2 * n_tris, B)), dim3(B), 0, st, scene, parent, 2 * n - 1);
   hipLaunchKernelGGL(k_tri_setup, dim3(cdiv(n_tris, B)), dim3(B), 0, st, d_verts, (uint32_t)n_verts, d_indices,
                      index_bytes, topology, (uint32_t)n_tris, raw, boxes, scene, d_err);
@@ -561,7 +565,7 @@ int build_device_mesh(Arena& ws, hipStream_t st, const float* d_verts, size_t n_
                        n2, o3, n3);
   }
   hipLaunchKernelGGL(k_emit, dim3(cdiv(2 * n_tris - 1, B)), dim3(B), 0, st, n, range, parent, seg, lv, order, raw,
-                     nodes, tris, slot_first, cen, planes);
+                     nodes, tris, slot_first, cen, planes, leaf_max);
   hipLaunchKernelGGL(k_node_ext_small, dim3(cdiv(2 * n_tris - 1, B)), dim3(B), 0, st, nodes, slot_first, tris,
                      (uint32_t)(2 * n_tris - 1), ext);
   hipLaunchKernelGGL(k_node_ext, dim3(cdiv(2 * n_tris - 1, 4)), dim3(B), 0, st, nodes, slot_first, tris,

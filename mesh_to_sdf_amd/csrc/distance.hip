@@ -170,11 +170,16 @@ __device__ __forceinline__ uint32_t stab_count(const DeviceMesh& mesh, f3 p) {
     const bool hit = ray_meets_box<AXIS>(p, mk3(nr.mnx, nr.mny, nr.mnz), mk3(nr.mxx, nr.mxy, nr.mxz));
     if (__ballot(hit) == 0ull) { node = nr.skip; continue; }
     if (nr.tri >= 0) {
-      const TriRec tr = mesh.tris[nr.tri];
-      float t;
-      const bool h = ray_triangle_aligned<AXIS>(p, mk3(tr.ax, tr.ay, tr.az), mk3(tr.bx, tr.by, tr.bz),
-                                                mk3(tr.cx, tr.cy, tr.cz), &t);
-      count += (hit & h) ? 1u : 0u;   // leaf box == padded triangle box: `hit` is the candidate rule
+      const uint32_t cnt = (nr.skip - node + 1u) >> 1;
+      for (uint32_t k = 0; k < cnt; ++k) {
+        const TriRec tr = mesh.tris[nr.tri + k];
+        const f3 a = mk3(tr.ax, tr.ay, tr.az), b = mk3(tr.bx, tr.by, tr.bz), c = mk3(tr.cx, tr.cy, tr.cz);
+        f3 mn, mx;
+        triangle_bounding_box(a, b, c, &mn, &mx);     // the candidate rule is per triangle: ITS padded box
+        float t;
+        const bool h = ray_meets_box<AXIS>(p, mn, mx) & ray_triangle_aligned<AXIS>(p, a, b, c, &t);
+        count += h ? 1u : 0u;
+      }
       node = nr.skip;
     } else {
       node = node + 1;
@@ -275,13 +280,16 @@ __global__ __launch_bounds__(256) void k_packet(DeviceMesh mesh, GridParams g, c
       const float ed2 = ext_dist2(p, nr);
       if (__ballot(!(ed2 > thr)) == 0ull) { node = nr.skip; continue; }   // a NaN bound keeps the node
       if (nr.tri >= 0) {
-        ++st_ext;
-        const TriPlanes tp = mesh.planes[nr.tri];
-        const TriRec tr = mesh.tris[nr.tri];
-        if (__ballot(!(planes_dist2(p, tp) > thr)) != 0ull) {   // some lane's bound reaches the triangle itself
-          ++st_leaf;
-          eval_triangle<MODE>(best, p, tr);
-          thr = prune_bound(best.d2, slack);
+        const uint32_t cnt = (nr.skip - node + 1u) >> 1;        // triangles of this (possibly collapsed) leaf
+        for (uint32_t k = 0; k < cnt; ++k) {
+          ++st_ext;
+          const TriPlanes tp = mesh.planes[nr.tri + k];
+          const TriRec tr = mesh.tris[nr.tri + k];
+          if (__ballot(!(planes_dist2(p, tp) > thr)) != 0ull) {   // some lane's bound reaches the triangle itself
+            ++st_leaf;
+            eval_triangle<MODE>(best, p, tr);
+            thr = prune_bound(best.d2, slack);
+          }
         }
         node = nr.skip;
       } else {
