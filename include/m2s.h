@@ -158,6 +158,61 @@ uint64_t m2s_grid_cell_idx(const m2s_grid* grid, const uint64_t cell[3]);
 /* Number of triangles Topology::get_triangles (lib.rs:175-193) yields for these arguments. */
 size_t m2s_triangle_count(size_t n_vertices, size_t n_indices, int has_indices, int topology);
 
+/* ---- the data formats and callers either side of the path -------------------
+ *
+ * V1 container — mesh_to_sdf/src/serde.rs:75-221.  `save_to_file` writes rmp-serde's compact MessagePack
+ * encoding of SerializeVersion::V1(SerializeSdf::{Generic,Grid}) (serde.rs:161-166): enums are one-entry
+ * maps keyed by the variant name, structs are arrays, f32 is `ca` + 4 big-endian bytes, usize is the
+ * shortest unsigned form, a point is `93 ca.. ca.. ca..`:
+ *   Grid    81 a2 "V1" 81 a4 "Grid"    92 [93 first_cell(3 f32) cell_size(3 f32) 93 cell_count(3 uint)] [array n: f32...]
+ *   Generic 81 a2 "V1" 81 a7 "Generic" 92 [array nq: point...] [array nd: f32...]
+ * Pinned byte for byte on the reference's golden files tests/sdf_grid_v1.bin and tests/sdf_generic_v1.bin
+ * (serde.rs:314-374).  The payload arrays (5 B per distance, 16 B per point) are produced / consumed by
+ * HIP kernels so a device-resident result is encoded without a round trip through host f32 arrays.
+ * `distances` / `queries` / `bytes` follow opts->mem_kind like every other data pointer. */
+enum m2s_sdf_kind { M2S_SDF_GENERIC = 0, M2S_SDF_GRID = 1 };
+
+typedef struct m2s_sdf_info {
+  int32_t kind;              /* enum m2s_sdf_kind */
+  int32_t canonical;         /* 1: both arrays use exactly the fixed-width encoding above (decoded by the HIP kernels);
+                                0: some element uses another valid MessagePack number form (f64, ints) that serde would
+                                   accept for an f32 — decoded by the scalar host reader */
+  m2s_grid grid;             /* kind == M2S_SDF_GRID */
+  uint64_t n_queries;        /* kind == M2S_SDF_GENERIC, else 0 */
+  uint64_t n_distances;
+  uint64_t queries_offset;   /* byte offset of the first element of each array (canonical == 1) */
+  uint64_t distances_offset;
+} m2s_sdf_info;
+
+/* Exact size in bytes of the container; 0 if a count does not fit MessagePack's 32-bit array header. */
+size_t m2s_sdf_grid_encoded_size(const m2s_grid* grid, size_t n_distances);
+size_t m2s_sdf_generic_encoded_size(size_t n_queries, size_t n_distances);
+
+/* serialize(&SerializeSdf::Grid(..)) — serde.rs:99-107,161-166.  n_distances is NOT required to equal the
+ * grid's cell count (the reference does not check either).  *written (optional) receives the size. */
+int m2s_sdf_encode_grid(const m2s_grid* grid, const float* distances, size_t n_distances, uint8_t* bytes,
+                        size_t capacity, size_t* written, const m2s_opts* opts);
+/* serialize(&SerializeSdf::Generic(..)) — serde.rs:87-95,161-166.  queries: n_queries packed xyz. */
+int m2s_sdf_encode_generic(const float* queries, size_t n_queries, const float* distances, size_t n_distances,
+                           uint8_t* bytes, size_t capacity, size_t* written, const m2s_opts* opts);
+
+/* First half of deserialize() — serde.rs:169-176: reads the envelope and the array headers so the caller
+ * can size its buffers.  M2S_ERR_BAD_ARG = SerdeError::DeserializationFailed. */
+int m2s_sdf_probe(const uint8_t* bytes, size_t n_bytes, m2s_sdf_info* info, const m2s_opts* opts);
+/* Second half: fills queries_out (n_queries*3 f32; may be NULL for a grid container) and distances_out
+ * (n_distances f32).  Always synchronous (a malformed element is reported by the return code). */
+int m2s_sdf_decode(const uint8_t* bytes, size_t n_bytes, float* queries_out, float* distances_out,
+                   const m2s_opts* opts);
+
+/* save_to_file / read_from_file — serde.rs:192-198, 216-220.  M2S_ERR_IO = SerdeError::IoError. */
+#define M2S_ERR_IO (-5)
+int m2s_sdf_save_grid(const char* path, const m2s_grid* grid, const float* distances, size_t n_distances,
+                      const m2s_opts* opts);
+int m2s_sdf_save_generic(const char* path, const float* queries, size_t n_queries, const float* distances,
+                         size_t n_distances, const m2s_opts* opts);
+int m2s_sdf_probe_file(const char* path, m2s_sdf_info* info);
+int m2s_sdf_read_file(const char* path, float* queries_out, float* distances_out, const m2s_opts* opts);
+
 /* Library / device introspection. */
 int m2s_version(void);               /* major*1000 + minor */
 int m2s_device_count(void);          /* HIP devices visible; 0 if none (every compute call then fails with M2S_ERR_HIP) */

@@ -7,3 +7,4 @@ this package is the thin host-side mirror of the reference's public interface
 from .api import (AccelerationMethod, Grid, M2SError, M2SPanic, Mesh, SignMethod, Topology, generate_grid_sdf,  # noqa: F401
                   generate_sdf)
 from ._lib import M2STimings  # noqa: F401
+from . import serde  # noqa: F401,E402  (mesh_to_sdf::serde, serde.rs)

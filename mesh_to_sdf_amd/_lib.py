@@ -13,7 +13,7 @@ SO_PATH = os.path.join(_HERE, "libm2s_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 M2S_OK = 0
-ERR_BAD_ARG, ERR_NAN, ERR_EMPTY_MESH, ERR_HIP = -1, -2, -3, -4
+ERR_BAD_ARG, ERR_NAN, ERR_EMPTY_MESH, ERR_HIP, ERR_IO = -1, -2, -3, -4, -5
 MEM_HOST, MEM_DEVICE = 0, 1
 
 
@@ -51,6 +51,18 @@ class M2SOpts(C.Structure):
     ]
 
 
+class M2SSdfInfo(C.Structure):
+    _fields_ = [
+        ("kind", C.c_int32),
+        ("canonical", C.c_int32),
+        ("grid", M2SGrid),
+        ("n_queries", C.c_uint64),
+        ("n_distances", C.c_uint64),
+        ("queries_offset", C.c_uint64),
+        ("distances_offset", C.c_uint64),
+    ]
+
+
 # every symbol include/m2s.h declares
 EXPORTS = [
     "m2s_generate_sdf",
@@ -69,6 +81,16 @@ EXPORTS = [
     "m2s_mesh_generate_grid_sdf",
     "m2s_mesh_generate_sdf",
     "m2s_mesh_drain_timings",
+    "m2s_sdf_grid_encoded_size",
+    "m2s_sdf_generic_encoded_size",
+    "m2s_sdf_encode_grid",
+    "m2s_sdf_encode_generic",
+    "m2s_sdf_probe",
+    "m2s_sdf_decode",
+    "m2s_sdf_save_grid",
+    "m2s_sdf_save_generic",
+    "m2s_sdf_probe_file",
+    "m2s_sdf_read_file",
 ]
 
 
@@ -132,6 +154,28 @@ def lib():
                                             C.POINTER(C.c_size_t), C.POINTER(M2SOpts)]
         L.m2s_mesh_drain_timings.restype = C.c_int
         L.m2s_mesh_drain_timings.argtypes = [C.c_void_p, C.POINTER(M2STimings)]
+        L.m2s_sdf_grid_encoded_size.restype = C.c_size_t
+        L.m2s_sdf_grid_encoded_size.argtypes = [C.POINTER(M2SGrid), C.c_size_t]
+        L.m2s_sdf_generic_encoded_size.restype = C.c_size_t
+        L.m2s_sdf_generic_encoded_size.argtypes = [C.c_size_t, C.c_size_t]
+        L.m2s_sdf_encode_grid.restype = C.c_int
+        L.m2s_sdf_encode_grid.argtypes = [C.POINTER(M2SGrid), C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                          C.POINTER(C.c_size_t), C.POINTER(M2SOpts)]
+        L.m2s_sdf_encode_generic.restype = C.c_int
+        L.m2s_sdf_encode_generic.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                             C.POINTER(C.c_size_t), C.POINTER(M2SOpts)]
+        L.m2s_sdf_probe.restype = C.c_int
+        L.m2s_sdf_probe.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(M2SSdfInfo), C.POINTER(M2SOpts)]
+        L.m2s_sdf_decode.restype = C.c_int
+        L.m2s_sdf_decode.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.POINTER(M2SOpts)]
+        L.m2s_sdf_save_grid.restype = C.c_int
+        L.m2s_sdf_save_grid.argtypes = [C.c_char_p, C.POINTER(M2SGrid), C.c_void_p, C.c_size_t, C.POINTER(M2SOpts)]
+        L.m2s_sdf_save_generic.restype = C.c_int
+        L.m2s_sdf_save_generic.argtypes = [C.c_char_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(M2SOpts)]
+        L.m2s_sdf_probe_file.restype = C.c_int
+        L.m2s_sdf_probe_file.argtypes = [C.c_char_p, C.POINTER(M2SSdfInfo)]
+        L.m2s_sdf_read_file.restype = C.c_int
+        L.m2s_sdf_read_file.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.POINTER(M2SOpts)]
         _lib = L
     return _lib
 

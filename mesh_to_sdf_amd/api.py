@@ -95,6 +95,12 @@ class Grid:
         _lib.lib().m2s_grid_from_bounding_box(mn, mx, cnt, C.byref(g._g))
         return g
 
+    def __eq__(self, other):  # #[derive(PartialEq)], grid.rs:27
+        return isinstance(other, Grid) and bytes(self._g) == bytes(other._g)
+
+    def __repr__(self):
+        return f"Grid(first_cell={list(self._g.first_cell)}, cell_size={list(self._g.cell_size)}, cell_count={list(self._g.cell_count)})"
+
     def get_first_cell(self):
         return np.array(list(self._g.first_cell), np.float32)
 

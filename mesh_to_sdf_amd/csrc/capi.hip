@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "../../include/m2s.h"
+#include "capi_internal.h"
 #include "common.h"
 
 namespace m2s {
@@ -22,17 +23,7 @@ void set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
-namespace {
-
-struct DeviceState {
-  char* base = nullptr;
-  size_t cap = 0;
-  hipStream_t stream = nullptr;
-  hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-  int* h_err = nullptr;  // pinned
-  char* spare_mesh = nullptr;  // last destroyed m2s_mesh block, recycled by the next m2s_mesh_create
-  size_t spare_mesh_bytes = 0;
-};
+void clear_error() { g_err[0] = 0; }
 
 std::mutex g_mu;
 std::map<int, DeviceState> g_dev;
@@ -70,16 +61,6 @@ int ensure_capacity(DeviceState& s, size_t bytes) {
   return 0;
 }
 
-struct CallCtx {
-  int device = -1;
-  int mem_kind = M2S_MEM_HOST;
-  int algorithm = 0;
-  bool sync = true;
-  hipStream_t stream = nullptr;
-  m2s_timings* timings = nullptr;
-  uint64_t x_begin = 0, x_end = 0;
-};
-
 int resolve_ctx(const m2s_opts* opts, CallCtx* c, DeviceState** st) {
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -107,6 +88,8 @@ int resolve_ctx(const m2s_opts* opts, CallCtx* c, DeviceState** st) {
   return 0;
 }
 
+namespace {
+
 int check_mesh_args(const float* vertices, size_t n_vertices, const void* indices, size_t n_indices, int index_bytes,
                     int topology) {
   if (topology != M2S_TRIANGLE_LIST && topology != M2S_TRIANGLE_STRIP) return fail(M2S_ERR_BAD_ARG, "bad topology %d", topology);
@@ -116,8 +99,6 @@ int check_mesh_args(const float* vertices, size_t n_vertices, const void* indice
   if (n_vertices >= 0x7fffffffull || n_indices >= 0x17fffffffull) return fail(M2S_ERR_BAD_ARG, "mesh too large for 32-bit indexing");
   return 0;
 }
-
-size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
 
 struct StagedMesh {
   const float* d_verts = nullptr;

@@ -1,0 +1,38 @@
+// capi_internal.h — per-device state and call context shared by the C-ABI translation units
+// (capi.hip: distance path; capi_io.hip: container encode/decode, cell ordering, instance merge).
+#pragma once
+#include <mutex>
+
+#include "../../include/m2s.h"
+#include "common.h"
+
+namespace m2s {
+
+struct DeviceState {
+  char* base = nullptr;
+  size_t cap = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  int* h_err = nullptr;  // pinned
+  char* spare_mesh = nullptr;  // last destroyed m2s_mesh block, recycled by the next m2s_mesh_create
+  size_t spare_mesh_bytes = 0;
+};
+
+struct CallCtx {
+  int device = -1;
+  int mem_kind = M2S_MEM_HOST;
+  int algorithm = 0;
+  bool sync = true;
+  hipStream_t stream = nullptr;
+  m2s_timings* timings = nullptr;
+  uint64_t x_begin = 0, x_end = 0;
+};
+
+extern std::mutex g_mu;                  // serialises the entry points (one workspace per device)
+void clear_error();
+int fail(int code, const char* fmt, ...);
+int resolve_ctx(const m2s_opts* opts, CallCtx* c, DeviceState** st);
+int ensure_capacity(DeviceState& s, size_t bytes);
+inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
+
+}  // namespace m2s

@@ -172,4 +172,13 @@ size_t query_workspace_bytes(size_t n_q);
 int launch_query_distance(Arena& ws, hipStream_t st, const DeviceMesh& mesh, const float* d_queries, size_t n_q,
                           int mode, int sign_src, int algorithm, float* d_out, int* d_err);
 
+
+// serde.hip: payload arrays of the V1 container (fixed-width MessagePack records), any byte alignment.
+struct wire_bytes { uint8_t b[120]; uint32_t n; };   // envelope bytes passed by value to a 1-block kernel
+int launch_write_bytes(hipStream_t st, uint8_t* d_dst, const uint8_t* bytes, uint32_t n);
+int launch_encode_f32(hipStream_t st, const float* d_values, uint64_t n, uint8_t* d_dst);      // 5 B per value
+int launch_encode_points(hipStream_t st, const float* d_points, uint64_t n, uint8_t* d_dst);   // 16 B per point
+int launch_decode_f32(hipStream_t st, const uint8_t* d_src, uint64_t n, float* d_out, int* d_err);
+int launch_decode_points(hipStream_t st, const uint8_t* d_src, uint64_t n, float* d_out, int* d_err);
+
 }  // namespace m2s

@@ -1,0 +1,213 @@
+// serde.hip — payload arrays of the V1 container (mesh_to_sdf/src/serde.rs:87-107) on the GPU.
+//
+// rmp-serde writes every f32 as `ca` + 4 big-endian bytes (5 B) and every point as `93` + three such
+// floats (16 B).  Both are fixed-width, so element q of an array lives at a computable byte offset and
+// the arrays encode / decode fully in parallel.  This is pure byte traffic — 4 B in + 5 B out per distance —
+// and HBM-bound:
+//   encode: one thread produces one 16-byte-ALIGNED chunk of the output (a single dwordx4 store, fully
+//           coalesced) from the ≤4 floats / ≤2 points whose records overlap it; the unaligned start and
+//           end of the payload are the only byte stores.
+//   decode: one thread per element, two (five) aligned dword loads + a 64-bit shift, tag bytes checked.
+#include <cstring>
+
+#include "common.h"
+
+namespace m2s {
+namespace {
+
+__device__ __forceinline__ uint32_t be32(float f) { return __builtin_bswap32(__float_as_uint(f)); }
+
+// Byte k (0..4) of the 5-byte record of value v.
+__device__ __forceinline__ uint8_t f32_record_byte(float v, uint32_t k) {
+  return k == 0 ? (uint8_t)0xca : (uint8_t)(__float_as_uint(v) >> (8 * (4 - k)));
+}
+
+// Byte k (0..15) of the 16-byte record of point (x, y, z).
+__device__ __forceinline__ uint8_t point_record_byte(const float* q, uint32_t k) {
+  if (k == 0) return 0x93;
+  const uint32_t c = (k - 1) / 5, r = (k - 1) % 5;
+  return f32_record_byte(q[c], r);
+}
+
+// distances[n] -> 5n bytes at `dst` (any alignment).
+__global__ __launch_bounds__(256) void k_encode_f32(const float* __restrict__ v, uint64_t n, uint8_t* __restrict__ dst,
+                                                    uint64_t n_chunks) {
+  const uint64_t c = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (c >= n_chunks) return;
+  const uintptr_t S = (uintptr_t)dst;
+  const uintptr_t base = (S & ~(uintptr_t)15) + 16 * c;   // absolute address of this thread's chunk
+  const int64_t o0 = (int64_t)(base - S);                 // payload offset of its first byte (may be < 0)
+  const int64_t total = (int64_t)(5 * n);
+  if (o0 >= 0 && o0 + 16 <= total) {
+    const uint64_t q0 = (uint64_t)o0 / 5;
+    const uint32_t r = (uint32_t)((uint64_t)o0 - 5 * q0);
+    // bytes r..r+15 of the 20-byte stream of records q0..q0+3 (the last byte always falls into q0+3)
+    const uint32_t x0 = be32(v[q0]), x1 = be32(v[q0 + 1]), x2 = be32(v[q0 + 2]), x3 = be32(v[q0 + 3]);
+    const uint32_t w0 = 0xcau | (x0 << 8);
+    const uint32_t w1 = (x0 >> 24) | (0xcau << 8) | (x1 << 16);
+    const uint32_t w2 = (x1 >> 16) | (0xcau << 16) | (x2 << 24);
+    const uint32_t w3 = (x2 >> 8) | (0xcau << 24);
+    const uint32_t w4 = x3;
+    uint4 o;
+    if (r == 0) {
+      o = make_uint4(w0, w1, w2, w3);
+    } else {
+      o.x = __builtin_amdgcn_alignbyte(w1, w0, r & 3);
+      o.y = __builtin_amdgcn_alignbyte(w2, w1, r & 3);
+      o.z = __builtin_amdgcn_alignbyte(w3, w2, r & 3);
+      o.w = __builtin_amdgcn_alignbyte(w4, w3, r & 3);
+      if (r == 4) o = make_uint4(w1, w2, w3, w4);
+    }
+    *reinterpret_cast<uint4*>(base) = o;
+    return;
+  }
+  for (int j = 0; j < 16; ++j) {   // first / last chunk of the payload
+    const int64_t o = o0 + j;
+    if (o < 0 || o >= total) continue;
+    const uint64_t q = (uint64_t)o / 5;
+    reinterpret_cast<uint8_t*>(base)[j] = f32_record_byte(v[q], (uint32_t)((uint64_t)o - 5 * q));
+  }
+}
+
+// points[n][3] -> 16n bytes at `dst` (any alignment).
+__global__ __launch_bounds__(256) void k_encode_points(const float* __restrict__ pts, uint64_t n, uint8_t* __restrict__ dst,
+                                                       uint64_t n_chunks) {
+  const uint64_t c = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (c >= n_chunks) return;
+  const uintptr_t S = (uintptr_t)dst;
+  const uintptr_t base = (S & ~(uintptr_t)15) + 16 * c;
+  const int64_t o0 = (int64_t)(base - S);
+  const int64_t total = (int64_t)(16 * n);
+  if (o0 >= 0 && o0 + 16 <= total) {
+    const uint64_t q = (uint64_t)o0 >> 4;
+    const uint32_t sh = (uint32_t)o0 & 15u;
+    uint32_t d[8];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const bool have = k == 0 || sh != 0;     // sh != 0 => the chunk ends inside record q+1 (< n)
+      const uint64_t qq = have ? q + k : q;
+      const uint32_t X = be32(pts[3 * qq]), Y = be32(pts[3 * qq + 1]), Z = be32(pts[3 * qq + 2]);
+      d[4 * k + 0] = 0x93u | (0xcau << 8) | (X << 16);
+      d[4 * k + 1] = (X >> 16) | (0xcau << 16) | (Y << 24);
+      d[4 * k + 2] = (Y >> 8) | (0xcau << 24);
+      d[4 * k + 3] = Z;
+    }
+    const uint32_t w = sh >> 2, r = sh & 3;
+    uint32_t e[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {   // e[i] = d[w + i] without dynamic register indexing
+      const uint32_t a = w == 0 ? d[i] : w == 1 ? d[i + 1] : w == 2 ? d[i + 2] : d[(i + 3) & 7];
+      e[i] = a;
+    }
+    if (w == 0 && r == 0) e[4] = 0;  // unused
+    uint4 o;
+    o.x = r ? __builtin_amdgcn_alignbyte(e[1], e[0], r) : e[0];
+    o.y = r ? __builtin_amdgcn_alignbyte(e[2], e[1], r) : e[1];
+    o.z = r ? __builtin_amdgcn_alignbyte(e[3], e[2], r) : e[2];
+    o.w = r ? __builtin_amdgcn_alignbyte(e[4], e[3], r) : e[3];
+    *reinterpret_cast<uint4*>(base) = o;
+    return;
+  }
+  for (int j = 0; j < 16; ++j) {
+    const int64_t o = o0 + j;
+    if (o < 0 || o >= total) continue;
+    const uint64_t q = (uint64_t)o >> 4;
+    reinterpret_cast<uint8_t*>(base)[j] = point_record_byte(pts + 3 * q, (uint32_t)o & 15u);
+  }
+}
+
+__global__ void k_write_bytes(uint8_t* __restrict__ dst, wire_bytes hdr) {
+  if (threadIdx.x < hdr.n) dst[threadIdx.x] = hdr.b[threadIdx.x];
+}
+
+// 5n bytes at `src` (any alignment) -> out[n]; *err |= 1 when a tag byte is not `ca`.
+__global__ __launch_bounds__(256) void k_decode_f32(const uint8_t* __restrict__ src, uint64_t n, float* __restrict__ out,
+                                                    int* __restrict__ err) {
+  const uint64_t q = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (q >= n) return;
+  const uintptr_t a = (uintptr_t)src + 5 * q;
+  const uint32_t* w = reinterpret_cast<const uint32_t*>(a & ~(uintptr_t)3);
+  const uint32_t r = (uint32_t)(a & 3);
+  const uint64_t lo = (uint64_t)w[0] | ((uint64_t)w[1] << 32);   // bytes r..r+4 lie inside these two dwords
+  const uint32_t tag = (uint32_t)(lo >> (8 * r)) & 0xffu;
+  const uint32_t val = (uint32_t)(lo >> (8 * r + 8));
+  if (tag != 0xcau) atomicOr(err, 1);
+  out[q] = __uint_as_float(__builtin_bswap32(val));
+}
+
+// 16n bytes at `src` -> out[n][3]; *err |= 2 when a record is not `93 ca.. ca.. ca..`.
+__global__ __launch_bounds__(256) void k_decode_points(const uint8_t* __restrict__ src, uint64_t n, float* __restrict__ out,
+                                                       int* __restrict__ err) {
+  const uint64_t q = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (q >= n) return;
+  const uintptr_t a = (uintptr_t)src + 16 * q;
+  const uint32_t* w = reinterpret_cast<const uint32_t*>(a & ~(uintptr_t)3);
+  const uint32_t r = (uint32_t)(a & 3);
+  uint32_t d[4];
+  if (r == 0) {
+    d[0] = w[0]; d[1] = w[1]; d[2] = w[2]; d[3] = w[3];
+  } else {
+    uint32_t x[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) x[i] = w[i];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) d[i] = __builtin_amdgcn_alignbyte(x[i + 1], x[i], r);
+  }
+  const bool good = (d[0] & 0xffffu) == 0xca93u && ((d[1] >> 16) & 0xffu) == 0xcau && (d[2] >> 24) == 0xcau;
+  if (!good) atomicOr(err, 2);
+  const uint32_t X = (d[0] >> 16) | (d[1] << 16), Y = (d[1] >> 24) | (d[2] << 8), Z = d[3];
+  out[3 * q] = __uint_as_float(__builtin_bswap32(X));
+  out[3 * q + 1] = __uint_as_float(__builtin_bswap32(Y));
+  out[3 * q + 2] = __uint_as_float(__builtin_bswap32(Z));
+}
+
+uint64_t chunk_count(const uint8_t* dst, uint64_t bytes) {
+  if (bytes == 0) return 0;
+  const uintptr_t S = (uintptr_t)dst, A = S & ~(uintptr_t)15;
+  return (S + bytes - A + 15) / 16;
+}
+
+}  // namespace
+
+int launch_write_bytes(hipStream_t st, uint8_t* d_dst, const uint8_t* bytes, uint32_t n) {
+  if (n == 0) return 0;
+  if (n > sizeof(wire_bytes::b)) { set_error("internal: envelope too long"); return M2S_ERR_HIP_INTERNAL; }
+  wire_bytes h;
+  memcpy(h.b, bytes, n);
+  h.n = n;
+  hipLaunchKernelGGL(k_write_bytes, dim3(1), dim3(128), 0, st, d_dst, h);
+  M2S_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+int launch_encode_f32(hipStream_t st, const float* d_values, uint64_t n, uint8_t* d_dst) {
+  const uint64_t chunks = chunk_count(d_dst, 5 * n);
+  if (chunks == 0) return 0;
+  hipLaunchKernelGGL(k_encode_f32, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, st, d_values, n, d_dst, chunks);
+  M2S_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+int launch_encode_points(hipStream_t st, const float* d_points, uint64_t n, uint8_t* d_dst) {
+  const uint64_t chunks = chunk_count(d_dst, 16 * n);
+  if (chunks == 0) return 0;
+  hipLaunchKernelGGL(k_encode_points, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, st, d_points, n, d_dst, chunks);
+  M2S_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+int launch_decode_f32(hipStream_t st, const uint8_t* d_src, uint64_t n, float* d_out, int* d_err) {
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(k_decode_f32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_src, n, d_out, d_err);
+  M2S_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+int launch_decode_points(hipStream_t st, const uint8_t* d_src, uint64_t n, float* d_out, int* d_err) {
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(k_decode_points, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_src, n, d_out, d_err);
+  M2S_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+}  // namespace m2s
