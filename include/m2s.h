@@ -213,6 +213,35 @@ int m2s_sdf_save_generic(const char* path, const float* queries, size_t n_querie
 int m2s_sdf_probe_file(const char* path, m2s_sdf_info* info);
 int m2s_sdf_read_file(const char* path, float* queries_out, float* distances_out, const m2s_opts* opts);
 
+/* Client post-step on a generated grid — mesh_to_sdf_client/src/sdf.rs:62-72 and :120:
+ *   ordered_indices = (0..n).sorted_by(|i, j| data[i].total_cmp(&data[j])).map(|i| i as u32)   (stable sort)
+ *   iso_limits      = data.iter().copied().minmax()                                            (itertools)
+ * ordered_indices: n u32, same side as `distances` (opts->mem_kind).  iso_limits: 2 floats on the HOST, optional;
+ * first of equal minima / last of equal maxima as itertools; NaNs (never produced by the generators) are skipped,
+ * (NaN, NaN) if nothing is comparable.  n must be < 2^32 (the reference's u32 cast).  Always synchronous when
+ * iso_limits is requested. */
+int m2s_order_cells_by_distance(const float* distances, size_t n, uint32_t* ordered_indices, float* iso_limits,
+                                const m2s_opts* opts);
+
+/* Client pre-step — mesh_to_sdf_client/src/sdf_program.rs:607-632: a glTF scene holds several model instances;
+ * the client merges them into the single vertex / index buffer the generator takes:
+ *   vertices.extend(model.vertices.map(|v| transform.transform_point3(v.position)))   glam Mat4 (no FMA)
+ *   indices.extend(model.indices.map(|i| i + len as u32))                             len = vertices so far
+ * and takes the per-axis minmax of the merged vertices as the mesh bounding box.
+ * `vertices`/`indices` of every instance and the outputs follow opts->mem_kind; the instance table itself and
+ * `bbox` ({xmin,ymin,zmin,xmax,ymax,zmax}, optional) are host memory.  Outputs hold sum(n_vertices) xyz and
+ * sum(n_indices) u32. */
+typedef struct m2s_instance {
+  const void* vertices;        /* first position (3 consecutive f32) */
+  size_t n_vertices;
+  size_t vertex_stride;        /* bytes between positions; 0 = 12 (packed).  The client's Vertex carries more attributes */
+  const uint32_t* indices;
+  size_t n_indices;
+  float transform[16];         /* glam::Mat4, column-major: x_axis, y_axis, z_axis, w_axis */
+} m2s_instance;
+int m2s_merge_instances(const m2s_instance* instances, size_t n_instances, float* vertices_out, uint32_t* indices_out,
+                        float* bbox, const m2s_opts* opts);
+
 /* Library / device introspection. */
 int m2s_version(void);               /* major*1000 + minor */
 int m2s_device_count(void);          /* HIP devices visible; 0 if none (every compute call then fails with M2S_ERR_HIP) */

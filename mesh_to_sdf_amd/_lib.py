@@ -63,6 +63,17 @@ class M2SSdfInfo(C.Structure):
     ]
 
 
+class M2SInstance(C.Structure):
+    _fields_ = [
+        ("vertices", C.c_void_p),
+        ("n_vertices", C.c_size_t),
+        ("vertex_stride", C.c_size_t),
+        ("indices", C.c_void_p),
+        ("n_indices", C.c_size_t),
+        ("transform", C.c_float * 16),
+    ]
+
+
 # every symbol include/m2s.h declares
 EXPORTS = [
     "m2s_generate_sdf",
@@ -91,6 +102,8 @@ EXPORTS = [
     "m2s_sdf_save_generic",
     "m2s_sdf_probe_file",
     "m2s_sdf_read_file",
+    "m2s_order_cells_by_distance",
+    "m2s_merge_instances",
 ]
 
 
@@ -176,6 +189,11 @@ def lib():
         L.m2s_sdf_probe_file.argtypes = [C.c_char_p, C.POINTER(M2SSdfInfo)]
         L.m2s_sdf_read_file.restype = C.c_int
         L.m2s_sdf_read_file.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.POINTER(M2SOpts)]
+        L.m2s_order_cells_by_distance.restype = C.c_int
+        L.m2s_order_cells_by_distance.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_float), C.POINTER(M2SOpts)]
+        L.m2s_merge_instances.restype = C.c_int
+        L.m2s_merge_instances.argtypes = [C.POINTER(M2SInstance), C.c_size_t, C.c_void_p, C.c_void_p, C.POINTER(C.c_float),
+                                          C.POINTER(M2SOpts)]
         _lib = L
     return _lib
 

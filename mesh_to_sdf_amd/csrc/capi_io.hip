@@ -412,4 +412,118 @@ int m2s_sdf_read_file(const char* path, float* queries_out, float* distances_out
   return decode_impl(c, *st, data.data(), data.size(), M2S_MEM_HOST, queries_out, distances_out);
 }
 
+int m2s_order_cells_by_distance(const float* distances, size_t n, uint32_t* ordered_indices, float* iso_limits,
+                                const m2s_opts* opts) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  clear_error();
+  if (n && (!distances || !ordered_indices)) return fail(M2S_ERR_BAD_ARG, "distances / ordered_indices is NULL");
+  if (n >= (1ull << 32)) return fail(M2S_ERR_BAD_ARG, "%zu cells do not fit the u32 indices of the reference (sdf.rs:67)", n);
+  CallCtx c;
+  DeviceState* st = nullptr;
+  int rc = resolve_ctx(opts, &c, &st);
+  if (rc) return rc;
+  size_t need = order_workspace_bytes(n) + 8192;
+  if (c.mem_kind == M2S_MEM_HOST) need += 2 * align_up(n * 4);
+  rc = ensure_capacity(*st, need);
+  if (rc) return rc;
+  Arena ws{st->base, st->cap, 0};
+  float* d_limits = iso_limits ? ws.take<float>(16) : nullptr;
+  const float* d_dist = distances;
+  uint32_t* d_ord = ordered_indices;
+  if (c.mem_kind == M2S_MEM_HOST && n) {
+    float* p = ws.take<float>(n);
+    d_ord = ws.take<uint32_t>(n);
+    if (!p || !d_ord) return fail(M2S_ERR_HIP, "internal: workspace");
+    M2S_HIP_CHECK(hipMemcpyAsync(p, distances, n * 4, hipMemcpyHostToDevice, c.stream));
+    d_dist = p;
+  }
+  rc = launch_order_cells(ws, c.stream, d_dist, n, d_ord, d_limits);
+  if (rc) return rc;
+  if (c.mem_kind == M2S_MEM_HOST && n)
+    M2S_HIP_CHECK(hipMemcpyAsync(ordered_indices, d_ord, n * 4, hipMemcpyDeviceToHost, c.stream));
+  if (iso_limits) M2S_HIP_CHECK(hipMemcpyAsync(st->h_err + 4, d_limits, 8, hipMemcpyDeviceToHost, c.stream));
+  if (c.sync || iso_limits || c.mem_kind == M2S_MEM_HOST) M2S_HIP_CHECK(hipStreamSynchronize(c.stream));
+  if (iso_limits) memcpy(iso_limits, st->h_err + 4, 8);
+  return M2S_OK;
+}
+
+int m2s_merge_instances(const m2s_instance* instances, size_t n_instances, float* vertices_out, uint32_t* indices_out,
+                        float* bbox, const m2s_opts* opts) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  clear_error();
+  if (n_instances && !instances) return fail(M2S_ERR_BAD_ARG, "instances is NULL");
+  if (n_instances >= (1ull << 31)) return fail(M2S_ERR_BAD_ARG, "too many instances");
+  std::vector<uint64_t> first(2 * (n_instances + 1));
+  uint64_t* vfirst = first.data();
+  uint64_t* ifirst = first.data() + n_instances + 1;
+  uint64_t nv = 0, ni = 0;
+  size_t stage = 0;
+  for (size_t k = 0; k < n_instances; ++k) {
+    const m2s_instance& I = instances[k];
+    if ((I.n_vertices && !I.vertices) || (I.n_indices && !I.indices)) return fail(M2S_ERR_BAD_ARG, "instance %zu: NULL buffer", k);
+    if (I.vertex_stride != 0 && (I.vertex_stride < 12 || I.vertex_stride % 4 != 0)) return fail(M2S_ERR_BAD_ARG, "instance %zu: bad vertex_stride", k);
+    vfirst[k] = nv;
+    ifirst[k] = ni;
+    nv += I.n_vertices;
+    ni += I.n_indices;
+    const size_t stride = I.vertex_stride ? I.vertex_stride : 12;
+    stage += align_up(I.n_vertices ? (I.n_vertices - 1) * stride + 12 : 0) + align_up(I.n_indices * 4);
+  }
+  vfirst[n_instances] = nv;
+  ifirst[n_instances] = ni;
+  if ((nv && !vertices_out) || (ni && !indices_out)) return fail(M2S_ERR_BAD_ARG, "vertices_out / indices_out is NULL");
+  CallCtx c;
+  DeviceState* st = nullptr;
+  int rc = resolve_ctx(opts, &c, &st);
+  if (rc) return rc;
+  size_t need = merge_workspace_bytes() + align_up(n_instances * sizeof(InstanceDev)) + align_up(first.size() * 8) + 8192;
+  if (c.mem_kind == M2S_MEM_HOST) need += stage + align_up(nv * 12) + align_up(ni * 4);
+  rc = ensure_capacity(*st, need);
+  if (rc) return rc;
+  Arena ws{st->base, st->cap, 0};
+  std::vector<InstanceDev> table(n_instances);
+  for (size_t k = 0; k < n_instances; ++k) {
+    const m2s_instance& I = instances[k];
+    InstanceDev& D = table[k];
+    D.stride = I.vertex_stride ? I.vertex_stride : 12;
+    memcpy(D.m, I.transform, sizeof(D.m));
+    D.vertices = I.vertices;
+    D.indices = I.indices;
+    if (c.mem_kind == M2S_MEM_HOST) {
+      const size_t vb = I.n_vertices ? (I.n_vertices - 1) * D.stride + 12 : 0, ib = I.n_indices * 4;
+      char* dv = ws.take<char>(vb ? vb : 1);
+      uint32_t* di = ws.take<uint32_t>(I.n_indices ? I.n_indices : 1);
+      if (!dv || !di) return fail(M2S_ERR_HIP, "internal: workspace");
+      if (vb) M2S_HIP_CHECK(hipMemcpyAsync(dv, I.vertices, vb, hipMemcpyHostToDevice, c.stream));
+      if (ib) M2S_HIP_CHECK(hipMemcpyAsync(di, I.indices, ib, hipMemcpyHostToDevice, c.stream));
+      D.vertices = dv;
+      D.indices = di;
+    }
+  }
+  InstanceDev* d_inst = ws.take<InstanceDev>(n_instances ? n_instances : 1);
+  uint64_t* d_first = ws.take<uint64_t>(first.size());
+  float* d_bbox = bbox ? ws.take<float>(16) : nullptr;
+  float* d_v = vertices_out;
+  uint32_t* d_i = indices_out;
+  if (c.mem_kind == M2S_MEM_HOST) {
+    d_v = ws.take<float>(nv ? nv * 3 : 1);
+    d_i = ws.take<uint32_t>(ni ? ni : 1);
+  }
+  if (!d_inst || !d_first || !d_v || !d_i) return fail(M2S_ERR_HIP, "internal: workspace");
+  // the tables are pageable host memory: these copies complete before the vectors go out of scope only
+  // because the call synchronises below
+  if (n_instances) M2S_HIP_CHECK(hipMemcpyAsync(d_inst, table.data(), n_instances * sizeof(InstanceDev), hipMemcpyHostToDevice, c.stream));
+  M2S_HIP_CHECK(hipMemcpyAsync(d_first, first.data(), first.size() * 8, hipMemcpyHostToDevice, c.stream));
+  rc = launch_merge_instances(ws, c.stream, d_inst, d_first, d_first + n_instances + 1, (uint32_t)n_instances, nv, ni, d_v, d_i, d_bbox);
+  if (rc) return rc;
+  if (c.mem_kind == M2S_MEM_HOST) {
+    if (nv) M2S_HIP_CHECK(hipMemcpyAsync(vertices_out, d_v, nv * 12, hipMemcpyDeviceToHost, c.stream));
+    if (ni) M2S_HIP_CHECK(hipMemcpyAsync(indices_out, d_i, ni * 4, hipMemcpyDeviceToHost, c.stream));
+  }
+  if (bbox) M2S_HIP_CHECK(hipMemcpyAsync(st->h_err + 4, d_bbox, 24, hipMemcpyDeviceToHost, c.stream));
+  M2S_HIP_CHECK(hipStreamSynchronize(c.stream));   // always: the instance tables above are call-local
+  if (bbox) memcpy(bbox, st->h_err + 4, 24);
+  return M2S_OK;
+}
+
 }  // extern "C"

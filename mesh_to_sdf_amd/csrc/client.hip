@@ -1,0 +1,190 @@
+// client.hip — the reference client's steps either side of generate_grid_sdf.
+// After (mesh_to_sdf_client/src/sdf.rs:62-72,120):
+//   ordered_indices = (0..n).sorted_by(|i, j| data[i].total_cmp(&data[j])) as u32      (stable)
+//   iso_limits      = data.iter().minmax()
+// Before (mesh_to_sdf_client/src/sdf_program.rs:607-632): the scene's model instances are merged into one
+//   vertex / index buffer — positions through the instance matrix (glam Mat4::transform_point3), indices
+//   offset by the running vertex count — and the per-axis minmax gives the mesh bounding box.
+// f32::total_cmp orders by the IEEE total order: as unsigned integers after flipping all bits of negative
+// values and the sign bit of the others.  The sort is an LSD radix sort of (key, index) pairs — stable, so
+// equal keys keep ascending index exactly like the reference's stable sort.  Integer work: bit-exact.
+#include <cstring>
+
+#include <rocprim/rocprim.hpp>
+
+#include "common.h"
+
+namespace m2s {
+namespace {
+
+struct TotalOrderKey {
+  __host__ __device__ uint32_t operator()(uint32_t b) const { return b ^ ((uint32_t)((int32_t)b >> 31) | 0x80000000u); }
+};
+
+// itertools::minmax (PartialOrd): the FIRST of several equal minima, the LAST of several equal maxima
+// (-0.0 == +0.0 there, so the index decides).  NaN never compares less / greater and is skipped.
+struct MinMax {
+  float mn, mx;
+  uint32_t imn, imx;
+};
+
+__device__ __forceinline__ void mm_merge(MinMax& a, const MinMax& b) {   // b's indices may be smaller or larger
+  if (b.imn != 0xffffffffu && (a.imn == 0xffffffffu || b.mn < a.mn || (b.mn == a.mn && b.imn < a.imn))) { a.mn = b.mn; a.imn = b.imn; }
+  if (b.imx != 0xffffffffu && (a.imx == 0xffffffffu || b.mx > a.mx || (b.mx == a.mx && b.imx > a.imx))) { a.mx = b.mx; a.imx = b.imx; }
+}
+
+__device__ __forceinline__ MinMax mm_wave_reduce(MinMax v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    MinMax o;
+    o.mn = __shfl_down(v.mn, off);
+    o.mx = __shfl_down(v.mx, off);
+    o.imn = __shfl_down(v.imn, off);
+    o.imx = __shfl_down(v.imx, off);
+    mm_merge(v, o);
+  }
+  return v;
+}
+
+__device__ __forceinline__ MinMax mm_block_reduce(MinMax v) {
+  __shared__ MinMax sh[4];
+  v = mm_wave_reduce(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) sh[wave] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; ++w) mm_merge(v, sh[w]);
+  }
+  return v;
+}
+
+// blockIdx.y selects the component when the input is an array of `stride`-float records (xyz vertices).
+__global__ __launch_bounds__(256) void k_minmax_partials(const float* __restrict__ d, uint64_t n, uint32_t stride,
+                                                         MinMax* __restrict__ part) {
+  MinMax v{0.0f, 0.0f, 0xffffffffu, 0xffffffffu};
+  d += blockIdx.y;
+  part += (size_t)blockIdx.y * gridDim.x;
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
+    const float x = d[i * stride];
+    if (x == x) {
+      MinMax o{x, x, (uint32_t)i, (uint32_t)i};
+      mm_merge(v, o);
+    }
+  }
+  v = mm_block_reduce(v);
+  if (threadIdx.x == 0) part[blockIdx.x] = v;
+}
+
+// limits[c] = min, limits[n_comp + c] = max of component c = blockIdx.x.
+__global__ __launch_bounds__(256) void k_minmax_final(const MinMax* __restrict__ part, uint32_t n_part, float* __restrict__ limits) {
+  MinMax v{0.0f, 0.0f, 0xffffffffu, 0xffffffffu};
+  part += (size_t)blockIdx.x * n_part;
+  for (uint32_t i = threadIdx.x; i < n_part; i += 256) mm_merge(v, part[i]);
+  v = mm_block_reduce(v);
+  if (threadIdx.x == 0) {
+    // an input without any comparable value has no minmax (the reference unwraps / bails: sdf.rs:120, sdf_program.rs:624)
+    limits[blockIdx.x] = v.imn == 0xffffffffu ? __uint_as_float(0x7fc00000u) : v.mn;
+    limits[gridDim.x + blockIdx.x] = v.imx == 0xffffffffu ? __uint_as_float(0x7fc00000u) : v.mx;
+  }
+}
+
+// Instance of flat element e: the last i with first[i] <= e (first[] ascending, first[0] == 0).
+__device__ __forceinline__ uint32_t find_instance(const uint64_t* __restrict__ first, uint32_t n_inst, uint64_t e) {
+  uint32_t lo = 0, hi = n_inst;
+  while (hi - lo > 1) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (first[mid] <= e) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+// glam Mat4::transform_point3: res = x_axis*x; res = y_axis*y + res; res = z_axis*z + res; res = w_axis + res
+// (separate mul and add per lane, no FMA; a + b is commutative so the operand order is immaterial).
+__global__ __launch_bounds__(256) void k_merge_vertices(const InstanceDev* __restrict__ inst, const uint64_t* __restrict__ vfirst,
+                                                        uint32_t n_inst, uint64_t n_total, float* __restrict__ out) {
+#pragma clang fp contract(off)
+  const uint64_t e = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= n_total) return;
+  const uint32_t k = find_instance(vfirst, n_inst, e);
+  const InstanceDev I = inst[k];
+  const float* p = reinterpret_cast<const float*>(reinterpret_cast<const char*>(I.vertices) + (e - vfirst[k]) * I.stride);
+  const float x = p[0], y = p[1], z = p[2];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    float acc = I.m[0 + r] * x;
+    acc = I.m[4 + r] * y + acc;
+    acc = I.m[8 + r] * z + acc;
+    acc = I.m[12 + r] + acc;
+    out[3 * e + r] = acc;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_merge_indices(const InstanceDev* __restrict__ inst, const uint64_t* __restrict__ ifirst,
+                                                       const uint64_t* __restrict__ vfirst, uint32_t n_inst, uint64_t n_total,
+                                                       uint32_t* __restrict__ out) {
+  const uint64_t e = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= n_total) return;
+  const uint32_t k = find_instance(ifirst, n_inst, e);
+  out[e] = inst[k].indices[e - ifirst[k]] + (uint32_t)vfirst[k];   // `*i + len as u32`, wrapping like the cast
+}
+
+using KeyIter = rocprim::transform_iterator<const uint32_t*, TotalOrderKey, uint32_t>;
+using IdxIter = rocprim::counting_iterator<uint32_t>;
+
+constexpr unsigned kMinMaxBlocks = 2048;
+
+}  // namespace
+
+size_t order_workspace_bytes(size_t n) {
+  size_t tmp = 0;
+  (void)rocprim::radix_sort_pairs(nullptr, tmp, KeyIter(nullptr, TotalOrderKey()), (uint32_t*)nullptr, IdxIter(0),
+                                  (uint32_t*)nullptr, n, 0, 32, (hipStream_t) nullptr);
+  return tmp + n * 4 + kMinMaxBlocks * sizeof(MinMax) + 4096;
+}
+
+size_t merge_workspace_bytes() { return 3 * kMinMaxBlocks * sizeof(MinMax) + 4096; }
+
+// d_ordered[n] <- indices in ascending total order of d_dist; d_limits[2] (optional) <- (min, max).
+int launch_order_cells(Arena& ws, hipStream_t st, const float* d_dist, size_t n, uint32_t* d_ordered, float* d_limits) {
+  if (d_limits) {
+    MinMax* part = ws.take<MinMax>(kMinMaxBlocks);
+    if (!part) { set_error("internal: workspace"); return M2S_ERR_HIP_INTERNAL; }
+    const unsigned blocks = (unsigned)std::min<size_t>(kMinMaxBlocks, (n + 255) / 256 ? (n + 255) / 256 : 1);
+    hipLaunchKernelGGL(k_minmax_partials, dim3(blocks), dim3(256), 0, st, d_dist, (uint64_t)n, 1u, part);
+    hipLaunchKernelGGL(k_minmax_final, dim3(1), dim3(256), 0, st, part, blocks, d_limits);
+    M2S_HIP_CHECK(hipGetLastError());
+  }
+  if (n == 0) return 0;
+  size_t tmp_bytes = 0;
+  KeyIter keys(reinterpret_cast<const uint32_t*>(d_dist), TotalOrderKey());
+  (void)rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys, (uint32_t*)nullptr, IdxIter(0), (uint32_t*)nullptr, n, 0, 32, st);
+  uint32_t* keys_out = ws.take<uint32_t>(n);
+  char* tmp = ws.take<char>(tmp_bytes ? tmp_bytes : 1);
+  if (!keys_out || !tmp) { set_error("internal: workspace"); return M2S_ERR_HIP_INTERNAL; }
+  M2S_HIP_CHECK(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, keys_out, IdxIter(0), d_ordered, n, 0, 32, st));
+  return 0;
+}
+
+// Merges the instances (device tables prepared by the caller) into d_vertices / d_indices;
+// d_bbox (optional) <- {xmin, ymin, zmin, xmax, ymax, zmax}.
+int launch_merge_instances(Arena& ws, hipStream_t st, const InstanceDev* d_inst, const uint64_t* d_vfirst, const uint64_t* d_ifirst,
+                           uint32_t n_inst, uint64_t n_vertices, uint64_t n_indices, float* d_vertices, uint32_t* d_indices,
+                           float* d_bbox) {
+  if (n_vertices)
+    hipLaunchKernelGGL(k_merge_vertices, dim3((unsigned)((n_vertices + 255) / 256)), dim3(256), 0, st, d_inst, d_vfirst, n_inst,
+                       n_vertices, d_vertices);
+  if (n_indices)
+    hipLaunchKernelGGL(k_merge_indices, dim3((unsigned)((n_indices + 255) / 256)), dim3(256), 0, st, d_inst, d_ifirst, d_vfirst, n_inst,
+                       n_indices, d_indices);
+  if (d_bbox) {
+    MinMax* part = ws.take<MinMax>(3 * kMinMaxBlocks);
+    if (!part) { set_error("internal: workspace"); return M2S_ERR_HIP_INTERNAL; }
+    const unsigned blocks = (unsigned)std::min<uint64_t>(kMinMaxBlocks, (n_vertices + 255) / 256 ? (n_vertices + 255) / 256 : 1);
+    hipLaunchKernelGGL(k_minmax_partials, dim3(blocks, 3), dim3(256), 0, st, d_vertices, n_vertices, 3u, part);
+    hipLaunchKernelGGL(k_minmax_final, dim3(3), dim3(256), 0, st, part, blocks, d_bbox);
+  }
+  M2S_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+}  // namespace m2s

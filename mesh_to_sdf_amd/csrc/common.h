@@ -181,4 +181,19 @@ int launch_encode_points(hipStream_t st, const float* d_points, uint64_t n, uint
 int launch_decode_f32(hipStream_t st, const uint8_t* d_src, uint64_t n, float* d_out, int* d_err);
 int launch_decode_points(hipStream_t st, const uint8_t* d_src, uint64_t n, float* d_out, int* d_err);
 
+// client.hip: stable argsort of f32 by total_cmp + itertools-style minmax (the client's voxel ordering),
+// and the instance merge in front of the generator.
+size_t order_workspace_bytes(size_t n);
+int launch_order_cells(Arena& ws, hipStream_t st, const float* d_dist, size_t n, uint32_t* d_ordered, float* d_limits);
+struct InstanceDev {        // one model instance, device pointers
+  const void* vertices;     // first position; consecutive positions are `stride` bytes apart
+  const uint32_t* indices;
+  uint64_t stride;
+  float m[16];              // glam Mat4, column-major: x_axis, y_axis, z_axis, w_axis
+};
+size_t merge_workspace_bytes();
+int launch_merge_instances(Arena& ws, hipStream_t st, const InstanceDev* d_inst, const uint64_t* d_vfirst, const uint64_t* d_ifirst,
+                           uint32_t n_inst, uint64_t n_vertices, uint64_t n_indices, float* d_vertices, uint32_t* d_indices,
+                           float* d_bbox);
+
 }  // namespace m2s
