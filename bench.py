@@ -172,7 +172,8 @@ def main():
         achieved = b_alg / (dist_ms * 1e-3) / 1e9
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
-        if os.path.exists(pmc):
+        # the PMC figure is per launch over the WHOLE 512^3 grid: it only applies to the 1-GPU, 1-launch step
+        if os.path.exists(pmc) and world == 1 and launches == args.steps and n == 512 and args.mesh == "blob-100k":
             try:
                 traffic = json.load(open(pmc)).get("k_packet_hbm_bytes_per_launch")
             except Exception:
