@@ -242,6 +242,24 @@ typedef struct m2s_instance {
 int m2s_merge_instances(const m2s_instance* instances, size_t n_instances, float* vertices_out, uint32_t* indices_out,
                         float* bbox, const m2s_opts* opts);
 
+/* glTF 2.0 / GLB ingestion (host side) — what the reference client extracts from a file before the merge:
+ * mesh_to_sdf_client/src/gltf/mod.rs:56-174 (models keyed by mesh index, one primitive per mesh survives;
+ * POSITION + indices, sparse accessors and byteStride honoured; missing indices = 0..n, pbr/model.rs:29-32),
+ * gltf/scene/mod.rs:56-160 (node tree, simplify_tree) and gltf/mod.rs:91-106 (flatten_hierarchy: children
+ * first, world = parent * local in glam's f32 arithmetic).  Instances come out in that order, over all scenes.
+ * Errors: M2S_ERR_IO (cannot read), M2S_ERR_BAD_ARG (invalid file, or a required extension other than
+ * KHR_lights_punctual — the reference's gltf build rejects those, gltf/mod.rs:407-410). */
+typedef struct m2s_gltf m2s_gltf;
+typedef struct m2s_gltf_info {
+  uint64_t n_scenes, n_models, n_instances;
+  uint64_t n_vertices, n_indices;   /* summed over the instances = sizes of the merged buffers */
+} m2s_gltf_info;
+int m2s_gltf_open(const char* path, m2s_gltf** out, m2s_gltf_info* info);
+/* Fills `capacity` >= n_instances entries with HOST pointers into the handle (valid until m2s_gltf_close);
+ * pass them to m2s_merge_instances with opts->mem_kind == M2S_MEM_HOST. */
+int m2s_gltf_instances(const m2s_gltf* gltf, m2s_instance* out, size_t capacity);
+void m2s_gltf_close(m2s_gltf* gltf);
+
 /* Library / device introspection. */
 int m2s_version(void);               /* major*1000 + minor */
 int m2s_device_count(void);          /* HIP devices visible; 0 if none (every compute call then fails with M2S_ERR_HIP) */

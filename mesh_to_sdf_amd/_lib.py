@@ -74,6 +74,11 @@ class M2SInstance(C.Structure):
     ]
 
 
+class M2SGltfInfo(C.Structure):
+    _fields_ = [("n_scenes", C.c_uint64), ("n_models", C.c_uint64), ("n_instances", C.c_uint64),
+                ("n_vertices", C.c_uint64), ("n_indices", C.c_uint64)]
+
+
 # every symbol include/m2s.h declares
 EXPORTS = [
     "m2s_generate_sdf",
@@ -104,6 +109,9 @@ EXPORTS = [
     "m2s_sdf_read_file",
     "m2s_order_cells_by_distance",
     "m2s_merge_instances",
+    "m2s_gltf_open",
+    "m2s_gltf_instances",
+    "m2s_gltf_close",
 ]
 
 
@@ -194,6 +202,12 @@ def lib():
         L.m2s_merge_instances.restype = C.c_int
         L.m2s_merge_instances.argtypes = [C.POINTER(M2SInstance), C.c_size_t, C.c_void_p, C.c_void_p, C.POINTER(C.c_float),
                                           C.POINTER(M2SOpts)]
+        L.m2s_gltf_open.restype = C.c_int
+        L.m2s_gltf_open.argtypes = [C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(M2SGltfInfo)]
+        L.m2s_gltf_instances.restype = C.c_int
+        L.m2s_gltf_instances.argtypes = [C.c_void_p, C.POINTER(M2SInstance), C.c_size_t]
+        L.m2s_gltf_close.restype = None
+        L.m2s_gltf_close.argtypes = [C.c_void_p]
         _lib = L
     return _lib
 

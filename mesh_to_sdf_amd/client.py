@@ -13,7 +13,7 @@ from dataclasses import dataclass
 import numpy as np
 
 from . import _lib
-from ._lib import M2SInstance, M2SOpts
+from ._lib import M2SGltfInfo, M2SInstance, M2SOpts
 from .api import Grid, M2SError, SignMethod, Topology, _is_torch, generate_grid_sdf
 from .serde import _opts
 
@@ -95,6 +95,61 @@ def merge_instances(instances, want_bbox=True):
     if rc != 0:
         _raise(rc)
     return vo, io, (np.array(list(bbox), np.float32) if want_bbox else None)
+
+
+class GltfFile:
+    """The models and instances of a glTF / GLB file (mesh_to_sdf_client/src/gltf/mod.rs:56-89 `load_scene`,
+    without the wgpu resources).  instances(): [(vertices (N,3) f32, indices u32, transform (16,) f32)] as numpy
+    views into the native handle — keep the GltfFile alive while they are used."""
+
+    def __init__(self, path):
+        import os
+
+        self._h = C.c_void_p()
+        self.info = M2SGltfInfo()
+        rc = _lib.lib().m2s_gltf_open(os.fsencode(path), C.byref(self._h), C.byref(self.info))
+        if rc != 0:
+            _raise(rc)
+
+    def instances(self):
+        n = int(self.info.n_instances)
+        table = (M2SInstance * max(n, 1))()
+        rc = _lib.lib().m2s_gltf_instances(self._h, table, n)
+        if rc != 0:
+            _raise(rc)
+        out = []
+        for k in range(n):
+            t = table[k]
+            v = np.ctypeslib.as_array(C.cast(t.vertices, C.POINTER(C.c_float)), (t.n_vertices, 3)) if t.n_vertices else np.zeros((0, 3), np.float32)
+            i = np.ctypeslib.as_array(C.cast(t.indices, C.POINTER(C.c_uint32)), (t.n_indices,)) if t.n_indices else np.zeros(0, np.uint32)
+            out.append((v, i, np.array(list(t.transform), np.float32)))
+        return out
+
+    def close(self):
+        if self._h:
+            _lib.lib().m2s_gltf_close(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+
+def load_gltf(path):
+    """mesh_to_sdf_client/src/sdf_program.rs:597-641 `load_gltf`: file -> merged (vertices, indices, bbox[6])."""
+    with GltfFile(path) as g:
+        inst = g.instances()
+        if not inst:
+            raise M2SError(_lib.ERR_BAD_ARG, "Bounding box is ill-defined")   # sdf_program.rs:624-626
+        return merge_instances(inst)
 
 
 @dataclass

@@ -130,3 +130,29 @@ def test_merge_instances_device_tensors_and_generator_input(suzanne):
 def test_merge_nothing():
     v, i, bbox = merge_instances([])
     assert v.shape == (0, 3) and i.size == 0 and np.isnan(bbox).all()
+
+
+def test_load_gltf_end_to_end(tmp_path):
+    """File -> instances (host) -> merged buffers + bbox (GPU) -> grid SDF, against the oracle chain; the client's
+    `load_gltf` + `Sdf::new` flow (sdf_program.rs:597-641, sdf.rs:32-72)."""
+    import os
+
+    import oracle as orc
+    from gltf_synth import zoo
+    from mesh_to_sdf_amd.client import load_gltf
+    from oracle import gltf_oracle as go
+
+    gold = os.path.join(os.path.dirname(__file__), "golden", "gltf")
+    p = tmp_path / "zoo.glb"
+    p.write_bytes(zoo(4).glb())
+    for path in (os.path.join(gold, "cube.glb"), os.path.join(gold, "suzanne.glb"), str(p)):
+        _, models, inst = go.load(path)
+        wv, wi, wb = co.merge_instances([(models[m][0], models[m][1], t.reshape(-1)) for m, t in inst])
+        v, i, bbox = load_gltf(path)
+        assert np.array_equal(v.view(np.uint32), wv.view(np.uint32)) and np.array_equal(i, wi)
+        assert np.array_equal(bbox.view(np.uint32), wb.view(np.uint32))
+        grid = Grid.from_bounding_box(bbox[:3], bbox[3:], [20, 24, 16])
+        got = generate_grid_sdf(v, Topology.TriangleList(i), grid, SignMethod.Raycast)
+        want = orc.generate_grid_sdf(wv, wi, grid.get_first_cell(), grid.get_cell_size(), grid.get_cell_count(),
+                                     sign=int(SignMethod.Raycast), semantics=orc.EXACT)
+        assert np.array_equal(got.view(np.uint32), np.asarray(want, np.float32).view(np.uint32))
