@@ -171,11 +171,14 @@ def main():
         b_alg = 4.0 * slab_voxels + 12.0 * v.shape[0] + 12.0 * n_tris
         achieved = b_alg / (dist_ms * 1e-3) / 1e9
         traffic = None
+        valu_frac = None
         pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
         # the PMC figure is per launch over the WHOLE 512^3 grid: it only applies to the 1-GPU, 1-launch step
         if os.path.exists(pmc) and world == 1 and launches == args.steps and n == 512 and args.mesh == "blob-100k":
             try:
-                traffic = json.load(open(pmc)).get("k_packet_hbm_bytes_per_launch")
+                pj = json.load(open(pmc))
+                traffic = pj.get("k_packet_hbm_bytes_per_launch")
+                valu_frac = pj.get("valu_issue_frac")
             except Exception:
                 traffic = None
         res = {
@@ -213,6 +216,8 @@ def main():
                 "traffic": traffic,
                 "algorithmic_bytes_per_launch": b_alg,
                 "avg_launch_ms": round(dist_ms, 4),
+                # context, from the same PMC passes: the kernel's real ceiling is VALU issue
+                "valu_issue_frac_pmc": valu_frac,
             },
         }
         if world == 1 and not args.no_cpu_baseline:
