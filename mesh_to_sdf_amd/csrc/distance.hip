@@ -41,12 +41,22 @@ struct GridBrick {
 // Brick sequence number -> brick coordinates.  Bricks are walked in 8x8x8 super-bricks (z fastest inside
 // and between them), so that consecutive packets of an XCD keep touching the same part of the BVH while
 // its 4 MiB L2 still holds it; a plain z-y-x sweep returns to a node only after a whole z column.
+// A thin x-slab (multi-GPU pieces are 16 layers = 4 bricks at 8 GPUs x 4 chunks) uses super-bricks that are
+// 4, 2 or 1 bricks wide in x instead, so that at most 1/8 of the launched packets are padding.
+__host__ __device__ __forceinline__ uint32_t super_brick_xlog(uint32_t nbx) {
+  for (uint32_t xl = 3; xl > 0; --xl) {
+    const uint32_t padded = ((nbx + (1u << xl) - 1u) >> xl) << xl;
+    if ((padded - nbx) * 8u <= nbx) return xl;
+  }
+  return 0;
+}
 __device__ __forceinline__ void brick_coords(const GridParams& g, uint32_t brick, uint32_t* bx, uint32_t* by, uint32_t* bz) {
   const uint32_t nby = (g.n[1] + 3) >> 2, nbz = (g.n[2] + 3) >> 2;
   const uint32_t sy = (nby + 7) >> 3, sz = (nbz + 7) >> 3;
-  const uint32_t sb = brick >> 9, in = brick & 511u;          // super-brick index, position inside (padded grid)
+  const uint32_t xl = super_brick_xlog((g.xe - g.xb + 3) >> 2);
+  const uint32_t sb = brick >> (6 + xl), in = brick & ((64u << xl) - 1u);   // super-brick index, position inside (padded grid)
   const uint32_t sbz = sb % sz, sby = (sb / sz) % sy, sbx = sb / (sz * sy);
-  *bx = sbx * 8 + (in >> 6);
+  *bx = (sbx << xl) + (in >> 6);
   *by = sby * 8 + ((in >> 3) & 7u);
   *bz = sbz * 8 + (in & 7u);
 }
@@ -576,9 +586,10 @@ void launch_brute(hipStream_t st, const DeviceMesh& mesh, const GridParams& g, c
                      out, err, n_packets);
 }
 
-uint32_t host_brick_count(const GridParams& g) {   // padded to whole 8x8x8 super-bricks
+uint32_t host_brick_count(const GridParams& g) {   // padded to whole super-bricks
   const uint32_t nbx = (g.xe - g.xb + 3) >> 2, nby = (g.n[1] + 3) >> 2, nbz = (g.n[2] + 3) >> 2;
-  return ((nbx + 7) >> 3) * ((nby + 7) >> 3) * ((nbz + 7) >> 3) * 512u;
+  const uint32_t xl = super_brick_xlog(nbx);
+  return ((nbx + (1u << xl) - 1u) >> xl) * ((nby + 7) >> 3) * ((nbz + 7) >> 3) * (64u << xl);
 }
 
 }  // namespace
