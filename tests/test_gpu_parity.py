@@ -500,3 +500,39 @@ def test_generic_10M_queries_subsample():
     assert_bit_equal(got[sub].cpu().numpy(), want, "10M RtreeBvh subsample")
     rev = generate_sdf(dv, Topology.TriangleList(di), torch.flip(dq, dims=[0]), AccelerationMethod.RtreeBvh)
     assert torch.equal(torch.flip(rev, dims=[0]), got)
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("M2S_FUZZ_SEEDS", "12"))))
+def test_fuzz_tree_walk_equals_brute_force(seed):
+    """Random triangle soups at random scales / offsets / anisotropic (also negative) cell sizes: the pruned LBVH walk
+    (algorithm 0) must equal the on-device brute force over all triangles (algorithm 1) bit for bit, in both
+    sign modes and for random queries — pruning slack, oriented bounds, leaf pre-test and seeds are all in play.
+    (Brute force itself is pinned to the oracle by the algorithm=1 variants of the tests above.)"""
+    rng = np.random.default_rng(1000 + seed)
+    nt = int(rng.integers(1, 4000))
+    scale = float(10.0 ** rng.uniform(-3, 3))
+    offset = rng.uniform(-1, 1, 3) * scale * float(10.0 ** rng.uniform(0, 2.5)) * (seed % 3 == 0)
+    centers = rng.uniform(-1, 1, (nt, 1, 3)) * scale
+    size = scale * 10.0 ** rng.uniform(-3, -0.3, (nt, 1, 1))
+    tri = (centers + rng.standard_normal((nt, 3, 3)) * size + offset).astype(F)
+    if seed % 4 == 1:                       # some exactly degenerate and duplicated triangles
+        tri[::7, 2] = tri[::7, 1]
+        tri[5::11] = tri[4::11][: tri[5::11].shape[0]]
+    v = tri.reshape(-1, 3)
+    idx = np.arange(v.shape[0], dtype=np.uint32)
+    lo, hi = v.min(0), v.max(0)
+    ext = np.maximum(hi - lo, 1e-3 * scale)
+    lo, hi = lo - rng.uniform(0.0, 0.5) * ext, hi + rng.uniform(0.0, 0.5) * ext
+    counts = [int(c) for c in rng.integers(5, 70, 3)]
+    if seed % 5 == 2:
+        lo[0], hi[0] = hi[0], lo[0]         # negative cell size along x
+    grid = Grid.from_bounding_box(lo, hi, counts)
+    for sign in (SignMethod.Raycast, SignMethod.Normal):
+        a = generate_grid_sdf(v, Topology.TriangleList(idx), grid, sign, algorithm=0)
+        b = generate_grid_sdf(v, Topology.TriangleList(idx), grid, sign, algorithm=1)
+        assert_bit_equal(a, b, f"grid seed {seed} {sign.name} nt {nt} scale {scale:.3g}")
+    q = (lo + rng.uniform(-0.3, 1.3, (20000, 3)) * (hi - lo)).astype(F)
+    for am in (AccelerationMethod.RtreeBvh, AccelerationMethod.Rtree, AccelerationMethod.Bvh(SignMethod.Normal)):
+        a = generate_sdf(v, Topology.TriangleList(idx), q, am, algorithm=0)
+        b = generate_sdf(v, Topology.TriangleList(idx), q, am, algorithm=1)
+        assert_bit_equal(a, b, f"queries seed {seed} accel {am.kind}")
