@@ -223,9 +223,14 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(v, idx, lo, hi, int(sign), args.cpu_seconds)
             # the PCIe-inclusive drop-in call (host pointers in/out), reported for DESIGN.md; never `value`
-            t1 = time.perf_counter()
-            generate_grid_sdf(v, Topology.TriangleList(idx), grid, sign)
-            res["host_pointer_call_ms"] = round((time.perf_counter() - t1) * 1e3, 2)
+            host_out = np.empty(n ** 3, np.float32)
+            times = []
+            for _ in range(3):   # the first call also allocates the pinned ring and faults the output pages in
+                t1 = time.perf_counter()
+                generate_grid_sdf(v, Topology.TriangleList(idx), grid, sign, out=host_out)
+                times.append((time.perf_counter() - t1) * 1e3)
+            res["host_pointer_call_ms"] = round(min(times[1:]), 2)
+            res["host_pointer_first_call_ms"] = round(times[0], 2)
         print(json.dumps(res), flush=True)
     if dist.is_initialized():
         dist.destroy_process_group()

@@ -3,9 +3,11 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <map>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 #include "../../include/m2s.h"
@@ -229,6 +231,184 @@ int fill_grid_params(const m2s_grid* grid, const m2s_opts* opts, GridParams* g, 
   return 0;
 }
 
+
+// ---- host-pointer result path ----------------------------------------------------------------------
+// The drop-in call returns the grid in caller-owned PAGEABLE memory (the reference returns a Vec<f32>).  One
+// hipMemcpy of 512 MiB into pageable memory runs at ~10 GB/s and only starts when the last voxel is done
+// (55 of the 73 ms of such a call).  Instead the slab is computed in x-pieces; each finished piece crosses PCIe
+// into a pinned ring buffer on a second stream while the next piece computes, and host threads move it from
+// the ring into the caller's array (spreading its first-touch page faults as well).
+struct ParallelCopy {
+  std::vector<std::thread> th;
+  void start(char* dst, const char* src, size_t n) {
+    const unsigned hw = std::thread::hardware_concurrency();
+    const size_t parts = std::max<size_t>(1, std::min<size_t>({(size_t)8, (size_t)(hw ? hw : 1), n / (4u << 20) + 1}));
+    const size_t per = (n + parts - 1) / parts;
+    for (size_t k = 0; k < parts; ++k) {
+      const size_t o = k * per;
+      if (o >= n) break;
+      const size_t l = std::min(per, n - o);
+      th.emplace_back([=]() { memcpy(dst + o, src + o, l); });
+    }
+  }
+  void join() {
+    for (auto& t : th) t.join();
+    th.clear();
+  }
+  ~ParallelCopy() { join(); }
+};
+
+int ensure_ring(DeviceState& st, size_t bytes) {
+  if (!st.copy_stream) M2S_HIP_CHECK(hipStreamCreateWithFlags(&st.copy_stream, hipStreamNonBlocking));
+  if (bytes <= st.ring_bytes) return 0;
+  for (auto& r : st.ring) {
+    if (r) (void)hipHostFree(r);
+    r = nullptr;
+  }
+  st.ring_bytes = 0;
+  for (auto& r : st.ring) M2S_HIP_CHECK(hipHostMalloc((void**)&r, bytes, hipHostMallocDefault));
+  st.ring_bytes = bytes;
+  return 0;
+}
+
+// Computes the slab [g.xb, g.xe) into d_slab piece by piece and streams it to `out_slab` (host, slab-relative).
+// Records ev[3] after the last piece's kernels.  *pieces_out = number of dominant launches.
+int run_grid_distance_to_host(Arena& ws, const CallCtx& c, DeviceState& st, const DeviceMesh& mesh, const GridParams& g,
+                              int sign_method, const uint32_t* plane, float* d_slab, int* d_err, float* out_slab,
+                              uint32_t* pieces_out) {
+  const uint64_t row = (uint64_t)g.n[1] * g.n[2];
+  const uint32_t layers = g.xe - g.xb;
+  static const size_t piece_mb = getenv("M2S_HOST_PIECE_MB") ? (size_t)atoi(getenv("M2S_HOST_PIECE_MB")) : 64;
+  uint64_t lpp = row ? std::max<uint64_t>(1, (piece_mb << 20) / 4 / row) : layers;
+  lpp = std::max<uint64_t>(4, lpp / 4 * 4);                       // whole 4-voxel bricks
+  const uint32_t pieces = (uint32_t)((layers + lpp - 1) / lpp);
+  *pieces_out = pieces;
+  int rc = ensure_ring(st, (size_t)std::min<uint64_t>(lpp, layers) * row * 4);
+  if (rc) return rc;
+  std::vector<hipEvent_t> done(pieces), copied(pieces);
+  for (uint32_t i = 0; i < pieces; ++i) {
+    M2S_HIP_CHECK(hipEventCreateWithFlags(&done[i], hipEventDisableTiming));
+    M2S_HIP_CHECK(hipEventCreateWithFlags(&copied[i], hipEventDisableTiming));
+  }
+  auto cleanup = [&]() {
+    for (uint32_t i = 0; i < pieces; ++i) { (void)hipEventDestroy(done[i]); (void)hipEventDestroy(copied[i]); }
+  };
+  const size_t ws_mark = ws.off;
+  const int mode = sign_method == M2S_SIGN_RAYCAST ? MODE_UNSIGNED : MODE_NORMAL_FOLD;
+  for (uint32_t i = 0; i < pieces; ++i) {                          // all kernels first: the GPU never waits for the host
+    GridParams gp = g;
+    gp.xb = g.xb + (uint32_t)(i * lpp);
+    gp.xe = (uint32_t)std::min<uint64_t>(g.xe, gp.xb + lpp);
+    ws.off = ws_mark;                                              // pieces run one after the other on c.stream: same scratch
+    rc = launch_grid_distance(ws, c.stream, mesh, gp, mode, plane, c.algorithm, d_slab, d_err, nullptr);
+    if (rc) { cleanup(); return rc; }
+    if (hipEventRecord(done[i], c.stream) != hipSuccess) { cleanup(); return fail(M2S_ERR_HIP, "hipEventRecord failed"); }
+  }
+  if (hipEventRecord(st.ev[3], c.stream) != hipSuccess) { cleanup(); return fail(M2S_ERR_HIP, "hipEventRecord failed"); }
+  ParallelCopy mover[DeviceState::RING];
+  auto piece_span = [&](uint32_t i, size_t* off, size_t* bytes) {
+    const uint64_t x0 = (uint64_t)i * lpp, x1 = std::min<uint64_t>(layers, x0 + lpp);
+    *off = (size_t)(x0 * row);
+    *bytes = (size_t)((x1 - x0) * row * 4);
+  };
+  hipError_t e = hipSuccess;
+  for (uint32_t i = 0; i <= pieces && e == hipSuccess; ++i) {
+    if (i < pieces) {
+      const int b = i % DeviceState::RING;
+      mover[b].join();                                             // piece i-RING has left this buffer
+      size_t off, bytes;
+      piece_span(i, &off, &bytes);
+      e = hipStreamWaitEvent(st.copy_stream, done[i], 0);
+      if (e == hipSuccess) e = hipMemcpyAsync(st.ring[b], d_slab + off, bytes, hipMemcpyDeviceToHost, st.copy_stream);
+      if (e == hipSuccess) e = hipEventRecord(copied[i], st.copy_stream);
+    }
+    if (i >= 1 && e == hipSuccess) {
+      const uint32_t j = i - 1;
+      size_t off, bytes;
+      piece_span(j, &off, &bytes);
+      e = hipEventSynchronize(copied[j]);
+      if (e == hipSuccess) mover[j % DeviceState::RING].start(reinterpret_cast<char*>(out_slab + off), st.ring[j % DeviceState::RING], bytes);
+    }
+  }
+  for (auto& m : mover) m.join();
+  cleanup();
+  if (e != hipSuccess) return fail(M2S_ERR_HIP, "pipelined device-to-host copy failed: %s", hipGetErrorString(e));
+  return 0;
+}
+
+
+// Large host<->device transfers of caller-owned pageable arrays at PCIe speed: through the pinned ring, with
+// host threads doing the pageable side.  `stream` is the call's stream: H2D data is visible to work enqueued
+// on it afterwards; D2H starts after everything enqueued on it so far.  Both return with the copy complete.
+constexpr size_t STAGE_CHUNK = 32u << 20;
+constexpr size_t STAGE_MIN = 8u << 20;      // below this a plain hipMemcpyAsync is as good
+
+int staged_h2d(DeviceState& st, hipStream_t stream, char* d_dst, const char* h_src, size_t bytes) {
+  if (bytes < STAGE_MIN) {
+    M2S_HIP_CHECK(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, stream));
+    return 0;
+  }
+  int rc = ensure_ring(st, STAGE_CHUNK);
+  if (rc) return rc;
+  hipEvent_t sent[DeviceState::RING];
+  for (auto& e : sent) M2S_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  hipError_t e = hipSuccess;
+  const size_t n = (bytes + STAGE_CHUNK - 1) / STAGE_CHUNK;
+  ParallelCopy mover;
+  for (size_t i = 0; i < n && e == hipSuccess; ++i) {
+    const int b = (int)(i % DeviceState::RING);
+    const size_t off = i * STAGE_CHUNK, len = std::min(STAGE_CHUNK, bytes - off);
+    if (i >= (size_t)DeviceState::RING) e = hipEventSynchronize(sent[b]);     // the ring slot has been read by the DMA
+    if (e != hipSuccess) break;
+    mover.start(st.ring[b], h_src + off, len);
+    mover.join();
+    e = hipMemcpyAsync(d_dst + off, st.ring[b], len, hipMemcpyHostToDevice, st.copy_stream);
+    if (e == hipSuccess) e = hipEventRecord(sent[b], st.copy_stream);
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(st.copy_stream);   // complete (and the ring is free) before returning
+  for (auto& ev : sent) (void)hipEventDestroy(ev);
+  if (e != hipSuccess) return fail(M2S_ERR_HIP, "staged host-to-device copy failed: %s", hipGetErrorString(e));
+  (void)stream;   // the data is resident before anything else is enqueued on `stream`
+  return 0;
+}
+
+int staged_d2h(DeviceState& st, hipStream_t stream, char* h_dst, const char* d_src, size_t bytes) {
+  if (bytes < STAGE_MIN) {
+    M2S_HIP_CHECK(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, stream));
+    return 0;
+  }
+  int rc = ensure_ring(st, STAGE_CHUNK);
+  if (rc) return rc;
+  hipEvent_t ready, got[DeviceState::RING];
+  M2S_HIP_CHECK(hipEventCreateWithFlags(&ready, hipEventDisableTiming));
+  for (auto& e : got) M2S_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  hipError_t e = hipEventRecord(ready, stream);
+  if (e == hipSuccess) e = hipStreamWaitEvent(st.copy_stream, ready, 0);
+  const size_t n = (bytes + STAGE_CHUNK - 1) / STAGE_CHUNK;
+  ParallelCopy mover[DeviceState::RING];
+  for (size_t i = 0; i <= n && e == hipSuccess; ++i) {
+    if (i < n) {
+      const int b = (int)(i % DeviceState::RING);
+      mover[b].join();
+      const size_t off = i * STAGE_CHUNK, len = std::min(STAGE_CHUNK, bytes - off);
+      e = hipMemcpyAsync(st.ring[b], d_src + off, len, hipMemcpyDeviceToHost, st.copy_stream);
+      if (e == hipSuccess) e = hipEventRecord(got[b], st.copy_stream);
+    }
+    if (i >= 1 && e == hipSuccess) {
+      const size_t j = i - 1;
+      const int b = (int)(j % DeviceState::RING);
+      const size_t off = j * STAGE_CHUNK, len = std::min(STAGE_CHUNK, bytes - off);
+      e = hipEventSynchronize(got[b]);
+      if (e == hipSuccess) mover[b].start(h_dst + off, st.ring[b], len);
+    }
+  }
+  for (auto& m : mover) m.join();
+  (void)hipEventDestroy(ready);
+  for (auto& ev : got) (void)hipEventDestroy(ev);
+  if (e != hipSuccess) return fail(M2S_ERR_HIP, "staged device-to-host copy failed: %s", hipGetErrorString(e));
+  return 0;
+}
+
 }  // namespace
 }  // namespace m2s
 
@@ -286,6 +466,11 @@ void m2s_release_workspace(void) {
     if (kv.second.spare_mesh) (void)hipFree(kv.second.spare_mesh);
     kv.second.spare_mesh = nullptr;
     kv.second.spare_mesh_bytes = 0;
+    for (auto& r : kv.second.ring) {
+      if (r) (void)hipHostFree(r);
+      r = nullptr;
+    }
+    kv.second.ring_bytes = 0;
   }
 }
 
@@ -373,6 +558,14 @@ int m2s_generate_grid_sdf(const float* vertices, size_t n_vertices, const void* 
     if (rc) return rc;
   }
   M2S_HIP_CHECK(hipEventRecord(st->ev[2], c.stream));
+  if (c.mem_kind == M2S_MEM_HOST && !getenv("M2S_STATS")) {
+    uint32_t pieces = 1;
+    rc = run_grid_distance_to_host(ws, c, *st, mesh, g, sign_method, plane, d_slab, d_err, out + (size_t)xb * ny * nz, &pieces);
+    if (rc) return rc;
+    rc = finish_call(c, *st, d_err, c.timings, n_tris, slab_cells, sign_method == M2S_SIGN_RAYCAST, false);
+    if (c.timings) c.timings->distance_launches = pieces;   // distance_ms then covers the seed passes of every piece too
+    return rc;
+  }
   rc = run_grid_distance(ws, c, *st, mesh, g, sign_method, plane, d_out, d_err);
   if (rc) return rc;
   if (c.mem_kind == M2S_MEM_HOST)
@@ -423,7 +616,8 @@ int m2s_generate_sdf(const float* vertices, size_t n_vertices, const void* indic
     float* dq = ws.take<float>(n_queries * 3);
     d_out = ws.take<float>(n_queries);
     if (!dq || !d_out) return fail(M2S_ERR_HIP, "internal: workspace");
-    M2S_HIP_CHECK(hipMemcpyAsync(dq, queries, n_queries * 12, hipMemcpyHostToDevice, c.stream));
+    rc = staged_h2d(*st, c.stream, reinterpret_cast<char*>(dq), reinterpret_cast<const char*>(queries), n_queries * 12);
+    if (rc) return rc;
     d_q = dq;
   }
   M2S_HIP_CHECK(hipEventRecord(st->ev[0], c.stream));
@@ -435,8 +629,10 @@ int m2s_generate_sdf(const float* vertices, size_t n_vertices, const void* indic
   rc = launch_query_distance(ws, c.stream, mesh, d_q, n_queries, mode, sign_src, algorithm, d_out, d_err);
   if (rc) return rc;
   M2S_HIP_CHECK(hipEventRecord(st->ev[3], c.stream));
-  if (c.mem_kind == M2S_MEM_HOST)
-    M2S_HIP_CHECK(hipMemcpyAsync(out, d_out, n_queries * 4, hipMemcpyDeviceToHost, c.stream));
+  if (c.mem_kind == M2S_MEM_HOST) {
+    rc = staged_d2h(*st, c.stream, reinterpret_cast<char*>(out), reinterpret_cast<const char*>(d_out), n_queries * 4);
+    if (rc) return rc;
+  }
   if (n_out) *n_out = n_queries;
   return finish_call(c, *st, d_err, c.timings, n_tris, n_queries, false);
 }
@@ -573,10 +769,20 @@ int m2s_mesh_generate_grid_sdf(m2s_mesh* m, const m2s_grid* grid, int sign_metho
     plane = m->plane;
   }
   M2S_HIP_CHECK(hipEventRecord(st->ev[2], c.stream));
+  if (c.mem_kind == M2S_MEM_HOST && !getenv("M2S_STATS")) {   // host result: x-pieces stream out while the next computes
+    uint32_t pieces = 1;
+    rc = run_grid_distance_to_host(ws, c, *st, m->dm, g, sign_method, plane, d_slab, d_err, out + (size_t)xb * ny * nz, &pieces);
+    if (rc) return rc;
+    rc = finish_call(c, *st, d_err, c.timings, m->n_tris, slab_cells, built_planes, false);
+    if (c.timings) c.timings->distance_launches = pieces;
+    return rc;
+  }
   rc = run_grid_distance(ws, c, *st, m->dm, g, sign_method, plane, d_out, d_err);
   if (rc) return rc;
-  if (c.mem_kind == M2S_MEM_HOST)
-    M2S_HIP_CHECK(hipMemcpyAsync(out + (size_t)xb * ny * nz, d_slab, slab_cells * 4, hipMemcpyDeviceToHost, c.stream));
+  if (c.mem_kind == M2S_MEM_HOST) {
+    rc = staged_d2h(*st, c.stream, reinterpret_cast<char*>(out + (size_t)xb * ny * nz), reinterpret_cast<const char*>(d_slab), slab_cells * 4);
+    if (rc) return rc;
+  }
   if (!c.sync) {
     // Asynchronous call: no host sync now.  Keep the event pair around the dominant launch so that its
     // duration can be read later (m2s_mesh_drain_timings): ev[4] was recorded just before that launch;
@@ -652,7 +858,8 @@ int m2s_mesh_generate_sdf(m2s_mesh* m, const float* queries, size_t n_queries, i
     float* dq = ws.take<float>(n_queries * 3);
     d_out = ws.take<float>(n_queries);
     if (!dq || !d_out) return fail(M2S_ERR_HIP, "internal: workspace");
-    M2S_HIP_CHECK(hipMemcpyAsync(dq, queries, n_queries * 12, hipMemcpyHostToDevice, c.stream));
+    rc = staged_h2d(*st, c.stream, reinterpret_cast<char*>(dq), reinterpret_cast<const char*>(queries), n_queries * 12);
+    if (rc) return rc;
     d_q = dq;
   }
   M2S_HIP_CHECK(hipEventRecord(st->ev[0], c.stream));
@@ -661,7 +868,10 @@ int m2s_mesh_generate_sdf(m2s_mesh* m, const float* queries, size_t n_queries, i
   rc = launch_query_distance(ws, c.stream, m->dm, d_q, n_queries, mode, sign_src, algorithm, d_out, d_err);
   if (rc) return rc;
   M2S_HIP_CHECK(hipEventRecord(st->ev[3], c.stream));
-  if (c.mem_kind == M2S_MEM_HOST) M2S_HIP_CHECK(hipMemcpyAsync(out, d_out, n_queries * 4, hipMemcpyDeviceToHost, c.stream));
+  if (c.mem_kind == M2S_MEM_HOST) {
+    rc = staged_d2h(*st, c.stream, reinterpret_cast<char*>(out), reinterpret_cast<const char*>(d_out), n_queries * 4);
+    if (rc) return rc;
+  }
   if (n_out) *n_out = n_queries;
   return finish_call(c, *st, d_err, c.timings, m->n_tris, n_queries, false);
 }

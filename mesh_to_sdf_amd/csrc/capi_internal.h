@@ -16,6 +16,11 @@ struct DeviceState {
   int* h_err = nullptr;  // pinned
   char* spare_mesh = nullptr;  // last destroyed m2s_mesh block, recycled by the next m2s_mesh_create
   size_t spare_mesh_bytes = 0;
+  // host-pointer calls: pinned ring + copy stream for the pipelined D2H of the result (capi.hip)
+  static constexpr int RING = 3;
+  char* ring[RING] = {nullptr, nullptr, nullptr};
+  size_t ring_bytes = 0;
+  hipStream_t copy_stream = nullptr;
 };
 
 struct CallCtx {
