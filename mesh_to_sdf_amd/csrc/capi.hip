@@ -232,6 +232,8 @@ int fill_grid_params(const m2s_grid* grid, const m2s_opts* opts, GridParams* g, 
 }
 
 
+}  // namespace
+
 // ---- host-pointer result path ----------------------------------------------------------------------
 // The drop-in call returns the grid in caller-owned PAGEABLE memory (the reference returns a Vec<f32>).  One
 // hipMemcpy of 512 MiB into pageable memory runs at ~10 GB/s and only starts when the last voxel is done
@@ -409,7 +411,39 @@ int staged_d2h(DeviceState& st, hipStream_t stream, char* h_dst, const char* d_s
   return 0;
 }
 
-}  // namespace
+
+// Same pipeline with a file as the sink: the ring slot is written out directly (no host copy of the whole array).
+int staged_d2h_to_file(DeviceState& st, hipStream_t stream, FILE* f, const char* d_src, size_t bytes) {
+  int rc = ensure_ring(st, STAGE_CHUNK);
+  if (rc) return rc;
+  hipEvent_t ready, got[DeviceState::RING];
+  M2S_HIP_CHECK(hipEventCreateWithFlags(&ready, hipEventDisableTiming));
+  for (auto& e : got) M2S_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  hipError_t e = hipEventRecord(ready, stream);
+  if (e == hipSuccess) e = hipStreamWaitEvent(st.copy_stream, ready, 0);
+  const size_t n = (bytes + STAGE_CHUNK - 1) / STAGE_CHUNK;
+  bool io_ok = true;
+  for (size_t i = 0; i < n + 2 && e == hipSuccess; ++i) {
+    if (i >= 2) {                                                 // write chunk i-2 (its slot is reused by chunk i+1)
+      const size_t j = i - 2;
+      const int b = (int)(j % DeviceState::RING);
+      const size_t off = j * STAGE_CHUNK, len = std::min(STAGE_CHUNK, bytes - off);
+      e = hipEventSynchronize(got[b]);
+      if (e == hipSuccess && io_ok) io_ok = fwrite(st.ring[b], 1, len, f) == len;
+    }
+    if (i < n) {
+      const int b = (int)(i % DeviceState::RING);
+      const size_t off = i * STAGE_CHUNK, len = std::min(STAGE_CHUNK, bytes - off);
+      e = hipMemcpyAsync(st.ring[b], d_src + off, len, hipMemcpyDeviceToHost, st.copy_stream);
+      if (e == hipSuccess) e = hipEventRecord(got[b], st.copy_stream);
+    }
+  }
+  (void)hipEventDestroy(ready);
+  for (auto& ev : got) (void)hipEventDestroy(ev);
+  if (e != hipSuccess) return fail(M2S_ERR_HIP, "staged device-to-host copy failed: %s", hipGetErrorString(e));
+  return io_ok ? 0 : M2S_ERR_IO;
+}
+
 }  // namespace m2s
 
 // Persistent mesh: triangle records + LBVH resident on one device, reusable across calls

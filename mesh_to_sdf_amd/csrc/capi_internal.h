@@ -1,6 +1,7 @@
 // capi_internal.h — per-device state and call context shared by the C-ABI translation units
 // (capi.hip: distance path; capi_io.hip: container encode/decode, cell ordering, instance merge).
 #pragma once
+#include <cstdio>
 #include <mutex>
 
 #include "../../include/m2s.h"
@@ -38,6 +39,10 @@ void clear_error();
 int fail(int code, const char* fmt, ...);
 int resolve_ctx(const m2s_opts* opts, CallCtx* c, DeviceState** st);
 int ensure_capacity(DeviceState& s, size_t bytes);
+// Pageable host arrays <-> device at PCIe speed through the pinned ring (capi.hip); complete on return.
+int staged_h2d(DeviceState& st, hipStream_t stream, char* d_dst, const char* h_src, size_t bytes);
+int staged_d2h(DeviceState& st, hipStream_t stream, char* h_dst, const char* d_src, size_t bytes);
+int staged_d2h_to_file(DeviceState& st, hipStream_t stream, FILE* f, const char* d_src, size_t bytes);   // M2S_ERR_IO on a short write
 inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
 
 }  // namespace m2s

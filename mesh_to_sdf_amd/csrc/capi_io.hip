@@ -1,6 +1,10 @@
 // capi_io.hip — C ABI of the SURVEY §8(f) rows: the V1 container (serde.rs:75-221).  The envelope is
 // host work (wire.h); the payload arrays go through serde.hip's kernels whatever side the data is on.
 #include <cstdio>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -45,9 +49,10 @@ bool plan_generic(uint64_t nq, uint64_t nd, Layout* L) {
   return true;
 }
 
-// Encodes into `out` (host if out_kind == M2S_MEM_HOST).  Inputs live where c.mem_kind says.
+// Encodes into device memory: `out` itself when out_kind == M2S_MEM_DEVICE, else an arena buffer returned in
+// *d_encoded (the caller moves it to its host sink).  Inputs live where c.mem_kind says.
 int encode_impl(const CallCtx& c, DeviceState& st, const Layout& L, const float* queries, uint64_t nq,
-                const float* distances, uint64_t nd, uint8_t* out, int out_kind, bool sync) {
+                const float* distances, uint64_t nd, uint8_t* out, int out_kind, bool sync, uint8_t** d_encoded) {
   size_t need = 4096;
   if (c.mem_kind == M2S_MEM_HOST) need += align_up(nd * 4) + align_up(nq * 12);
   if (out_kind == M2S_MEM_HOST) need += align_up(L.total + 64);
@@ -60,13 +65,15 @@ int encode_impl(const CallCtx& c, DeviceState& st, const Layout& L, const float*
     if (nd) {
       float* p = ws.take<float>(nd);
       if (!p) return fail(M2S_ERR_HIP, "internal: workspace");
-      M2S_HIP_CHECK(hipMemcpyAsync(p, distances, nd * 4, hipMemcpyHostToDevice, c.stream));
+      rc = staged_h2d(st, c.stream, reinterpret_cast<char*>(p), reinterpret_cast<const char*>(distances), nd * 4);
+      if (rc) return rc;
       d_dist = p;
     }
     if (nq) {
       float* p = ws.take<float>(nq * 3);
       if (!p) return fail(M2S_ERR_HIP, "internal: workspace");
-      M2S_HIP_CHECK(hipMemcpyAsync(p, queries, nq * 12, hipMemcpyHostToDevice, c.stream));
+      rc = staged_h2d(st, c.stream, reinterpret_cast<char*>(p), reinterpret_cast<const char*>(queries), nq * 12);
+      if (rc) return rc;
       d_q = p;
     }
   }
@@ -85,8 +92,11 @@ int encode_impl(const CallCtx& c, DeviceState& st, const Layout& L, const float*
   if (rc) return rc;
   rc = launch_encode_f32(c.stream, d_dist, nd, d_out + L.dist_off);
   if (rc) return rc;
-  if (out_kind == M2S_MEM_HOST)
-    M2S_HIP_CHECK(hipMemcpyAsync(out, d_out, L.total, hipMemcpyDeviceToHost, c.stream));
+  if (d_encoded) *d_encoded = d_out;
+  if (out_kind == M2S_MEM_HOST && out) {
+    rc = staged_d2h(st, c.stream, reinterpret_cast<char*>(out), reinterpret_cast<const char*>(d_out), L.total);
+    if (rc) return rc;
+  }
   if (sync || out_kind == M2S_MEM_HOST || c.mem_kind == M2S_MEM_HOST) M2S_HIP_CHECK(hipStreamSynchronize(c.stream));
   return M2S_OK;
 }
@@ -192,7 +202,8 @@ int decode_impl(const CallCtx& c, DeviceState& st, const uint8_t* bytes, size_t 
     if (bytes_kind == M2S_MEM_HOST) {
       uint8_t* p = ws.take<uint8_t>(n + 64);
       if (!p) return fail(M2S_ERR_HIP, "internal: workspace");
-      M2S_HIP_CHECK(hipMemcpyAsync(p, bytes, n, hipMemcpyHostToDevice, c.stream));
+      rc = staged_h2d(st, c.stream, reinterpret_cast<char*>(p), reinterpret_cast<const char*>(bytes), n);
+      if (rc) return rc;
       d_bytes = p;
     }
     float* d_q = queries_out;
@@ -210,8 +221,8 @@ int decode_impl(const CallCtx& c, DeviceState& st, const uint8_t* bytes, size_t 
     if (rc) return rc;
     M2S_HIP_CHECK(hipMemcpyAsync(st.h_err, d_err, 4, hipMemcpyDeviceToHost, c.stream));
     if (c.mem_kind == M2S_MEM_HOST) {
-      if (nd) M2S_HIP_CHECK(hipMemcpyAsync(distances_out, d_d, nd * 4, hipMemcpyDeviceToHost, c.stream));
-      if (nq) M2S_HIP_CHECK(hipMemcpyAsync(queries_out, d_q, nq * 12, hipMemcpyDeviceToHost, c.stream));
+      if (nd) { rc = staged_d2h(st, c.stream, reinterpret_cast<char*>(distances_out), reinterpret_cast<const char*>(d_d), nd * 4); if (rc) return rc; }
+      if (nq) { rc = staged_d2h(st, c.stream, reinterpret_cast<char*>(queries_out), reinterpret_cast<const char*>(d_q), nq * 12); if (rc) return rc; }
     }
     M2S_HIP_CHECK(hipStreamSynchronize(c.stream));
     if (st.h_err[0] == 0) return M2S_OK;
@@ -250,28 +261,27 @@ int decode_impl(const CallCtx& c, DeviceState& st, const uint8_t* bytes, size_t 
   return M2S_OK;
 }
 
-int write_file(const char* path, const uint8_t* data, size_t n) {
-  FILE* f = fopen(path, "wb");
-  if (!f) return fail(M2S_ERR_IO, "IoError: cannot open %s for writing", path);
-  const size_t w = n ? fwrite(data, 1, n, f) : 0;
-  const int c = fclose(f);
-  if (w != n || c != 0) return fail(M2S_ERR_IO, "IoError: short write to %s", path);
-  return M2S_OK;
-}
-
-int read_file(const char* path, std::vector<uint8_t>* out) {
-  FILE* f = fopen(path, "rb");
-  if (!f) return fail(M2S_ERR_IO, "IoError: cannot open %s", path);
-  fseek(f, 0, SEEK_END);
-  const long sz = ftell(f);
-  fseek(f, 0, SEEK_SET);
-  if (sz < 0) { fclose(f); return fail(M2S_ERR_IO, "IoError: cannot size %s", path); }
-  out->resize((size_t)sz);
-  const size_t r = sz ? fread(out->data(), 1, (size_t)sz, f) : 0;
-  fclose(f);
-  if (r != (size_t)sz) return fail(M2S_ERR_IO, "IoError: short read from %s", path);
-  return M2S_OK;
-}
+// Read-only mapping of a container file: the probe touches two pages, the decode streams the mapping through
+// the pinned ring (host threads fault the page cache in while earlier chunks cross PCIe) — no copy of the file.
+struct MappedFile {
+  const uint8_t* p = nullptr;
+  size_t n = 0;
+  int open_path(const char* path) {
+    const int fd = ::open(path, O_RDONLY);
+    if (fd < 0) return fail(M2S_ERR_IO, "IoError: cannot open %s", path);
+    struct stat sb;
+    if (fstat(fd, &sb) != 0 || !S_ISREG(sb.st_mode)) { ::close(fd); return fail(M2S_ERR_IO, "IoError: cannot stat %s", path); }
+    n = (size_t)sb.st_size;
+    if (n) {
+      void* m = mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
+      if (m == MAP_FAILED) { ::close(fd); n = 0; return fail(M2S_ERR_IO, "IoError: cannot map %s", path); }
+      p = static_cast<const uint8_t*>(m);
+    }
+    ::close(fd);
+    return M2S_OK;
+  }
+  ~MappedFile() { if (p) munmap(const_cast<uint8_t*>(p), n); }
+};
 
 int save_impl(const char* path, const Layout& L, const float* queries, uint64_t nq, const float* distances, uint64_t nd,
               const m2s_opts* opts) {
@@ -279,11 +289,14 @@ int save_impl(const char* path, const Layout& L, const float* queries, uint64_t 
   DeviceState* st = nullptr;
   int rc = resolve_ctx(opts, &c, &st);
   if (rc) return rc;
-  uint8_t* host = nullptr;
-  M2S_HIP_CHECK(hipHostMalloc((void**)&host, L.total + 64, hipHostMallocDefault));   // pinned: D2H at link speed
-  rc = encode_impl(c, *st, L, queries, nq, distances, nd, host, M2S_MEM_HOST, true);
-  if (rc == M2S_OK) rc = write_file(path, host, L.total);
-  (void)hipHostFree(host);
+  uint8_t* d_enc = nullptr;   // encoded on the device, then streamed to the file through the pinned ring
+  rc = encode_impl(c, *st, L, queries, nq, distances, nd, nullptr, M2S_MEM_HOST, false, &d_enc);
+  if (rc) return rc;
+  FILE* f = fopen(path, "wb");
+  if (!f) return fail(M2S_ERR_IO, "IoError: cannot open %s for writing", path);
+  rc = staged_d2h_to_file(*st, c.stream, f, reinterpret_cast<const char*>(d_enc), L.total);
+  const int cl = fclose(f);
+  if (rc == M2S_ERR_IO || (rc == 0 && cl != 0)) return fail(M2S_ERR_IO, "IoError: short write to %s", path);
   return rc;
 }
 
@@ -319,7 +332,7 @@ int m2s_sdf_encode_grid(const m2s_grid* grid, const float* distances, size_t n_d
   DeviceState* st = nullptr;
   int rc = resolve_ctx(opts, &c, &st);
   if (rc) return rc;
-  rc = encode_impl(c, *st, L, nullptr, 0, distances, n_distances, bytes, c.mem_kind, c.sync);
+  rc = encode_impl(c, *st, L, nullptr, 0, distances, n_distances, bytes, c.mem_kind, c.sync, nullptr);
   if (rc == M2S_OK && written) *written = L.total;
   return rc;
 }
@@ -337,7 +350,7 @@ int m2s_sdf_encode_generic(const float* queries, size_t n_queries, const float* 
   DeviceState* st = nullptr;
   int rc = resolve_ctx(opts, &c, &st);
   if (rc) return rc;
-  rc = encode_impl(c, *st, L, queries, n_queries, distances, n_distances, bytes, c.mem_kind, c.sync);
+  rc = encode_impl(c, *st, L, queries, n_queries, distances, n_distances, bytes, c.mem_kind, c.sync, nullptr);
   if (rc == M2S_OK && written) *written = L.total;
   return rc;
 }
@@ -392,24 +405,27 @@ int m2s_sdf_probe_file(const char* path, m2s_sdf_info* info) {
   std::lock_guard<std::mutex> lk(g_mu);
   clear_error();
   if (!path || !info) return fail(M2S_ERR_BAD_ARG, "path / info is NULL");
-  std::vector<uint8_t> data, unused;
-  int rc = read_file(path, &data);
+  MappedFile file;
+  int rc = file.open_path(path);
   if (rc) return rc;
-  return probe_impl(data.data(), data.size(), M2S_MEM_HOST, nullptr, info, &unused);
+  static const uint8_t kEmpty = 0;
+  std::vector<uint8_t> unused;
+  return probe_impl(file.n ? file.p : &kEmpty, file.n, M2S_MEM_HOST, nullptr, info, &unused);
 }
 
 int m2s_sdf_read_file(const char* path, float* queries_out, float* distances_out, const m2s_opts* opts) {
   std::lock_guard<std::mutex> lk(g_mu);
   clear_error();
   if (!path) return fail(M2S_ERR_BAD_ARG, "path is NULL");
-  std::vector<uint8_t> data;
-  int rc = read_file(path, &data);
+  MappedFile file;
+  int rc = file.open_path(path);
   if (rc) return rc;
+  static const uint8_t kEmpty = 0;
   CallCtx c;
   DeviceState* st = nullptr;
   rc = resolve_ctx(opts, &c, &st);
   if (rc) return rc;
-  return decode_impl(c, *st, data.data(), data.size(), M2S_MEM_HOST, queries_out, distances_out);
+  return decode_impl(c, *st, file.n ? file.p : &kEmpty, file.n, M2S_MEM_HOST, queries_out, distances_out);
 }
 
 int m2s_order_cells_by_distance(const float* distances, size_t n, uint32_t* ordered_indices, float* iso_limits,

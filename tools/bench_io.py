@@ -66,3 +66,24 @@ m = np.eye(4, dtype=np.float32).reshape(-1)
 inst = [(v, i, m)] * 64
 ms = timed(lambda: merge_instances(inst), a.reps)
 line("merge_instances (64 x 1M vertices, 3M indices) + bbox", ms, 64 * (nv * 24 + 3 * nv * 8), {"cells": 64 * nv})
+# host-side flavours: numpy in -> bytes out / file out (PCIe + page cache inclusive)
+import tempfile, time
+from mesh_to_sdf_amd.serde import read_from_file, save_to_file
+dh = d.cpu().numpy()
+for label, fn in (("serialize numpy -> bytes", lambda: serialize(SerializeGrid(grid, dh))),):
+    ts = []
+    for _ in range(3):
+        t0 = time.perf_counter(); r = fn(); ts.append((time.perf_counter() - t0) * 1e3); del r
+    print(json.dumps({"op": label, "cells": n, "ms_first": round(ts[0], 1), "ms": round(min(ts[1:]), 1)}), flush=True)
+with tempfile.TemporaryDirectory() as td:
+    path = os.path.join(td, "sdf.bin")
+    for label, src in (("save_to_file from device tensor", d), ("save_to_file from numpy", dh)):
+        ts = []
+        for _ in range(3):
+            t0 = time.perf_counter(); save_to_file(SerializeGrid(grid, src), path); ts.append((time.perf_counter() - t0) * 1e3)
+        print(json.dumps({"op": label, "cells": n, "file_MB": round(os.path.getsize(path) / 1e6, 1), "ms_first": round(ts[0], 1), "ms": round(min(ts[1:]), 1)}), flush=True)
+    ts = []
+    for _ in range(3):
+        t0 = time.perf_counter(); de = read_from_file(path); ts.append((time.perf_counter() - t0) * 1e3)
+    print(json.dumps({"op": "read_from_file -> numpy", "cells": n, "ms_first": round(ts[0], 1), "ms": round(min(ts[1:]), 1)}), flush=True)
+    assert np.array_equal(de.distances.view(np.uint32), dh.view(np.uint32))
