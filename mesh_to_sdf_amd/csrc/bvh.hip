@@ -125,11 +125,23 @@ __global__ __launch_bounds__(256) void k_scene_reduce(int* __restrict__ scene, u
     if ((threadIdx.x & 63) == 0) { part[k][wv] = l; part[3 + k][wv] = h; }
   }
   __syncthreads();
+  __shared__ int fin[6];
   if (threadIdx.x < 6) {
     const int k = threadIdx.x;
     int v = part[k][0];
     for (int w = 1; w < 4; ++w) v = k < 3 ? min(v, part[k][w]) : max(v, part[k][w]);
     scene[k] = v;
+    fin[k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {   // scene[6]: largest finite |coordinate| as float bits (mesh_scale); the partials are dead now
+    float s = 0.0f;
+    for (int k = 0; k < 6; ++k) {
+      const int i = fin[k];
+      const float f = __int_as_float(i >= 0 ? i : i ^ 0x7fffffff);
+      if (f == f && fabsf(f) < 3.0e38f) s = fmaxf(s, fabsf(f));
+    }
+    scene[6] = __float_as_int(s);
   }
 }
 
@@ -356,6 +368,15 @@ __device__ __forceinline__ float wave_max(float v) {
 // Pass 2: extent along it and lateral radius about the AABB centre.  All roundings go outwards.
 constexpr uint32_t EXT_THREAD_BELOW = 16;   // subtrees up to this many triangles: one THREAD per node
 
+// Slab [lo, hi] along n in the (mid, half) form the walk tests with one op less: max(|t - mid| - half, 0).
+// half is rounded up over both one-sided widths, so the stored slab contains [lo, hi].
+__device__ __forceinline__ void set_slab(NodeExt& x, float lo, float hi) {
+  const float mid = 0.5f * lo + 0.5f * hi;
+  const float w = fmaxf(hi - mid, mid - lo);
+  x.mid = mid;
+  x.half = w + fabsf(w) * 2.4e-7f;   // >= the exact widths: each subtraction above is off by <= 1/2 ulp(w)
+}
+
 // Serial version of the same computation for small subtrees (most nodes: half of them are leaves).
 __global__ __launch_bounds__(256) void k_node_ext_small(const NodeRec* __restrict__ nodes,
                                                         const uint32_t* __restrict__ slot_first,
@@ -399,8 +420,8 @@ __global__ __launch_bounds__(256) void k_node_ext_small(const NodeRec* __restric
   const float e = 1.0e-5f * (fabsf(dlo) + fabsf(dhi)) + 2.0e-6f * sqrtf(w2max) + 1.0e-30f;
   NodeExt x;
   x.cx = cx; x.cy = cy; x.cz = cz; x.R = R;
-  x.nx = nx; x.ny = ny; x.nz = nz; x.dlo = dlo - e;
-  x.dhi = dhi + e; x.skip = nr.skip; x.tri = nr.tri; x.pad = 0;
+  x.nx = nx; x.ny = ny; x.nz = nz; set_slab(x, dlo - e, dhi + e);
+  x.skip = nr.skip; x.tri = nr.tri; x.pad = 0;
   ext[slot] = x;
 }
 
@@ -425,8 +446,8 @@ __global__ __launch_bounds__(256) void k_node_ext(const NodeRec* __restrict__ no
       const float e = 1.0e-5f * (fabsf(hx) + fabsf(hy) + fabsf(hz)) + 1.0e-30f;
       NodeExt x;
       x.cx = cx; x.cy = cy; x.cz = cz; x.R = sqrtf(hy * hy + hz * hz) * 1.00001f + e;
-      x.nx = 1.0f; x.ny = 0.0f; x.nz = 0.0f; x.dlo = -hx - e;
-      x.dhi = hx + e; x.skip = nr.skip; x.tri = nr.tri; x.pad = 0;
+      x.nx = 1.0f; x.ny = 0.0f; x.nz = 0.0f; set_slab(x, -hx - e, hx + e);
+      x.skip = nr.skip; x.tri = nr.tri; x.pad = 0;
       ext[slot] = x;
     }
     return;
@@ -463,8 +484,8 @@ __global__ __launch_bounds__(256) void k_node_ext(const NodeRec* __restrict__ no
     const float e = 1.0e-5f * (fabsf(dlo) + fabsf(dhi)) + 2.0e-6f * sqrtf(w2max) + 1.0e-30f;
     NodeExt x;
     x.cx = cx; x.cy = cy; x.cz = cz; x.R = R;
-    x.nx = nx; x.ny = ny; x.nz = nz; x.dlo = dlo - e;
-    x.dhi = dhi + e; x.skip = nr.skip; x.tri = nr.tri; x.pad = 0;
+    x.nx = nx; x.ny = ny; x.nz = nz; set_slab(x, dlo - e, dhi + e);
+    x.skip = nr.skip; x.tri = nr.tri; x.pad = 0;
     ext[slot] = x;
   }
 }

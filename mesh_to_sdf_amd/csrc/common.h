@@ -44,6 +44,7 @@ static_assert(sizeof(NodeRec) == 32, "NodeRec must be 32 bytes");
 // For a smooth surface patch the slab is thin, which is what an AABB cannot express: a query at
 // distance D from a flat patch meets ~rho*pi*2*s*D leaf AABBs of thickness s but only the O(1)
 // discs that cover its foot point.  lower bound^2 = max(dlo - t, t - dhi, 0)^2 + max(l - R, 0)^2
+// (stored as mid = (dlo+dhi)/2, half = (dhi-dlo)/2 rounded up: the slab term is max(|t - mid| - half, 0))
 // with t = n.(p - c), l^2 = |p - c|^2 - t^2.
 // The record also repeats the node's `skip` and `tri`, so the nearest-triangle traversal reads
 // ONLY this array (one 48-byte scalar load per node); NodeRec boxes serve the ray stabbing.
@@ -51,8 +52,8 @@ static_assert(sizeof(NodeRec) == 32, "NodeRec must be 32 bytes");
 // (n = +x): at that size a surface patch is not flat and the loop over its triangles is not worth it.
 struct alignas(16) NodeExt {
   float cx, cy, cz, R;
-  float nx, ny, nz, dlo;
-  float dhi;
+  float nx, ny, nz, mid;   // slab along n: |n.(p-c) - mid| <= half
+  float half;
   uint32_t skip;
   int32_t tri;
   uint32_t pad;
@@ -86,17 +87,9 @@ struct DeviceMesh {
   const int* scene;     // 6 order-encoded ints: min xyz / max xyz of the triangle box centres (see bvh.hip)
 };
 
-// Largest |coordinate| of the mesh (from the order-encoded centre bounds); feeds the pruning slack.
-__device__ __forceinline__ float mesh_scale(const DeviceMesh& m) {
-  float s = 0.0f;
-  for (int k = 0; k < 6; ++k) {
-    int i = m.scene[k];
-    int b = i >= 0 ? i : i ^ 0x7fffffff;
-    float f = __int_as_float(b);
-    if (f == f && fabsf(f) < 3.0e38f) s = fmaxf(s, fabsf(f));
-  }
-  return s;
-}
+// Largest finite |coordinate| of the mesh's triangle-box centres; feeds the pruning slack.  k_scene_reduce
+// (bvh.hip) leaves it as float bits in scene[6], so a walk pays one wave-uniform load for it.
+__device__ __forceinline__ float mesh_scale(const DeviceMesh& m) { return __int_as_float(m.scene[6]); }
 
 struct GridParams {
   float first[3];

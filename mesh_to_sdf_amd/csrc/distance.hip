@@ -156,7 +156,7 @@ __device__ __forceinline__ float ext_dist2(f3 p, const NodeExt& e) {
   const float l2 = __builtin_fmaf(-1.0e-6f, v2, __builtin_fmaf(-t, t, v2));
   // l2 < 0 (rounding) gives sqrt = NaN and fmaxf(NaN - R, 0) = 0: still a valid lower bound
   const float lat = fmaxf(__builtin_amdgcn_sqrtf(l2) - e.R, 0.0f);
-  const float s = fmaxf(fmaxf(e.dlo - t, t - e.dhi), 0.0f);
+  const float s = fmaxf(fabsf(t - e.mid) - e.half, 0.0f);
   return __builtin_fmaf(s, s, lat * lat);
 }
 
