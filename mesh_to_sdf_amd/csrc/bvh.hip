@@ -12,6 +12,7 @@
 //   k_karras      : Karras 2012 hierarchy over the sorted keys (ranges, children, parents)
 //   k_seg_level   : segment tree of leaf boxes, one launch per level (fence-free refit)
 //   k_emit        : node boxes by range query, pre-order index = 2*first + #left-turns, skip links
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 
@@ -554,7 +555,7 @@ int build_device_mesh(Arena& ws, hipStream_t st, const float* d_verts, size_t n_
   }
 
   const unsigned B = 256;
-  static const uint32_t leaf_max = getenv("M2S_LEAF_MAX") ? (uint32_t)atoi(getenv("M2S_LEAF_MAX")) : 2u;
+  static const uint32_t leaf_max = getenv("M2S_LEAF_MAX") ? std::max(1u, (uint32_t)atoi(getenv("M2S_LEAF_MAX"))) : 2u;
   hipLaunchKernelGGL(k_init_scene, dim3(cdiv(2 * n_tris, B)), dim3(B), 0, st, scene, parent, 2 * n - 1);
   hipLaunchKernelGGL(k_tri_setup, dim3(cdiv(n_tris, B)), dim3(B), 0, st, d_verts, (uint32_t)n_verts, d_indices,
                      index_bytes, topology, (uint32_t)n_tris, raw, boxes, scene, d_err);

@@ -15,6 +15,7 @@
 // Pruning is conservative: a subtree is dropped only if its box is farther than the lane's
 // current best by a margin that covers f32 rounding of both the box test and the reference
 // arithmetic (see prune_bound), so the minimum is the brute-force minimum bit for bit.
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 
@@ -572,7 +573,7 @@ void launch_packet(hipStream_t st, const DeviceMesh& mesh, const GridParams& g, 
                    uint32_t n_q, const uint32_t* plane, float* out, int* err, uint32_t n_packets,
                    const uint32_t* seed_in = nullptr, uint32_t seed_shift = 0, uint32_t seed_ny = 0,
                    uint32_t seed_nz = 0, const GridParams* seed_lattice = nullptr) {
-  static const uint32_t wpb = getenv("M2S_WPB") ? (uint32_t)atoi(getenv("M2S_WPB")) : 1u;   // waves (packets) per workgroup: single-wave groups free their slot as soon as the walk ends (4 -> 1: -3.8 %)
+  static const uint32_t wpb = getenv("M2S_WPB") ? std::min(4u, std::max(1u, (uint32_t)atoi(getenv("M2S_WPB")))) : 1u;   // waves (packets) per workgroup: single-wave groups free their slot as soon as the walk ends (4 -> 1: -3.8 %)
   const uint32_t blocks = (n_packets + wpb - 1) / wpb;
   static const bool remap = !(getenv("M2S_XCD_REMAP") && atoi(getenv("M2S_XCD_REMAP")) == 0);
   const uint32_t chunk = remap ? (blocks + 7) / 8 : 0;

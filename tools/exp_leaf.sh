@@ -1,1 +1,1 @@
-for L in 1 2 4 8 16; do echo "leaf_max=$L"; M2S_LEAF_MAX=$L python bench.py --steps 6 --warmup 2 --no-cpu-baseline | python -c "import sys,json; d=json.loads(sys.stdin.readline()); print(d['value'], d['ms_per_step'], d['phases_ms'])"; M2S_LEAF_MAX=$L M2S_STATS=1 python tools/exp_grid.py --reps 1 2>&1 | grep stats; M2S_LEAF_MAX=$L python tools/exp_configs.py c3 2>&1 | grep queries; done
+for L in 1 2 4 8 16; do echo "leaf_max=$L"; M2S_LEAF_MAX=$L python tools/exp_configs.py c4 2>&1 | grep -E "slab=None"; done
