@@ -255,7 +255,8 @@ __global__ __launch_bounds__(256) void k_packet(DeviceMesh mesh, GridParams g, c
         }
         sidx = __builtin_amdgcn_readfirstlane((cell[0] * L.n[1] + cell[1]) * L.n[2] + cell[2]);
       }
-      const uint32_t slot = min(seed_in[sidx], mesh.n_tris - 1);
+      // one seed per packet: wave-uniform, so the 96-byte record comes through scalar loads
+      const uint32_t slot = __builtin_amdgcn_readfirstlane(min(seed_in[sidx], mesh.n_tris - 1));
       const TriRec tr = mesh.tris[slot];
       eval_triangle<MODE>(best, p, tr);
     } else {
