@@ -15,7 +15,7 @@ scaling alive once the kernel is fast.  The mesh (LBVH + sign planes) is built o
 """
 from typing import Callable, List, Optional, Tuple
 
-from .api import Grid, Mesh, SignMethod, Topology, generate_grid_sdf
+from .api import AccelerationMethod, Grid, Mesh, SignMethod, Topology, generate_grid_sdf, generate_sdf
 
 
 import os
@@ -131,3 +131,45 @@ def generate_grid_sdf_sharded(vertices, indices: Topology, grid: Grid, sign_meth
                 torch.cuda.current_stream(out.device).synchronize()
             own_mesh.close()
     return (out, mesh) if return_mesh else out
+
+
+def query_bounds(n_queries: int, world: int, rank: int) -> Tuple[int, int]:
+    """Contiguous query range of rank `rank`; every rank gets ceil(n / world) queries except the tail ranks."""
+    per = -(-n_queries // world) if world else n_queries
+    q0 = min(rank * per, n_queries)
+    return q0, min(q0 + per, n_queries)
+
+
+def generate_sdf_sharded(vertices, indices: Topology, query_points, acceleration_method: AccelerationMethod = None, *,
+                         group=None, out=None, compute_range: Optional[Callable] = None):
+    """generate_sdf over all ranks of `group`: the query array is cut into `world` contiguous ranges (queries are
+    independent given the replicated mesh), every rank computes its range and the results are
+    all-gathered in place; returns all distances on every rank.  `query_points` is the FULL array on every rank.
+
+    compute_range(out, q0, q1) may replace the computation (CPU tests inject the oracle)."""
+    import torch
+    import torch.distributed as dist
+
+    inited = dist.is_available() and dist.is_initialized()
+    world = dist.get_world_size(group) if inited else 1
+    rank = dist.get_rank(group) if inited else 0
+    nq = int(query_points.shape[0])
+    per = -(-nq // world) if nq else 0
+    if out is None:
+        dev = query_points.device if hasattr(query_points, "device") else "cpu"
+        out = torch.empty(nq, dtype=torch.float32, device=dev)
+    q0, q1 = query_bounds(nq, world, rank)
+    padded = out
+    if world > 1 and per * world != nq:
+        padded = torch.empty(per * world, dtype=torch.float32, device=out.device)   # equal pieces for the in-place gather
+    if q1 > q0:
+        if compute_range is not None:
+            compute_range(padded, q0, q1)
+        else:
+            padded[q0:q1] = generate_sdf(vertices, indices, query_points[q0:q1], acceleration_method)
+    if world > 1 or (_FORCE_COLLECTIVES and inited):
+        if per:
+            dist.all_gather_into_tensor(padded[: per * world], padded[rank * per : (rank + 1) * per], group=group)
+    if padded is not out:
+        out.copy_(padded[:nq])
+    return out

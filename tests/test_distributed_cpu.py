@@ -94,3 +94,54 @@ def test_sharded_grid_gloo(world, nx, chunks):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert all(ok for _, ok in res), res
+
+
+def test_query_bounds_cover_all_queries():
+    from mesh_to_sdf_amd.distributed import query_bounds
+
+    for nq in (0, 1, 7, 64, 1000, 10_000_001):
+        for world in (1, 2, 3, 8):
+            prev = 0
+            for r in range(world):
+                q0, q1 = query_bounds(nq, world, r)
+                assert q0 == prev and q1 >= q0
+                prev = q1
+            assert prev == nq
+
+
+def _query_worker(rank, world, port, nq, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from mesh_to_sdf_amd import AccelerationMethod
+        from mesh_to_sdf_amd.distributed import generate_sdf_sharded
+
+        v, idx = meshes.blob(24, 13)
+        lo, hi = meshes.extended_bbox(v, 0.1)
+        pts = meshes.uniform_queries(lo, hi, nq)
+        whole = orc.generate_sdf(v, idx, pts, accel=3, fast=True) if nq else np.zeros(0, np.float32)
+
+        def compute_range(out, q0, q1):   # writes ONLY this rank's queries, like the HIP call on the sub-array
+            out[q0:q1] = torch.from_numpy(whole[q0:q1].copy())
+
+        out = generate_sdf_sharded(torch.from_numpy(v), Topology.TriangleList(idx), torch.from_numpy(pts), AccelerationMethod.RtreeBvh,
+                                   compute_range=compute_range)
+        q.put((rank, bool(np.array_equal(out.numpy().view(np.uint32), whole.view(np.uint32)))))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,nq", [(2, 1000), (2, 1001), (3, 10), (3, 2), (2, 0)])
+def test_sharded_queries_gloo(world, nq):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_query_worker, args=(r, world, port, nq, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in res), res

@@ -376,6 +376,13 @@ def test_sharded_driver_single_process(suzanne):
     dv, di = torch.as_tensor(v, device="cuda"), torch.as_tensor(idx.astype(np.int64), device="cuda")
     out = generate_grid_sdf_sharded(dv, Topology.TriangleList(di), g, SignMethod.Raycast, chunks=4)
     assert_bit_equal(out.cpu().numpy(), generate_grid_sdf(v, Topology.TriangleList(idx), g), "sharded driver")
+    # the query driver (split the query array, all-gather), world size 1
+    from mesh_to_sdf_amd.distributed import generate_sdf_sharded
+
+    lo, hi = meshes.extended_bbox(v, 0.2)
+    q = meshes.uniform_queries(lo, hi, 4099)
+    got = generate_sdf_sharded(dv, Topology.TriangleList(di), torch.as_tensor(q, device="cuda"), AccelerationMethod.RtreeBvh)
+    assert_bit_equal(got.cpu().numpy(), orc.generate_sdf(v, idx, q, accel=3, fast=True), "sharded queries")
 
 
 # ---- nastier inputs ---------------------------------------------------------------------------------
@@ -447,7 +454,12 @@ def _two_rank_worker(rank, world, port, q):
         g = grid_of(v, [48, 20, 28])
         dv, di = torch.as_tensor(v, device="cuda:0"), torch.as_tensor(idx.astype(np.int64), device="cuda:0")
         out = generate_grid_sdf_sharded(dv, Topology.TriangleList(di), g, SignMethod.Raycast, chunks=3)
-        q.put((rank, out.cpu().numpy()))
+        from mesh_to_sdf_amd.distributed import generate_sdf_sharded
+
+        lo, hi = meshes.extended_bbox(v, 0.2)
+        pts = torch.as_tensor(meshes.uniform_queries(lo, hi, 3001), device="cuda:0")   # uneven split: padded gather
+        dq = generate_sdf_sharded(dv, Topology.TriangleList(di), pts, AccelerationMethod.RtreeBvh)
+        q.put((rank, (out.cpu().numpy(), dq.cpu().numpy())))
     finally:
         dist.destroy_process_group()
 
@@ -476,8 +488,11 @@ def test_two_ranks_share_one_gpu_gloo():
     v, idx = meshes.blob(40, 21)
     g = grid_of(v, [48, 20, 28])
     want = oracle_grid(v, idx, g, SignMethod.Raycast)
+    lo, hi = meshes.extended_bbox(v, 0.2)
+    want_q = orc.generate_sdf(v, idx, meshes.uniform_queries(lo, hi, 3001), accel=3, fast=True)
     for r in range(2):
-        assert_bit_equal(res[r], want, f"rank {r}")
+        assert_bit_equal(res[r][0], want, f"rank {r}")
+        assert_bit_equal(res[r][1], want_q, f"rank {r} queries")
 
 
 def test_generic_10M_queries_subsample():
