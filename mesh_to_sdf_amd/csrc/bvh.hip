@@ -76,9 +76,11 @@ __global__ __launch_bounds__(256) void k_tri_setup(const float* __restrict__ ver
     r.ax = a.x; r.ay = a.y; r.az = a.z; r.cls = tri_class(a, b, c);
     r.bx = b.x; r.by = b.y; r.bz = b.z; r.index = t;
     r.cx = c.x; r.cy = c.y; r.cz = c.z; r.pad0 = 0.0f;
-    r.abx = b.x - a.x; r.aby = b.y - a.y; r.abz = b.z - a.z; r.pad1 = 0.0f;
-    r.acx = c.x - a.x; r.acy = c.y - a.y; r.acz = c.z - a.z; r.pad2 = 0.0f;
-    r.bcx = c.x - b.x; r.bcy = c.y - b.y; r.bcz = c.z - b.z; r.pad3 = 0.0f;
+    r.abx = b.x - a.x; r.aby = b.y - a.y; r.abz = b.z - a.z;
+    r.acx = c.x - a.x; r.acy = c.y - a.y; r.acz = c.z - a.z;
+    r.bcx = c.x - b.x; r.bcy = c.y - b.y; r.bcz = c.z - b.z;
+    const f3 nr = cross3(mk3(r.abx, r.aby, r.abz), mk3(r.acx, r.acy, r.acz));   // triangle_normal, not normalised
+    r.nrx = nr.x; r.nry = nr.y; r.nrz = nr.z;
     const float sx = 0.5f * (mn.x + mx.x), sy = 0.5f * (mn.y + mx.y), sz = 0.5f * (mn.z + mx.z);
     raw[t] = r;
     boxes[t] = {mn.x, mn.y, mn.z, mx.x, mx.y, mx.z};

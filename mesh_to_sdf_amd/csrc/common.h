@@ -20,9 +20,10 @@ struct alignas(32) TriRec {
   float pad0;
   // edge vectors exactly as geo.rs computes them per call (b.sub(a), c.sub(a), c.sub(b)): they are
   // the same for all 64 lanes, so they are formed once at build time instead of on the VALU
-  float abx, aby, abz, pad1;
-  float acx, acy, acz, pad2;
-  float bcx, bcy, bcz, pad3;
+  // the 4th components carry the raw normal ab x ac (geo.rs:60-64), same arithmetic as the reference, formed once
+  float abx, aby, abz, nrx;
+  float acx, acy, acz, nry;
+  float bcx, bcy, bcz, nrz;
 };
 static_assert(sizeof(TriRec) == 96, "TriRec must be 96 bytes");
 

@@ -110,7 +110,7 @@ __device__ __forceinline__ void eval_triangle(Best<MODE>& best, f3 p, const TriR
     best.d2 = fminf(best.d2, d2);  // f32::min drops a NaN operand (default.rs:47)
   } else {
     bool positive;
-    const float d2 = point_triangle_dist2_signed(p, a, b, c, e, cls, &positive);
+    const float d2 = point_triangle_dist2_signed_n(p, a, b, c, e, cls, mk3(tr.nrx, tr.nry, tr.nrz), &positive);
     if (MODE == MODE_NORMAL_FOLD) {
       best.nan |= !(d2 == d2);  // the reference panics: "NaN distance" (lib.rs:257)
       best.d2 = fminf(best.d2, d2);

@@ -137,6 +137,13 @@ M2S_HD float point_triangle_dist2_signed(f3 p, f3 a, f3 b, f3 c, const TriEdges&
   *positive = dot3(d, nrm) > 0.0f;
   return dot3(d, d);
 }
+// Same with the normal cross3(e.ab, e.ac) supplied by the caller (precomputed per triangle, bit-identical).
+M2S_HD float point_triangle_dist2_signed_n(f3 p, f3 a, f3 b, f3 c, const TriEdges& e, uint32_t cls, f3 nrm, bool* positive) {
+  const f3 n = closest_point_triangle(p, a, b, c, e, cls);
+  const f3 d = sub3(p, n);
+  *positive = dot3(d, nrm) > 0.0f;
+  return dot3(d, d);
+}
 
 // geo.rs:165-216 — axis-aligned ray/triangle.  AXIS 0: ray +X, plane (y,z); 1: +Y, (z,x); 2: +Z, (x,y).
 template <int AXIS>
