@@ -424,7 +424,7 @@ __global__ __launch_bounds__(256) void k_node_ext_small(const NodeRec* __restric
   NodeExt x;
   x.cx = cx; x.cy = cy; x.cz = cz; x.R = R;
   x.nx = nx; x.ny = ny; x.nz = nz; set_slab(x, dlo - e, dhi + e);
-  x.skip = nr.skip; x.tri = nr.tri; x.pad = 0;
+  x.skip = nr.skip * (uint32_t)sizeof(NodeExt); x.tri = nr.tri; x.pad = 0;   // BYTE offset of the skip target
   ext[slot] = x;
 }
 
@@ -450,7 +450,7 @@ __global__ __launch_bounds__(256) void k_node_ext(const NodeRec* __restrict__ no
       NodeExt x;
       x.cx = cx; x.cy = cy; x.cz = cz; x.R = sqrtf(hy * hy + hz * hz) * 1.00001f + e;
       x.nx = 1.0f; x.ny = 0.0f; x.nz = 0.0f; set_slab(x, -hx - e, hx + e);
-      x.skip = nr.skip; x.tri = nr.tri; x.pad = 0;
+      x.skip = nr.skip * (uint32_t)sizeof(NodeExt); x.tri = nr.tri; x.pad = 0;   // BYTE offset of the skip target
       ext[slot] = x;
     }
     return;
@@ -488,7 +488,7 @@ __global__ __launch_bounds__(256) void k_node_ext(const NodeRec* __restrict__ no
     NodeExt x;
     x.cx = cx; x.cy = cy; x.cz = cz; x.R = R;
     x.nx = nx; x.ny = ny; x.nz = nz; set_slab(x, dlo - e, dhi + e);
-    x.skip = nr.skip; x.tri = nr.tri; x.pad = 0;
+    x.skip = nr.skip * (uint32_t)sizeof(NodeExt); x.tri = nr.tri; x.pad = 0;   // BYTE offset of the skip target
     ext[slot] = x;
   }
 }

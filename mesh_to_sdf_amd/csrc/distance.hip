@@ -202,7 +202,7 @@ __device__ __forceinline__ uint32_t stab_count(const DeviceMesh& mesh, f3 p) {
 // ---- k_packet -------------------------------------------------------------------------------
 // `seed_in` (one TriRec slot per 2^seed_shift bricks per axis, may be null) replaces the greedy descent:
 // the packet starts from a triangle near its own centre (jump-flooding seed pass below).
-template <bool GRID, int MODE, int SIGN>
+template <bool GRID, int MODE, int SIGN, bool STATS>
 __global__ __launch_bounds__(256) void k_packet(DeviceMesh mesh, GridParams g, const float4* __restrict__ qsorted,
                                                 const uint32_t* __restrict__ perm, uint32_t n_q,
                                                 const uint32_t* __restrict__ plane, float* __restrict__ out,
@@ -281,37 +281,41 @@ __global__ __launch_bounds__(256) void k_packet(DeviceMesh mesh, GridParams g, c
 
     float thr = prune_bound(best.d2, slack);
     // M2S_STATS=2: a second, counting-only traversal that starts from the final bound ("perfect seed")
-    const int passes = (mesh.stats != nullptr && mesh.stats[7] == 2ull) ? 2 : 1;
+    const int passes = (STATS && mesh.stats != nullptr && mesh.stats[7] == 2ull) ? 2 : 1;
     for (int pass = 0; pass < passes; ++pass) {
     if (pass == 1) { st_box = 0; st_ext = 0; st_leaf = 0; }
-    uint32_t node = 0;
-    while (node < mesh.n_nodes) {
-      node = __builtin_amdgcn_readfirstlane(node);
-      const NodeExt nr = mesh.ext[node];
-      ++st_box;
+    // The walk addresses NodeExt by BYTE offset (its skip links are stored that way): the scalar loads then take
+    // the offset operand directly and the loop carries no address arithmetic.
+    constexpr uint32_t NB = (uint32_t)sizeof(NodeExt);
+    const uint32_t end = mesh.n_nodes * NB;
+    uint32_t off = 0;
+    while (off < end) {
+      off = __builtin_amdgcn_readfirstlane(off);
+      const NodeExt nr = *reinterpret_cast<const NodeExt*>(reinterpret_cast<const char*>(mesh.ext) + off);
+      if (STATS) ++st_box;
       const float ed2 = ext_dist2(p, nr);
-      if (__ballot(!(ed2 > thr)) == 0ull) { node = nr.skip; continue; }   // a NaN bound keeps the node
+      if (__ballot(!(ed2 > thr)) == 0ull) { off = nr.skip; continue; }   // a NaN bound keeps the node
       if (nr.tri >= 0) {
-        const uint32_t cnt = (nr.skip - node + 1u) >> 1;        // triangles of this (possibly collapsed) leaf
+        const uint32_t cnt = (nr.skip - off + NB) / (2u * NB);    // triangles of this (possibly collapsed) leaf
         for (uint32_t k = 0; k < cnt; ++k) {
-          ++st_ext;
+          if (STATS) ++st_ext;
           const TriPlanes tp = mesh.planes[nr.tri + k];
           const TriRec tr = mesh.tris[nr.tri + k];
           if (__ballot(!(planes_dist2(p, tp) > thr)) != 0ull) {   // some lane's bound reaches the triangle itself
-            ++st_leaf;
+            if (STATS) ++st_leaf;
             eval_triangle<MODE>(best, p, tr);
             thr = prune_bound(best.d2, slack);
           }
         }
-        node = nr.skip;
+        off = nr.skip;
       } else {
-        node = node + 1;
+        off = off + NB;
       }
     }
     }
   }
 
-  if (mesh.stats != nullptr && lane == 0) {
+  if (STATS && mesh.stats != nullptr && lane == 0) {
     atomicAdd(&mesh.stats[0], (unsigned long long)st_box);
     atomicAdd(&mesh.stats[1], (unsigned long long)st_ext);
     atomicAdd(&mesh.stats[2], (unsigned long long)st_leaf);
@@ -578,8 +582,12 @@ void launch_packet(hipStream_t st, const DeviceMesh& mesh, const GridParams& g, 
   const uint32_t blocks = (n_packets + wpb - 1) / wpb;
   static const bool remap = !(getenv("M2S_XCD_REMAP") && atoi(getenv("M2S_XCD_REMAP")) == 0);
   const uint32_t chunk = remap ? (blocks + 7) / 8 : 0;
-  hipLaunchKernelGGL((k_packet<GRID, MODE, SIGN>), dim3(remap ? chunk * 8 : blocks), dim3(64 * wpb), 0, st, mesh, g,
-                     qs, perm, n_q, plane, out, err, n_packets, chunk, seed_in, seed_shift, seed_ny, seed_nz, seed_lattice);
+  if (mesh.stats != nullptr)   // M2S_STATS: the counting variant (a few SALU ops more per node)
+    hipLaunchKernelGGL((k_packet<GRID, MODE, SIGN, true>), dim3(remap ? chunk * 8 : blocks), dim3(64 * wpb), 0, st, mesh, g,
+                       qs, perm, n_q, plane, out, err, n_packets, chunk, seed_in, seed_shift, seed_ny, seed_nz, seed_lattice);
+  else
+    hipLaunchKernelGGL((k_packet<GRID, MODE, SIGN, false>), dim3(remap ? chunk * 8 : blocks), dim3(64 * wpb), 0, st, mesh, g,
+                       qs, perm, n_q, plane, out, err, n_packets, chunk, seed_in, seed_shift, seed_ny, seed_nz, seed_lattice);
 }
 template <bool GRID, int MODE, int SIGN>
 void launch_brute(hipStream_t st, const DeviceMesh& mesh, const GridParams& g, const float* q, uint32_t n_q,
