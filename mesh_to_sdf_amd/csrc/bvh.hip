@@ -18,6 +18,7 @@
 
 #include <rocprim/rocprim.hpp>
 
+#include "../../include/m2s.h"
 #include "common.h"
 #include "geo.hip.h"
 
@@ -525,6 +526,10 @@ int build_device_mesh(Arena& ws, hipStream_t st, const float* d_verts, size_t n_
   out->ext = nullptr;
   out->stats = nullptr;
   out->scene = nullptr;
+  if (n_tris > (1u << 25)) {   // the walks address 96-byte records through 32-bit byte offsets
+    set_error("mesh has %zu triangles; this build handles up to 33 554 432", n_tris);
+    return M2S_ERR_BAD_ARG;
+  }
   out->n_tris = (uint32_t)n_tris;
   out->n_nodes = n_tris ? (uint32_t)(2 * n_tris - 1) : 0;
   if (n_tris == 0) return 0;

@@ -31,6 +31,14 @@ namespace {
 constexpr float F32_MAX_C = 3.402823466e+38f;
 constexpr int TILE = 128;  // triangles per LDS tile in k_brute (12 KiB)
 
+// Record `index` of a read-only array through a 32-bit BYTE offset: a wave-uniform offset then goes straight into
+// the scalar load's offset operand (no 64-bit address arithmetic in the walk loops).  Arrays stay below 4 GiB:
+// 96 B x n_tris with n_tris < 2^25 (checked by the build).
+template <class T>
+__device__ __forceinline__ T record_at(const T* base, uint32_t index) {
+  return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + index * (uint32_t)sizeof(T));
+}
+
 // ---- point sources -------------------------------------------------------------------------
 struct GridBrick {
   uint32_t x, y, z;
@@ -177,13 +185,13 @@ __device__ __forceinline__ uint32_t stab_count(const DeviceMesh& mesh, f3 p) {
   uint32_t node = 0;
   while (node < mesh.n_nodes) {
     node = __builtin_amdgcn_readfirstlane(node);
-    const NodeRec nr = mesh.nodes[node];
+    const NodeRec nr = record_at(mesh.nodes, node);
     const bool hit = ray_meets_box<AXIS>(p, mk3(nr.mnx, nr.mny, nr.mnz), mk3(nr.mxx, nr.mxy, nr.mxz));
     if (__ballot(hit) == 0ull) { node = nr.skip; continue; }
     if (nr.tri >= 0) {
       const uint32_t cnt = (nr.skip - node + 1u) >> 1;
       for (uint32_t k = 0; k < cnt; ++k) {
-        const TriRec tr = mesh.tris[nr.tri + k];
+        const TriRec tr = record_at(mesh.tris, (uint32_t)nr.tri + k);
         const f3 a = mk3(tr.ax, tr.ay, tr.az), b = mk3(tr.bx, tr.by, tr.bz), c = mk3(tr.cx, tr.cy, tr.cz);
         f3 mn, mx;
         triangle_bounding_box(a, b, c, &mn, &mx);     // the candidate rule is per triangle: ITS padded box
@@ -257,7 +265,7 @@ __global__ __launch_bounds__(256) void k_packet(DeviceMesh mesh, GridParams g, c
       }
       // one seed per packet: wave-uniform, so the 96-byte record comes through scalar loads
       const uint32_t slot = __builtin_amdgcn_readfirstlane(min(seed_in[sidx], mesh.n_tris - 1));
-      const TriRec tr = mesh.tris[slot];
+      const TriRec tr = record_at(mesh.tris, slot);
       eval_triangle<MODE>(best, p, tr);
     } else {
       // seed: greedy descent towards the packet's first point, evaluate that leaf for every lane
@@ -299,8 +307,8 @@ __global__ __launch_bounds__(256) void k_packet(DeviceMesh mesh, GridParams g, c
         const uint32_t cnt = (nr.skip - off + NB) / (2u * NB);    // triangles of this (possibly collapsed) leaf
         for (uint32_t k = 0; k < cnt; ++k) {
           if (STATS) ++st_ext;
-          const TriPlanes tp = mesh.planes[nr.tri + k];
-          const TriRec tr = mesh.tris[nr.tri + k];
+          const TriPlanes tp = record_at(mesh.planes, (uint32_t)nr.tri + k);
+          const TriRec tr = record_at(mesh.tris, (uint32_t)nr.tri + k);
           if (__ballot(!(planes_dist2(p, tp) > thr)) != 0ull) {   // some lane's bound reaches the triangle itself
             if (STATS) ++st_leaf;
             eval_triangle<MODE>(best, p, tr);
