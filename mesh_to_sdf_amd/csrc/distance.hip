@@ -39,6 +39,18 @@ __device__ __forceinline__ T record_at(const T* base, uint32_t index) {
   return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + index * (uint32_t)sizeof(T));
 }
 
+// Leaf records (TriPlanes 64 B + TriRec 96 B per triangle) are read through the VECTOR path although their
+// address is wave-uniform: a uniform-address vector load is a broadcast out of the 32 KB vector L1, lands in
+// VGPRs, waits on the in-order vmcnt — and keeps the 16 KB scalar cache for the node records of the walk
+// (measured: 16.5 vs 17.3 ms with the same records through scalar loads).  The index is laundered through a
+// VGPR so that the compiler does not turn the load back into a scalar one.
+template <class T>
+__device__ __forceinline__ T record_at_vec(const T* base, uint32_t uniform_index) {
+  uint32_t vi;
+  asm("v_mov_b32_e32 %0, %1" : "=v"(vi) : "s"(uniform_index));
+  return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + (size_t)vi * sizeof(T));
+}
+
 // ---- point sources -------------------------------------------------------------------------
 struct GridBrick {
   uint32_t x, y, z;
@@ -307,10 +319,10 @@ __global__ __launch_bounds__(256) void k_packet(DeviceMesh mesh, GridParams g, c
         const uint32_t cnt = (nr.skip - off + NB) / (2u * NB);    // triangles of this (possibly collapsed) leaf
         for (uint32_t k = 0; k < cnt; ++k) {
           if (STATS) ++st_ext;
-          const TriPlanes tp = record_at(mesh.planes, (uint32_t)nr.tri + k);
-          const TriRec tr = record_at(mesh.tris, (uint32_t)nr.tri + k);
+          const TriPlanes tp = record_at_vec(mesh.planes, (uint32_t)nr.tri + k);
           if (__ballot(!(planes_dist2(p, tp) > thr)) != 0ull) {   // some lane's bound reaches the triangle itself
             if (STATS) ++st_leaf;
+            const TriRec tr = record_at_vec(mesh.tris, (uint32_t)nr.tri + k);
             eval_triangle<MODE>(best, p, tr);
             thr = prune_bound(best.d2, slack);
           }
