@@ -203,7 +203,7 @@ __device__ __forceinline__ uint32_t stab_count(const DeviceMesh& mesh, f3 p) {
     if (nr.tri >= 0) {
       const uint32_t cnt = (nr.skip - node + 1u) >> 1;
       for (uint32_t k = 0; k < cnt; ++k) {
-        const TriRec tr = record_at(mesh.tris, (uint32_t)nr.tri + k);
+        const TriRec tr = record_at_vec(mesh.tris, (uint32_t)nr.tri + k);
         const f3 a = mk3(tr.ax, tr.ay, tr.az), b = mk3(tr.bx, tr.by, tr.bz), c = mk3(tr.cx, tr.cy, tr.cz);
         f3 mn, mx;
         triangle_bounding_box(a, b, c, &mn, &mx);     // the candidate rule is per triangle: ITS padded box
