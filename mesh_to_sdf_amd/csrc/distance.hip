@@ -408,7 +408,7 @@ __global__ __launch_bounds__(256) void k_jfa_pass(DeviceMesh mesh, GridParams g0
   if (i >= total) return;
   const int z = (int)(i % g.n[2]), y = (int)((i / g.n[2]) % g.n[1]), x = (int)(i / ((size_t)g.n[2] * g.n[1]));
   const f3 p = lattice_point(g, (uint32_t)x, (uint32_t)y, (uint32_t)z);
-  uint32_t best = 0xffffffffu;
+  uint32_t best = 0xffffffffu, prev = 0xffffffffu;
   float bd = __builtin_inff();
   for (int dx = -1; dx <= 1; ++dx) {
     const int xx = x + dx * step;
@@ -420,7 +420,8 @@ __global__ __launch_bounds__(256) void k_jfa_pass(DeviceMesh mesh, GridParams g0
         const int zz = z + dz * step;
         if (zz < 0 || zz >= (int)g.n[2]) continue;
         const uint32_t cand = in[((size_t)xx * g.n[1] + yy) * g.n[2] + zz];
-        if (cand == 0xffffffffu) continue;
+        if (cand == 0xffffffffu || cand == best || cand == prev) continue;   // neighbours mostly agree: skip the gather
+        prev = cand;
         const float4 c = mesh.cen[cand];
         const float ex = p.x - c.x, ey = p.y - c.y, ez = p.z - c.z;
         const float d = __builtin_fmaf(ex, ex, __builtin_fmaf(ey, ey, ez * ez));
