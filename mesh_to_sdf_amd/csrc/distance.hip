@@ -104,9 +104,16 @@ __device__ __forceinline__ uint32_t grid_brick_count(const GridParams& g) {
   return ((g.xe - g.xb + 3) >> 2) * ((g.n[1] + 3) >> 2) * ((g.n[2] + 3) >> 2);
 }
 
-// XCD-aware work order: the dispatcher places block b on XCD b % 8; give every XCD one contiguous
-// run of the brick sequence so that its private L2 keeps seeing the same part of the BVH.
+// XCD-aware work order: the dispatcher places block b on XCD b % 8.  Each XCD works through runs of consecutive
+// packets (its private L2 keeps seeing the same part of the BVH), and the runs are dealt out round-robin:
+// chunk has bit 31 set: interleaved mode — XCD x takes the runs x, x+8, x+16, ... of 2^run_log blocks (run_log in
+// the low bits): every XCD still works through whole super-bricks, but the static split no longer hands one XCD the
+// expensive eighth of the grid (matters most for the thin multi-GPU pieces, which have few runs).
 __device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t chunk) {
+  if (chunk & 0x80000000u) {
+    const uint32_t run_log = chunk & 31u, i = b >> 3, x = b & 7u;
+    return ((((i >> run_log) << 3) + x) << run_log) | (i & ((1u << run_log) - 1u));
+  }
   return chunk ? (b & 7u) * chunk + (b >> 3) : b;   // chunk == 0: plain order (M2S_XCD_REMAP=0)
 }
 
@@ -601,8 +608,24 @@ void launch_packet(hipStream_t st, const DeviceMesh& mesh, const GridParams& g, 
                    uint32_t seed_nz = 0, const GridParams* seed_lattice = nullptr) {
   static const uint32_t wpb = getenv("M2S_WPB") ? std::min(4u, std::max(1u, (uint32_t)atoi(getenv("M2S_WPB")))) : 1u;   // waves (packets) per workgroup: single-wave groups free their slot as soon as the walk ends (4 -> 1: -3.8 %)
   const uint32_t blocks = (n_packets + wpb - 1) / wpb;
-  static const bool remap = !(getenv("M2S_XCD_REMAP") && atoi(getenv("M2S_XCD_REMAP")) == 0);
-  const uint32_t chunk = remap ? (blocks + 7) / 8 : 0;
+  // 2 (default): XCD x takes runs x, x+8, ... of 2^run_log packets; 1: one contiguous eighth per XCD; 0: plain order
+  static const int remap_mode = getenv("M2S_XCD_REMAP") ? atoi(getenv("M2S_XCD_REMAP")) : 2;
+  static const uint32_t run_log = getenv("M2S_XCD_RUN_LOG") ? std::min(20u, (uint32_t)atoi(getenv("M2S_XCD_RUN_LOG"))) : 7u;
+  const bool remap = remap_mode != 0;
+  uint32_t chunk = remap ? (blocks + 7) / 8 : 0;
+  if (remap_mode == 2) {
+    const uint32_t per = 8u << run_log;
+    chunk = ((blocks + per - 1) / per) * (per / 8);          // blocks per XCD, a whole number of runs
+    const uint32_t grid_blocks = chunk * 8;
+    const uint32_t code = 0x80000000u | run_log;
+    if (mesh.stats != nullptr)
+      hipLaunchKernelGGL((k_packet<GRID, MODE, SIGN, true>), dim3(grid_blocks), dim3(64 * wpb), 0, st, mesh, g,
+                         qs, perm, n_q, plane, out, err, n_packets, code, seed_in, seed_shift, seed_ny, seed_nz, seed_lattice);
+    else
+      hipLaunchKernelGGL((k_packet<GRID, MODE, SIGN, false>), dim3(grid_blocks), dim3(64 * wpb), 0, st, mesh, g,
+                         qs, perm, n_q, plane, out, err, n_packets, code, seed_in, seed_shift, seed_ny, seed_nz, seed_lattice);
+    return;
+  }
   if (mesh.stats != nullptr)   // M2S_STATS: the counting variant (a few SALU ops more per node)
     hipLaunchKernelGGL((k_packet<GRID, MODE, SIGN, true>), dim3(remap ? chunk * 8 : blocks), dim3(64 * wpb), 0, st, mesh, g,
                        qs, perm, n_q, plane, out, err, n_packets, chunk, seed_in, seed_shift, seed_ny, seed_nz, seed_lattice);
