@@ -282,6 +282,7 @@ int run_grid_distance_to_host(Arena& ws, const CallCtx& c, DeviceState& st, cons
   const uint32_t layers = g.xe - g.xb;
   static const size_t piece_mb = getenv("M2S_HOST_PIECE_MB") ? (size_t)atoi(getenv("M2S_HOST_PIECE_MB")) : 64;
   uint64_t lpp = row ? std::max<uint64_t>(1, (piece_mb << 20) / 4 / row) : layers;
+  if ((uint64_t)layers * row * 4 >= (16u << 20)) lpp = std::min<uint64_t>(lpp, (layers + 3) / 4);   // >= 4 pieces: something to overlap
   lpp = std::max<uint64_t>(4, lpp / 4 * 4);                       // whole 4-voxel bricks
   const uint32_t pieces = (uint32_t)((layers + lpp - 1) / lpp);
   *pieces_out = pieces;
