@@ -610,7 +610,7 @@ void launch_packet(hipStream_t st, const DeviceMesh& mesh, const GridParams& g, 
   const uint32_t blocks = (n_packets + wpb - 1) / wpb;
   // 2 (default): XCD x takes runs x, x+8, ... of 2^run_log packets; 1: one contiguous eighth per XCD; 0: plain order
   static const int remap_mode = getenv("M2S_XCD_REMAP") ? atoi(getenv("M2S_XCD_REMAP")) : 2;
-  static const uint32_t run_log = getenv("M2S_XCD_RUN_LOG") ? std::min(20u, (uint32_t)atoi(getenv("M2S_XCD_RUN_LOG"))) : 7u;
+  static const uint32_t run_log = getenv("M2S_XCD_RUN_LOG") ? std::min(20u, (uint32_t)atoi(getenv("M2S_XCD_RUN_LOG"))) : 8u;   // 7 is as fast, 8 re-fetches less (L2 misses 363 -> 263 MB)
   const bool remap = remap_mode != 0;
   uint32_t chunk = remap ? (blocks + 7) / 8 : 0;
   if (remap_mode == 2) {
