@@ -560,7 +560,7 @@ int m2s_generate_grid_sdf(const float* vertices, size_t n_vertices, const void* 
   if (rc) return rc;
 
   size_t need = bvh_workspace_bytes(n_tris) + 4096;
-  if (sign_method == M2S_SIGN_RAYCAST) need += sign_workspace_bytes(g);
+  if (sign_method == M2S_SIGN_RAYCAST) need += sign_workspace_bytes(g, n_tris);
   need += grid_distance_workspace_bytes(g);
   if (c.mem_kind == M2S_MEM_HOST)
     need += align_up(n_vertices * 12) + align_up(n_indices * (size_t)(indices ? index_bytes : 0)) + align_up(slab_cells * 4) + 1024;
@@ -788,7 +788,7 @@ int m2s_mesh_generate_grid_sdf(m2s_mesh* m, const m2s_grid* grid, int sign_metho
   const uint32_t* plane = nullptr;
   if (sign_method == M2S_SIGN_RAYCAST) {
     if (!m->plane_valid || !same_grid(m->plane_grid, *grid)) {
-      const size_t bytes = sign_workspace_bytes(g);
+      const size_t bytes = sign_workspace_bytes(g, m->n_tris);
       if (bytes > m->plane_bytes) {
         if (m->plane_mem) { M2S_HIP_CHECK(hipDeviceSynchronize()); M2S_HIP_CHECK(hipFree(m->plane_mem)); m->plane_mem = nullptr; }
         M2S_HIP_CHECK(hipMalloc((void**)&m->plane_mem, bytes));

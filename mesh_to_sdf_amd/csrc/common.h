@@ -152,7 +152,7 @@ int build_device_mesh(Arena& ws, hipStream_t st, const float* d_verts, size_t n_
                       size_t n_indices, int index_bytes, int topology, size_t n_tris, int* d_err, DeviceMesh* out);
 
 // sign.hip: grid-line ray parity -> one "inside" bit per voxel (bit plane in grid layout).
-size_t sign_workspace_bytes(const GridParams& g);
+size_t sign_workspace_bytes(const GridParams& g, size_t n_tris);
 int build_grid_sign_plane(Arena& ws, hipStream_t st, const DeviceMesh& mesh, const GridParams& g,
                           const uint32_t** d_inside_plane);
 

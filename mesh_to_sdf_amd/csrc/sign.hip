@@ -12,6 +12,8 @@
 //   k_scan_x/y : suffix XOR of the markers along x / y  ==  parity of "increment cells 0..=k".
 //   k_scan_z_combine : suffix XOR along z inside the words, then majority of the three planes.
 // Work is O(T * lines-per-triangle + N^3 / 32) instead of O(N^2 log T + hits * N) atomics.
+#include <algorithm>
+
 #include "common.h"
 #include "geo.hip.h"
 
@@ -82,9 +84,15 @@ __device__ __forceinline__ void mark_line(f3 a, f3 b, f3 c, f3 mn, f3 mx, const 
   atomicXor(&plane[word], 1u << (cell[2] & 31u));
 }
 
+constexpr uint32_t BIG_CHUNK = 2048;   // lines of a big window one workgroup pass handles (256 threads x 8)
+struct BigList {
+  unsigned long long* counter;   // (items << 32) | chunks
+  uint2* items;                  // x = triangle | axis << 30, y = first chunk;  nullptr: no list (small grids)
+};
+
 template <int AXIS>
-__device__ __forceinline__ void mark_axis(bool valid, f3 a, f3 b, f3 c, f3 mn, f3 mx, const GridParams& g,
-                                          uint32_t* __restrict__ plane) {
+__device__ __forceinline__ void mark_axis(bool valid, uint32_t tri, f3 a, f3 b, f3 c, f3 mn, f3 mx, const GridParams& g,
+                                          uint32_t* __restrict__ plane, const BigList& list) {
   Window w = {1, 0, 1, 0};
   if (valid) w = make_window<AXIS>(mn, mx, g);
   const uint32_t cnt = window_count(w);
@@ -93,7 +101,21 @@ __device__ __forceinline__ void mark_axis(bool valid, f3 a, f3 b, f3 c, f3 mn, f
     for (uint32_t iu = w.ulo; iu <= w.uhi && cnt; ++iu)
       for (uint32_t iw = w.wlo; iw <= w.whi; ++iw) mark_line<AXIS>(a, b, c, mn, mx, g, iu, iw, plane);
   }
-  // windows too large for one lane: the whole wave walks them, one owner lane at a time
+  if (list.items != nullptr) {
+    // Windows too large for one lane go onto a work list; k_ray_mark_big spreads their lines over the whole
+    // chip.  (A low-poly mesh in a fine grid has FEW triangles with HUGE windows: walking them with the owner's
+    // wave alone left the chip idle — suzanne in 512^3: 1.8 ms of marking on 16 waves.)
+    // One packed 64-bit counter hands out the item slot (high word) and the first chunk (low word) together,
+    // so item order == chunk order and the consumer can binary-search chunk -> item.
+    if (!small) {
+      const uint32_t nchunks = (cnt + BIG_CHUNK - 1u) / BIG_CHUNK;
+      const unsigned long long old = atomicAdd(list.counter, (1ull << 32) | (unsigned long long)nchunks);
+      const uint32_t slot = (uint32_t)(old >> 32);
+      list.items[slot] = make_uint2((uint32_t)tri | ((uint32_t)AXIS << 30), (uint32_t)old);
+    }
+    return;
+  }
+  // small grids (no list): the whole wave walks a big window, one owner lane at a time
   unsigned long long big = __ballot(!small);
   const int lane = threadIdx.x & 63;
   while (big) {
@@ -114,7 +136,7 @@ __device__ __forceinline__ void mark_axis(bool valid, f3 a, f3 b, f3 c, f3 mn, f
 }
 
 __global__ __launch_bounds__(256) void k_ray_mark(DeviceMesh mesh, GridParams g, uint32_t* __restrict__ px,
-                                                  uint32_t* __restrict__ py, uint32_t* __restrict__ pz) {
+                                                  uint32_t* __restrict__ py, uint32_t* __restrict__ pz, BigList list) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   const bool valid = t < mesh.n_tris;
   f3 a = {0, 0, 0}, b = {0, 0, 0}, c = {0, 0, 0}, mn = {0, 0, 0}, mx = {0, 0, 0};
@@ -125,9 +147,41 @@ __global__ __launch_bounds__(256) void k_ray_mark(DeviceMesh mesh, GridParams g,
     c = mk3(r.cx, r.cy, r.cz);
     triangle_bounding_box(a, b, c, &mn, &mx);
   }
-  mark_axis<0>(valid, a, b, c, mn, mx, g, px);
-  mark_axis<1>(valid, a, b, c, mn, mx, g, py);
-  mark_axis<2>(valid, a, b, c, mn, mx, g, pz);
+  mark_axis<0>(valid, t, a, b, c, mn, mx, g, px, list);
+  mark_axis<1>(valid, t, a, b, c, mn, mx, g, py, list);
+  mark_axis<2>(valid, t, a, b, c, mn, mx, g, pz, list);
+}
+
+template <int AXIS>
+__device__ __forceinline__ void mark_chunk(const TriRec& r, const GridParams& g, uint32_t chunk, uint32_t* __restrict__ plane) {
+  const f3 a = mk3(r.ax, r.ay, r.az), b = mk3(r.bx, r.by, r.bz), c = mk3(r.cx, r.cy, r.cz);
+  f3 mn, mx;
+  triangle_bounding_box(a, b, c, &mn, &mx);
+  const Window w = make_window<AXIS>(mn, mx, g);
+  const uint32_t nw = w.whi - w.wlo + 1u, total = window_count(w);
+  const uint32_t i0 = chunk * BIG_CHUNK, i1 = min(total, i0 + BIG_CHUNK);
+  for (uint32_t i = i0 + threadIdx.x; i < i1; i += blockDim.x)
+    mark_line<AXIS>(a, b, c, mn, mx, g, w.ulo + i / nw, w.wlo + i % nw, plane);
+}
+
+// Chunks of the big windows, one per workgroup pass, over a fixed grid (the totals are only known on the device).
+__global__ __launch_bounds__(256) void k_ray_mark_big(DeviceMesh mesh, GridParams g, uint32_t* __restrict__ px,
+                                                      uint32_t* __restrict__ py, uint32_t* __restrict__ pz, BigList list) {
+  const unsigned long long ctr = *list.counter;
+  const uint32_t n_items = (uint32_t)(ctr >> 32), n_chunks = (uint32_t)ctr;
+  for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+    uint32_t lo = 0, hi = n_items;           // last item whose first chunk <= chunk (first chunks ascend with the slot)
+    while (hi - lo > 1) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (list.items[mid].y <= chunk) lo = mid; else hi = mid;
+    }
+    const uint2 it = list.items[lo];
+    const TriRec r = mesh.tris[it.x & 0x3fffffffu];
+    const uint32_t local = chunk - it.y, axis = it.x >> 30;
+    if (axis == 0) mark_chunk<0>(r, g, local, px);
+    else if (axis == 1) mark_chunk<1>(r, g, local, py);
+    else mark_chunk<2>(r, g, local, pz);
+  }
 }
 
 // Suffix XOR along x: thread = one (y, zw) word column, walking x from nx-1 down to 0.
@@ -208,8 +262,15 @@ __global__ __launch_bounds__(256) void k_scan_z_combine_rows(const uint32_t* __r
 
 }  // namespace
 
-size_t sign_workspace_bytes(const GridParams& g) {
-  return 3 * ((size_t)g.n[0] * g.n[1] * g.nzw * 4 + 256) + 1024;
+// Grids whose largest possible window (a whole face of the grid) exceeds this use the work list for big windows.
+constexpr uint64_t LIST_ABOVE_LINES = 4096;
+static bool use_big_list(const GridParams& g) {
+  const uint64_t a = (uint64_t)g.n[1] * g.n[2], b = (uint64_t)g.n[0] * g.n[2], c = (uint64_t)g.n[0] * g.n[1];
+  return std::max(a, std::max(b, c)) > LIST_ABOVE_LINES;
+}
+
+size_t sign_workspace_bytes(const GridParams& g, size_t n_tris) {
+  return 3 * ((size_t)g.n[0] * g.n[1] * g.nzw * 4 + 256) + 1024 + (use_big_list(g) ? 3 * n_tris * sizeof(uint2) + 512 : 0);
 }
 
 int build_grid_sign_plane(Arena& ws, hipStream_t st, const DeviceMesh& mesh, const GridParams& g,
@@ -229,7 +290,18 @@ int build_grid_sign_plane(Arena& ws, hipStream_t st, const DeviceMesh& mesh, con
   M2S_HIP_CHECK(hipMemsetAsync(pz, 0, words * 4, st));
   const unsigned B = 256;
   if (mesh.n_tris) {
-    hipLaunchKernelGGL(k_ray_mark, dim3((mesh.n_tris + B - 1) / B), dim3(B), 0, st, mesh, g, px, py, pz);
+    BigList list{nullptr, nullptr};
+    if (use_big_list(g)) {
+      list.counter = ws.take<unsigned long long>(8);
+      list.items = ws.take<uint2>(3 * (size_t)mesh.n_tris);
+      if (!list.counter || !list.items) {
+        set_error("internal: sign workspace too small");
+        return M2S_ERR_HIP_INTERNAL;
+      }
+      M2S_HIP_CHECK(hipMemsetAsync(list.counter, 0, 8, st));
+    }
+    hipLaunchKernelGGL(k_ray_mark, dim3((mesh.n_tris + B - 1) / B), dim3(B), 0, st, mesh, g, px, py, pz, list);
+    if (list.items) hipLaunchKernelGGL(k_ray_mark_big, dim3(2048), dim3(B), 0, st, mesh, g, px, py, pz, list);
     const size_t row_words = (size_t)g.n[1] * g.nzw;
     hipLaunchKernelGGL(k_scan_x, dim3((unsigned)((row_words + B - 1) / B)), dim3(B), 0, st, px, g.n[0], row_words);
     const size_t ycols = (size_t)g.n[0] * g.nzw;
