@@ -227,6 +227,10 @@ int fill_grid_params(const m2s_grid* grid, const m2s_opts* opts, GridParams* g, 
   g->xe = (uint32_t)xe;
   g->nzw = (uint32_t)((gz + 31) / 32);
   g->out_off = 0;
+  g->pad_ = 0;
+  static const bool cube_only = getenv("M2S_BRICK_CUBE") && atoi(getenv("M2S_BRICK_CUBE")) != 0;
+  if (cube_only) g->bl[0] = g->bl[1] = g->bl[2] = 2;
+  else choose_brick_shape(g->size, g->bl);
   *slab_cells = (size_t)(xe - xb) * gy * gz;
   return 0;
 }
@@ -283,7 +287,8 @@ int run_grid_distance_to_host(Arena& ws, const CallCtx& c, DeviceState& st, cons
   static const size_t piece_mb = getenv("M2S_HOST_PIECE_MB") ? (size_t)atoi(getenv("M2S_HOST_PIECE_MB")) : 64;
   uint64_t lpp = row ? std::max<uint64_t>(1, (piece_mb << 20) / 4 / row) : layers;
   if ((uint64_t)layers * row * 4 >= (16u << 20)) lpp = std::min<uint64_t>(lpp, (layers + 3) / 4);   // >= 4 pieces: something to overlap
-  lpp = std::max<uint64_t>(4, lpp / 4 * 4);                       // whole 4-voxel bricks
+  const uint64_t bx = 1ull << g.bl[0];
+  lpp = std::max<uint64_t>(bx, lpp / bx * bx);                    // whole bricks along x
   const uint32_t pieces = (uint32_t)((layers + lpp - 1) / lpp);
   *pieces_out = pieces;
   int rc = ensure_ring(st, (size_t)std::min<uint64_t>(lpp, layers) * row * 4);

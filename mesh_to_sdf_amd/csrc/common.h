@@ -99,7 +99,33 @@ struct GridParams {
   uint32_t xb, xe;   // x-slab [xb, xe)
   uint32_t nzw;      // 32-bit words per (x,y) row of a bit plane = ceil(nz / 32)
   uint64_t out_off;  // subtracted from the whole-grid cell index when writing (slab staging buffers)
+  // log2 extents of the 64-voxel packet brick along x, y, z (sum 6; 2,2,2 = 4x4x4).  Chosen per grid so that the
+  // brick is as close to a cube in WORLD space as powers of two allow (anisotropic cell sizes): the walk's cost
+  // grows with the brick's diameter, not its voxel count.
+  uint32_t bl[3];
+  uint32_t pad_;
 };
+
+// Brick shape for a cell size: minimises max/min of the world extents |size[k]| * 2^bl[k] over all splits of 6.
+inline void choose_brick_shape(const float size[3], uint32_t bl[3]) {
+  bl[0] = bl[1] = bl[2] = 2;
+  float s[3];
+  for (int k = 0; k < 3; ++k) {
+    s[k] = size[k] < 0 ? -size[k] : size[k];
+    if (!(s[k] > 0.0f) || !(s[k] < 3.0e38f)) return;
+  }
+  float best = -1.0f;
+  for (uint32_t a = 0; a <= 6; ++a)
+    for (uint32_t b = 0; a + b <= 6; ++b) {
+      const uint32_t c = 6 - a - b;
+      const float e[3] = {s[0] * (float)(1u << a), s[1] * (float)(1u << b), s[2] * (float)(1u << c)};
+      const float mx = e[0] > e[1] ? (e[0] > e[2] ? e[0] : e[2]) : (e[1] > e[2] ? e[1] : e[2]);
+      const float mn = e[0] < e[1] ? (e[0] < e[2] ? e[0] : e[2]) : (e[1] < e[2] ? e[1] : e[2]);
+      const float ratio = mx / mn;
+      const bool cube = a == 2 && b == 2;
+      if (best < 0.0f || ratio < best * 0.999f || (cube && ratio <= best * 1.001f)) { best = ratio; bl[0] = a; bl[1] = b; bl[2] = c; }
+    }
+}
 
 // Device-side error flags (OR-ed into one int by kernels).
 enum : int { ERRF_INDEX_OOB = 1, ERRF_NAN = 2 };

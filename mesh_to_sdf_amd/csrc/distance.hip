@@ -64,6 +64,9 @@ struct GridBrick {
 // its 4 MiB L2 still holds it; a plain z-y-x sweep returns to a node only after a whole z column.
 // A thin x-slab (multi-GPU pieces are 16 layers = 4 bricks at 8 GPUs x 4 chunks) uses super-bricks that are
 // 4, 2 or 1 bricks wide in x instead, so that at most 1/8 of the launched packets are padding.
+__host__ __device__ __forceinline__ uint32_t bricks_along(uint32_t cells, uint32_t log2_extent) {
+  return (cells + (1u << log2_extent) - 1u) >> log2_extent;
+}
 __host__ __device__ __forceinline__ uint32_t super_brick_xlog(uint32_t nbx) {
   for (uint32_t xl = 3; xl > 0; --xl) {
     const uint32_t padded = ((nbx + (1u << xl) - 1u) >> xl) << xl;
@@ -72,9 +75,9 @@ __host__ __device__ __forceinline__ uint32_t super_brick_xlog(uint32_t nbx) {
   return 0;
 }
 __device__ __forceinline__ void brick_coords(const GridParams& g, uint32_t brick, uint32_t* bx, uint32_t* by, uint32_t* bz) {
-  const uint32_t nby = (g.n[1] + 3) >> 2, nbz = (g.n[2] + 3) >> 2;
+  const uint32_t nby = bricks_along(g.n[1], g.bl[1]), nbz = bricks_along(g.n[2], g.bl[2]);
   const uint32_t sy = (nby + 7) >> 3, sz = (nbz + 7) >> 3;
-  const uint32_t xl = super_brick_xlog((g.xe - g.xb + 3) >> 2);
+  const uint32_t xl = super_brick_xlog(bricks_along(g.xe - g.xb, g.bl[0]));
   const uint32_t sb = brick >> (6 + xl), in = brick & ((64u << xl) - 1u);   // super-brick index, position inside (padded grid)
   const uint32_t sbz = sb % sz, sby = (sb / sz) % sy, sbx = sb / (sz * sy);
   *bx = (sbx << xl) + (in >> 6);
@@ -85,11 +88,12 @@ __device__ __forceinline__ GridBrick grid_lane_voxel(const GridParams& g, uint32
   uint32_t bx, by, bz;
   brick_coords(g, brick, &bx, &by, &bz);
   GridBrick v;
-  v.x = g.xb + bx * 4 + (lane >> 4);
-  v.y = by * 4 + ((lane >> 2) & 3);
-  v.z = bz * 4 + (lane & 3);
+  const uint32_t lx = g.bl[0], ly = g.bl[1], lz = g.bl[2], l = (uint32_t)lane;   // z in the low bits: the fastest axis
+  v.x = g.xb + (bx << lx) + (l >> (ly + lz));
+  v.y = (by << ly) + ((l >> lz) & ((1u << ly) - 1u));
+  v.z = (bz << lz) + (l & ((1u << lz) - 1u));
   v.in_range = v.x < g.xe && v.y < g.n[1] && v.z < g.n[2];
-  v.brick_in_grid = (g.xb + bx * 4 < g.xe) && (by * 4 < g.n[1]) && (bz * 4 < g.n[2]);
+  v.brick_in_grid = (g.xb + (bx << lx) < g.xe) && ((by << ly) < g.n[1]) && ((bz << lz) < g.n[2]);
   v.bx = bx; v.by = by; v.bz = bz;
   v.x = min(v.x, g.xe - 1);
   v.y = min(v.y, g.n[1] - 1);
@@ -101,7 +105,7 @@ __device__ __forceinline__ f3 grid_point(const GridParams& g, const GridBrick& v
           cell_center(g.first[2], g.size[2], v.z)};  // grid.rs:135-141
 }
 __device__ __forceinline__ uint32_t grid_brick_count(const GridParams& g) {
-  return ((g.xe - g.xb + 3) >> 2) * ((g.n[1] + 3) >> 2) * ((g.n[2] + 3) >> 2);
+  return bricks_along(g.xe - g.xb, g.bl[0]) * bricks_along(g.n[1], g.bl[1]) * bricks_along(g.n[2], g.bl[2]);
 }
 
 // XCD-aware work order: the dispatcher places block b on XCD b % 8.  Each XCD works through runs of consecutive
@@ -641,7 +645,7 @@ void launch_brute(hipStream_t st, const DeviceMesh& mesh, const GridParams& g, c
 }
 
 uint32_t host_brick_count(const GridParams& g) {   // padded to whole super-bricks
-  const uint32_t nbx = (g.xe - g.xb + 3) >> 2, nby = (g.n[1] + 3) >> 2, nbz = (g.n[2] + 3) >> 2;
+  const uint32_t nbx = bricks_along(g.xe - g.xb, g.bl[0]), nby = bricks_along(g.n[1], g.bl[1]), nbz = bricks_along(g.n[2], g.bl[2]);
   const uint32_t xl = super_brick_xlog(nbx);
   return ((nbx + (1u << xl) - 1u) >> xl) * ((nby + 7) >> 3) * ((nbz + 7) >> 3) * (64u << xl);
 }
@@ -649,12 +653,13 @@ uint32_t host_brick_count(const GridParams& g) {   // padded to whole super-bric
 }  // namespace
 
 // Coarse lattice whose points sit at the centres of the `stride`-sized blocks of `fine`.
-static GridParams coarse_level(const GridParams& fine, uint32_t stride, uint32_t x_origin) {
+static GridParams coarse_level(const GridParams& fine, const uint32_t log2_stride[3], uint32_t x_origin) {
   GridParams c = fine;
   for (int k = 0; k < 3; ++k) {
     const uint32_t span = k == 0 ? fine.xe - fine.xb : fine.n[k];
+    const uint32_t stride = 1u << log2_stride[k];
     c.n[k] = (span + stride - 1) / stride;
-    c.first[k] = fine.first[k] + (float)((k == 0 ? x_origin : 0u) + stride / 2) * fine.size[k];
+    c.first[k] = fine.first[k] + ((float)(k == 0 ? x_origin : 0u) + 0.5f * (float)(stride - 1u)) * fine.size[k];   // brick centre
     c.size[k] = (float)stride * fine.size[k];
   }
   c.xb = 0;
@@ -684,7 +689,7 @@ int launch_grid_distance(Arena& ws, hipStream_t st, const DeviceMesh& mesh, cons
   uint32_t sh1 = 0, s1ny = 0, s1nz = 0;
   static const bool use_seeds = !(getenv("M2S_SEEDS") && atoi(getenv("M2S_SEEDS")) == 0);
   if (!brute && mesh.n_tris && packets >= 8 && use_seeds) {
-    const GridParams g1 = coarse_level(g, 4, g.xb);
+    const GridParams g1 = coarse_level(g, g.bl, g.xb);   // one lattice point per packet brick, at its centre
     const size_t points1 = (size_t)g1.n[0] * g1.n[1] * g1.n[2];
     uint32_t* s1 = ws.take<uint32_t>(points1);
     uint32_t* s1b = ws.take<uint32_t>(points1);

@@ -551,3 +551,20 @@ def test_fuzz_tree_walk_equals_brute_force(seed):
         a = generate_sdf(v, Topology.TriangleList(idx), q, am, algorithm=0)
         b = generate_sdf(v, Topology.TriangleList(idx), q, am, algorithm=1)
         assert_bit_equal(a, b, f"queries seed {seed} accel {am.kind}")
+
+
+@pytest.mark.parametrize("counts", [[260, 9, 33], [7, 300, 5], [3, 6, 500], [64, 1, 64]])
+def test_anisotropic_grids_use_non_cubic_bricks(suzanne, counts):
+    """Strongly anisotropic cell sizes make the kernels pick a packet brick that is not 4x4x4 (64x1x1 ... 1x1x64):
+    exact result, also when the grid is computed in x-slab pieces."""
+    v, idx = suzanne
+    g = grid_of(v, counts)
+    for sign in (SignMethod.Raycast, SignMethod.Normal):
+        want = oracle_grid(v, idx, g, sign)
+        assert_bit_equal(generate_grid_sdf(v, Topology.TriangleList(idx), g, sign), want, f"{counts} {sign.name}")
+        out = np.full(g.get_total_cell_count(), np.nan, F)
+        nx = counts[0]
+        cuts = sorted({0, nx // 3, (2 * nx) // 3 + 1, nx} & set(range(nx + 1)))
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            generate_grid_sdf(v, Topology.TriangleList(idx), g, sign, x_slab=(a, b), out=out)
+        assert_bit_equal(out, want, f"{counts} {sign.name} in slabs {cuts}")
