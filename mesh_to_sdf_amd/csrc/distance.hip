@@ -16,6 +16,7 @@
 // current best by a margin that covers f32 rounding of both the box test and the reference
 // arithmetic (see prune_bound), so the minimum is the brute-force minimum bit for bit.
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 
@@ -369,6 +370,64 @@ __global__ __launch_bounds__(256) void k_packet(DeviceMesh mesh, GridParams g, c
 
 
 
+
+// ---- k_lane ---------------------------------------------------------------------------------
+// One VOXEL per lane, every lane walking the tree on its own (per-lane offsets, records by vector gathers).
+// For the opposite regime of k_packet: when the triangles are much smaller than the voxels (a 1 M-triangle
+// scan into a 128^3 grid), the 64 voxels of a brick each need a different handful of triangles; the packet walk
+// then runs every exact evaluation wave-wide for the benefit of one lane (blob-1M in 128^3: 11.8 ms), while
+// independent walks only pay for what each voxel needs.  Same bounds, same leaf pre-test, same arithmetic, same
+// per-brick seed; the result is the exact minimum either way.
+template <int MODE, int SIGN>
+__global__ __launch_bounds__(256) void k_lane(DeviceMesh mesh, GridParams g, const uint32_t* __restrict__ plane,
+                                              float* __restrict__ out, int* __restrict__ err, uint32_t n_packets,
+                                              const uint32_t* __restrict__ seed_in, uint32_t seed_ny, uint32_t seed_nz) {
+  const int lane = threadIdx.x & 63;
+  const uint32_t packet = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (packet >= n_packets) return;
+  const GridBrick vox = grid_lane_voxel(g, packet, lane);
+  if (!vox.brick_in_grid) return;
+  const f3 p = grid_point(g, vox);
+  const size_t out_index = ((size_t)vox.x * g.n[1] + vox.y) * g.n[2] + vox.z - (size_t)g.out_off;
+
+  Best<MODE> best;
+  if (mesh.n_nodes) {
+    const float scale = fmaxf(mesh_scale(mesh), fmaxf(fabsf(p.x), fmaxf(fabsf(p.y), fabsf(p.z))));
+    const float slack = 4.0e-6f * scale + (MODE == MODE_NORMAL_FOLD ? 2.5e-6f : 0.0f);
+    uint32_t slot = 0;
+    if (seed_in != nullptr) slot = min(seed_in[(vox.bx * seed_ny + vox.by) * seed_nz + vox.bz], mesh.n_tris - 1);
+    eval_triangle<MODE>(best, p, mesh.tris[slot]);
+    float thr = prune_bound(best.d2, slack);
+    constexpr uint32_t NB = (uint32_t)sizeof(NodeExt);
+    const uint32_t end = mesh.n_nodes * NB;
+    const char* ext_bytes = reinterpret_cast<const char*>(mesh.ext);
+    uint32_t off = 0;                                  // per lane
+    while (off < end) {
+      const NodeExt nr = *reinterpret_cast<const NodeExt*>(ext_bytes + off);
+      if (ext_dist2(p, nr) > thr) { off = nr.skip; continue; }
+      if (nr.tri >= 0) {
+        const uint32_t cnt = (nr.skip - off + NB) / (2u * NB);
+        for (uint32_t k = 0; k < cnt; ++k) {
+          if (!(planes_dist2(p, mesh.planes[nr.tri + k]) > thr)) {
+            eval_triangle<MODE>(best, p, mesh.tris[nr.tri + k]);
+            thr = prune_bound(best.d2, slack);
+          }
+        }
+        off = nr.skip;
+      } else {
+        off += NB;
+      }
+    }
+  }
+  bool negate = false;
+  if (MODE == MODE_UNSIGNED && SIGN == SIGN_GRID_PLANE) {
+    const size_t w = ((size_t)vox.x * g.n[1] + vox.y) * g.nzw + (vox.z >> 5);
+    negate = (plane[w] >> (vox.z & 31u)) & 1u;                         // grid.rs:630-636
+  }
+  if (MODE == MODE_NORMAL_FOLD && best.nan) atomicOr(err, ERRF_NAN);
+  if (vox.in_range) out[out_index] = finish<MODE>(best, negate);
+}
+
 // ---- jump-flooding seed pass ------------------------------------------------------------------
 // Seeds only have to be GOOD, never exact (they bound the first prune, nothing else), so the seed
 // lattice (one point per 4^3 brick) is filled by jump flooding (Rong & Tan 2006) over triangle
@@ -716,6 +775,22 @@ int launch_grid_distance(Arena& ws, hipStream_t st, const DeviceMesh& mesh, cons
   }
   if (ev_before_final) M2S_HIP_CHECK(hipEventRecord(ev_before_final, st));
 
+  // Walk flavour: bricks that each meet MANY triangles (triangles much smaller than voxels) are better served by
+  // independent per-lane walks.  Estimate: triangles per surface brick ~ T / (6 * bricks^(2/3)).
+  static const int lane_env = getenv("M2S_LANE_WALK") ? atoi(getenv("M2S_LANE_WALK")) : -1;   // -1 auto, 0 never, 1 always
+  const double surface_bricks = 6.0 * pow((double)packets, 2.0 / 3.0);
+  const bool lane_walk = !brute && mesh.n_tris && (lane_env >= 0 ? lane_env == 1 : (double)mesh.n_tris > 60.0 * surface_bricks);   // measured crossover: 40 per brick favours the packet walk, 65 the lane walk
+  if (lane_walk) {
+    const unsigned blocks = (packets + 3) / 4;
+    if (mode == MODE_UNSIGNED && d_inside_plane)
+      hipLaunchKernelGGL((k_lane<MODE_UNSIGNED, SIGN_GRID_PLANE>), dim3(blocks), dim3(256), 0, st, mesh, g, d_inside_plane, d_out, d_err, packets, seed1, s1ny, s1nz);
+    else if (mode == MODE_UNSIGNED)
+      hipLaunchKernelGGL((k_lane<MODE_UNSIGNED, SIGN_NONE>), dim3(blocks), dim3(256), 0, st, mesh, g, nullptr, d_out, d_err, packets, seed1, s1ny, s1nz);
+    else
+      hipLaunchKernelGGL((k_lane<MODE_NORMAL_FOLD, SIGN_NONE>), dim3(blocks), dim3(256), 0, st, mesh, g, nullptr, d_out, d_err, packets, seed1, s1ny, s1nz);
+    M2S_HIP_CHECK(hipGetLastError());
+    return 0;
+  }
   if (mode == MODE_UNSIGNED && d_inside_plane) {
     if (brute) launch_brute<true, MODE_UNSIGNED, SIGN_GRID_PLANE>(st, mesh, g, nullptr, 0, d_inside_plane, d_out, d_err, packets);
     else launch_packet<true, MODE_UNSIGNED, SIGN_GRID_PLANE>(st, mesh, g, nullptr, nullptr, 0, d_inside_plane, d_out, d_err, packets, seed1, sh1, s1ny, s1nz);

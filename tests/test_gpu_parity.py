@@ -568,3 +568,17 @@ def test_anisotropic_grids_use_non_cubic_bricks(suzanne, counts):
         for a, b in zip(cuts[:-1], cuts[1:]):
             generate_grid_sdf(v, Topology.TriangleList(idx), g, sign, x_slab=(a, b), out=out)
         assert_bit_equal(out, want, f"{counts} {sign.name} in slabs {cuts}")
+
+
+@pytest.mark.parametrize("sign", [SignMethod.Raycast, SignMethod.Normal])
+def test_many_small_triangles_per_voxel_lane_walk(sign):
+    """100k triangles into a ~24^3 grid: hundreds of triangles per brick, the regime in which the library switches
+    from the packet walk to independent per-lane walks (k_lane).  Same exact result; also in x-slab pieces."""
+    v, idx = meshes.named("blob-100k")
+    g = grid_of(v, [20, 24, 28])
+    want = oracle_grid(v, idx, g, sign)
+    assert_bit_equal(generate_grid_sdf(v, Topology.TriangleList(idx), g, sign), want, f"lane walk {sign.name}")
+    out = np.full(g.get_total_cell_count(), np.nan, F)
+    for a, b in ((0, 7), (7, 8), (8, 20)):
+        generate_grid_sdf(v, Topology.TriangleList(idx), g, sign, x_slab=(a, b), out=out)
+    assert_bit_equal(out, want, f"lane walk {sign.name} in slabs")
