@@ -40,11 +40,12 @@ __device__ __forceinline__ T record_at(const T* base, uint32_t index) {
   return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + index * (uint32_t)sizeof(T));
 }
 
-// Leaf records (TriPlanes 64 B + TriRec 96 B per triangle) are read through the VECTOR path although their
-// address is wave-uniform: a uniform-address vector load is a broadcast out of the 32 KB vector L1, lands in
-// VGPRs, waits on the in-order vmcnt — and keeps the 16 KB scalar cache for the node records of the walk
-// (measured: 16.5 vs 17.3 ms with the same records through scalar loads).  The index is laundered through a
-// VGPR so that the compiler does not turn the load back into a scalar one.
+// The 96-byte triangle records of the exact evaluation are read through the VECTOR path although their address
+// is wave-uniform: a uniform-address vector load is a broadcast out of the 32 KB vector L1, lands in VGPRs, waits
+// on the in-order vmcnt — and keeps the 16 KB scalar cache for the node records (and the 64-byte pre-test planes)
+// of the walk.  Measured on 512^3 x blob-100k: both leaf records scalar 14.9 ms (kernel), both vector 14.05,
+// planes scalar + triangle vector 13.67, the other way round 14.36.  The index is laundered through a VGPR so that
+// the compiler does not turn the load back into a scalar one.
 template <class T>
 __device__ __forceinline__ T record_at_vec(const T* base, uint32_t uniform_index) {
   uint32_t vi;
@@ -331,7 +332,7 @@ __global__ __launch_bounds__(256) void k_packet(DeviceMesh mesh, GridParams g, c
         const uint32_t cnt = (nr.skip - off + NB) / (2u * NB);    // triangles of this (possibly collapsed) leaf
         for (uint32_t k = 0; k < cnt; ++k) {
           if (STATS) ++st_ext;
-          const TriPlanes tp = record_at_vec(mesh.planes, (uint32_t)nr.tri + k);
+          const TriPlanes tp = record_at(mesh.planes, (uint32_t)nr.tri + k);   // scalar: small, needed for every leaf triangle
           if (__ballot(!(planes_dist2(p, tp) > thr)) != 0ull) {   // some lane's bound reaches the triangle itself
             if (STATS) ++st_leaf;
             const TriRec tr = record_at_vec(mesh.tris, (uint32_t)nr.tri + k);
