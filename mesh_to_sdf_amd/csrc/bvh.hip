@@ -15,6 +15,8 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <cstdio>
+#include <vector>
 
 #include <rocprim/rocprim.hpp>
 
@@ -568,6 +570,18 @@ int build_device_mesh(Arena& ws, hipStream_t st, const float* d_verts, size_t n_
                      index_bytes, topology, (uint32_t)n_tris, raw, boxes, scene, d_err);
   hipLaunchKernelGGL(k_scene_reduce, dim3(1), dim3(256), 0, st, scene, (uint32_t)cdiv(n_tris, B));
   hipLaunchKernelGGL(k_morton, dim3(cdiv(n_tris, B)), dim3(B), 0, st, boxes, (uint32_t)n_tris, scene, keys, vals);
+  if (const char* kf = getenv("M2S_KEYS_FILE")) {
+    // Experiment knob (tools/exp_tree.py): one 64-bit key per triangle from a file instead of the Morton keys.  The
+    // radix tree over prefix-free path codes IS the tree that produced them, so any binary tree of depth < 64 built
+    // elsewhere can be walked by the unchanged kernels.
+    std::vector<uint64_t> hk(n_tris);
+    FILE* f = fopen(kf, "rb");
+    const bool ok = f && fread(hk.data(), 8, n_tris, f) == n_tris;
+    if (f) fclose(f);
+    if (!ok) { set_error("M2S_KEYS_FILE: cannot read one key per triangle"); return M2S_ERR_BAD_ARG; }
+    M2S_HIP_CHECK(hipMemcpyAsync(keys, hk.data(), 8 * n_tris, hipMemcpyHostToDevice, st));
+    M2S_HIP_CHECK(hipStreamSynchronize(st));
+  }
   M2S_HIP_CHECK(rocprim::radix_sort_pairs(tmp, sort_tmp, keys, keys2, vals, order, n_tris, 0, 64, st));
   if (n > 1) hipLaunchKernelGGL(k_karras, dim3(cdiv(n_tris - 1, B)), dim3(B), 0, st, keys2, n, range, child, parent);
 

@@ -63,6 +63,41 @@ int ensure_capacity(DeviceState& s, size_t bytes) {
   return 0;
 }
 
+int select_scratch(DeviceState& s, hipStream_t stream) {
+  if (s.active >= 0) { s.scratch[s.active].base = s.base; s.scratch[s.active].cap = s.cap; }
+  int pick = -1;
+  for (int i = 0; i < s.n_scratch; ++i)
+    if (s.scratch[i].stream == stream) pick = i;
+  if (pick < 0 && s.n_scratch < DeviceState::SCRATCH) {
+    pick = s.n_scratch++;
+    s.scratch[pick] = DeviceState::Scratch{};
+    s.scratch[pick].stream = stream;
+  }
+  if (pick < 0) {   // more streams than blocks: hand the least recently used block over once its work has drained
+    pick = 0;
+    for (int i = 1; i < s.n_scratch; ++i)
+      if (s.scratch[i].last_use < s.scratch[pick].last_use) pick = i;
+    M2S_HIP_CHECK(hipDeviceSynchronize());
+    s.scratch[pick].stream = stream;
+  }
+  s.scratch[pick].last_use = ++s.tick;
+  s.base = s.scratch[pick].base;
+  s.cap = s.scratch[pick].cap;
+  s.active = pick;
+  return 0;
+}
+
+void release_scratch(DeviceState& s) {
+  if (s.active >= 0) { s.scratch[s.active].base = s.base; s.scratch[s.active].cap = s.cap; }
+  else if (s.base) (void)hipFree(s.base);
+  for (int i = 0; i < s.n_scratch; ++i)
+    if (s.scratch[i].base) (void)hipFree(s.scratch[i].base);
+  s.n_scratch = 0;
+  s.active = -1;
+  s.base = nullptr;
+  s.cap = 0;
+}
+
 int resolve_ctx(const m2s_opts* opts, CallCtx* c, DeviceState** st) {
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -87,7 +122,7 @@ int resolve_ctx(const m2s_opts* opts, CallCtx* c, DeviceState** st) {
   int rc = get_state(dev, st);
   if (rc) return rc;
   c->stream = (opts && (opts->stream || opts->stream_mode == 1)) ? (hipStream_t)opts->stream : (*st)->stream;
-  return 0;
+  return select_scratch(**st, c->stream);
 }
 
 namespace {
@@ -467,6 +502,9 @@ struct m2s_mesh {
   char* plane_mem = nullptr;
   size_t plane_bytes = 0;
   const uint32_t* plane = nullptr;
+  hipEvent_t plane_ready = nullptr;   // recorded after the sign planes were built, on plane_stream
+  hipStream_t plane_stream = nullptr;
+  bool multi_stream = false;          // the planes have been read from a stream other than plane_stream
   struct Pending {
     hipEvent_t a, b;
     uint64_t units;
@@ -500,9 +538,7 @@ void m2s_release_workspace(void) {
   for (auto& kv : g_dev) {
     if (hipSetDevice(kv.first) != hipSuccess) continue;
     (void)hipDeviceSynchronize();
-    if (kv.second.base) (void)hipFree(kv.second.base);
-    kv.second.base = nullptr;
-    kv.second.cap = 0;
+    release_scratch(kv.second);
     if (kv.second.spare_mesh) (void)hipFree(kv.second.spare_mesh);
     kv.second.spare_mesh = nullptr;
     kv.second.spare_mesh_bytes = 0;
@@ -736,6 +772,7 @@ void m2s_mesh_destroy(m2s_mesh* m) {
     if (m->mem && !ds.spare_mesh) { ds.spare_mesh = m->mem; ds.spare_mesh_bytes = m->mem_bytes; }
     else if (m->mem) (void)hipFree(m->mem);
     if (m->plane_mem) (void)hipFree(m->plane_mem);
+    if (m->plane_ready) (void)hipEventDestroy(m->plane_ready);
     for (auto& p : m->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (auto e : m->free_events) (void)hipEventDestroy(e);
   }
@@ -793,6 +830,7 @@ int m2s_mesh_generate_grid_sdf(m2s_mesh* m, const m2s_grid* grid, int sign_metho
   const uint32_t* plane = nullptr;
   if (sign_method == M2S_SIGN_RAYCAST) {
     if (!m->plane_valid || !same_grid(m->plane_grid, *grid)) {
+      if (m->multi_stream) { M2S_HIP_CHECK(hipDeviceSynchronize()); m->multi_stream = false; }   // readers on other streams
       const size_t bytes = sign_workspace_bytes(g, m->n_tris);
       if (bytes > m->plane_bytes) {
         if (m->plane_mem) { M2S_HIP_CHECK(hipDeviceSynchronize()); M2S_HIP_CHECK(hipFree(m->plane_mem)); m->plane_mem = nullptr; }
@@ -805,6 +843,12 @@ int m2s_mesh_generate_grid_sdf(m2s_mesh* m, const m2s_grid* grid, int sign_metho
       m->plane_grid = *grid;
       m->plane_valid = true;
       built_planes = true;
+      if (!m->plane_ready) M2S_HIP_CHECK(hipEventCreateWithFlags(&m->plane_ready, hipEventDisableTiming));
+      M2S_HIP_CHECK(hipEventRecord(m->plane_ready, c.stream));
+      m->plane_stream = c.stream;
+    } else if (c.stream != m->plane_stream) {   // built (perhaps still being built) on another stream
+      M2S_HIP_CHECK(hipStreamWaitEvent(c.stream, m->plane_ready, 0));
+      m->multi_stream = true;
     }
     plane = m->plane;
   }

@@ -10,8 +10,21 @@
 namespace m2s {
 
 struct DeviceState {
+  // Scratch of the call in progress.  It belongs to the STREAM the call is enqueued on (resolve_ctx selects it):
+  // calls on one stream are ordered by the stream and share one block, calls on different streams get different
+  // blocks, so asynchronous calls on two streams (the x-pieces of a sharded grid) may overlap on the device.
   char* base = nullptr;
   size_t cap = 0;
+  struct Scratch {
+    hipStream_t stream = nullptr;
+    char* base = nullptr;
+    size_t cap = 0;
+    uint64_t last_use = 0;
+  };
+  static constexpr int SCRATCH = 4;
+  Scratch scratch[SCRATCH];
+  int n_scratch = 0, active = -1;
+  uint64_t tick = 0;
   hipStream_t stream = nullptr;
   hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   int* h_err = nullptr;  // pinned
@@ -39,6 +52,8 @@ void clear_error();
 int fail(int code, const char* fmt, ...);
 int resolve_ctx(const m2s_opts* opts, CallCtx* c, DeviceState** st);
 int ensure_capacity(DeviceState& s, size_t bytes);
+int select_scratch(DeviceState& s, hipStream_t stream);   // called by resolve_ctx
+void release_scratch(DeviceState& s);                     // device must be idle
 // Pageable host arrays <-> device at PCIe speed through the pinned ring (capi.hip); complete on return.
 int staged_h2d(DeviceState& st, hipStream_t stream, char* d_dst, const char* h_src, size_t bytes);
 int staged_d2h(DeviceState& st, hipStream_t stream, char* h_dst, const char* d_src, size_t bytes);

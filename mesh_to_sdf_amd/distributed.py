@@ -12,6 +12,12 @@ sub-slab, so the all-gather of chunk c is an in-place collective on ONE contiguo
 (asynchronously, on RCCL's stream) while the ranks already compute chunk c+1.  xGMI is
 point-to-point, so the gather is per-link bound; hiding it under compute is what keeps strong
 scaling alive once the kernel is fast.  The mesh (LBVH + sign planes) is built once per call.
+
+A rank's pieces are thin (512 / 8 ranks / 4 chunks = 16 layers): alone on the chip each would end in a
+partly filled tail, and its small seeding kernels would leave most CUs idle.  Consecutive pieces are
+therefore enqueued on two alternating side streams (the library keeps one scratch block per stream), so
+piece c+1 fills the CUs that piece c's tail leaves free; the gather of chunk c is ordered after the
+stream that computed it.
 """
 from typing import Callable, List, Optional, Tuple
 
@@ -88,6 +94,50 @@ def _wait(work):
             w.wait()
 
 
+_SIDE_STREAMS = {}
+
+
+def _side_streams(device):
+    import torch
+
+    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = [torch.cuda.Stream(device=key), torch.cuda.Stream(device=key)]
+    return _SIDE_STREAMS[key]
+
+
+def run_pieces(mesh: Mesh, grid: Grid, sign_method: SignMethod, out, pieces: List[Tuple[int, int]],
+               after_piece: Optional[Callable] = None, overlap: bool = True) -> list:
+    """Enqueues the x-pieces `pieces` of one grid (device-resident `out`), calling `after_piece(i)` right
+    after piece i has been enqueued — with the stream that computes piece i as torch's current stream, so a
+    collective issued there is ordered after exactly that piece.  Returns what `after_piece` returned.
+    On return the caller's current stream waits for every piece."""
+    import torch
+
+    def one(i):
+        a, b = pieces[i]
+        if b > a:
+            mesh.generate_grid_sdf(grid, sign_method, x_slab=(a, b), out=out, synchronous=False)
+        return after_piece(i) if after_piece is not None else None
+
+    if not overlap or len(pieces) < 2 or os.environ.get("M2S_PIECE_STREAMS", "2") == "1":
+        return [one(i) for i in range(len(pieces))]
+    cur = torch.cuda.current_stream(out.device)
+    streams = _side_streams(out.device)
+    start = cur.record_event()
+    results = []
+    for i in range(len(pieces)):
+        s = streams[i % 2]
+        if i < 2:
+            s.wait_event(start)     # inputs and `out` were produced on the caller's stream
+        with torch.cuda.stream(s):
+            results.append(one(i))
+    for s in streams:
+        cur.wait_stream(s)
+        out.record_stream(s)
+    return results
+
+
 def generate_grid_sdf_sharded(vertices, indices: Topology, grid: Grid, sign_method: SignMethod = SignMethod.Raycast, *,
                               group=None, out=None, compute_slab: Optional[Callable] = None, chunks: int = 1,
                               mesh: Optional[Mesh] = None, gather: bool = True, return_mesh: bool = False):
@@ -112,17 +162,19 @@ def generate_grid_sdf_sharded(vertices, indices: Topology, grid: Grid, sign_meth
     if compute_slab is None and mesh is None:
         mesh = own_mesh = Mesh(vertices, indices)   # LBVH built once for all pieces of this call
     pending = []
+    collective = gather and (world > 1 or (_FORCE_COLLECTIVES and inited))
     try:
-        for ci, chunk in enumerate(plan):
-            a, b = piece_bounds(chunk, world, rank)
-            if compute_slab is not None:
+        if compute_slab is not None:
+            for ci, chunk in enumerate(plan):
+                a, b = piece_bounds(chunk, world, rank)
                 compute_slab(out, a, b)
-            elif b > a:
-                # asynchronous: the kernels are only enqueued, so the collective of the previous chunk
-                # (already running on RCCL's stream) overlaps them
-                mesh.generate_grid_sdf(grid, sign_method, x_slab=(a, b), out=out, synchronous=False)
-            if gather and (world > 1 or (_FORCE_COLLECTIVES and inited)):
-                pending.append(gather_chunk(out, chunk, row, group, async_op=True))
+                if collective:
+                    pending.append(gather_chunk(out, chunk, row, group, async_op=True))
+        else:
+            # asynchronous: the kernels are only enqueued, so the collective of the previous chunk
+            # (already running on RCCL's stream) overlaps them
+            pending = run_pieces(mesh, grid, sign_method, out, [piece_bounds(ch, world, rank) for ch in plan],
+                                 (lambda i: gather_chunk(out, plan[i], row, group, async_op=True)) if collective else None)
         for w in pending:
             _wait(w)
     finally:

@@ -4,7 +4,7 @@ sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(_
 import numpy as np, torch
 from mesh_to_sdf_amd import *
 from mesh_to_sdf_amd import meshes
-from mesh_to_sdf_amd.distributed import chunk_plan, piece_bounds
+from mesh_to_sdf_amd.distributed import chunk_plan, piece_bounds, run_pieces
 v, idx = meshes.named('blob-100k'); lo, hi = meshes.extended_bbox(v, 0.1)
 n = 512
 g = Grid.from_bounding_box(lo, hi, [n] * 3)
@@ -17,10 +17,7 @@ for rank in (0, 3, 7):
     for rep in range(2):
         torch.cuda.synchronize(); t0 = time.perf_counter()
         m = Mesh(dv, Topology.TriangleList(di))
-        tt = []
-        for ch in plan:
-            a, b = piece_bounds(ch, world, rank)
-            m.generate_grid_sdf(g, SignMethod.Raycast, x_slab=(a, b), out=out, synchronous=False)
+        run_pieces(m, g, SignMethod.Raycast, out, [piece_bounds(ch, world, rank) for ch in plan])
         t = m.drain_timings(); torch.cuda.synchronize(); dt = (time.perf_counter() - t0) * 1e3
         m.close()
     print(f"world {world} chunks {chunks} rank {rank}: wall {dt:.2f} ms; build {t.accel_build_ms:.2f}; k_packet launches {t.distance_launches} sum {t.distance_ms:.2f} ms")
