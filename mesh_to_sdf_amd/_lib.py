@@ -9,7 +9,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "libm2s_hip.so")
+SO_PATH = os.environ.get("M2S_LIB") or os.path.join(_HERE, "libm2s_hip.so")   # M2S_LIB: A/B builds of the same library (tools/)
 CSRC = os.path.join(_HERE, "csrc")
 
 M2S_OK = 0
