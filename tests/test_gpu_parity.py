@@ -336,6 +336,70 @@ def test_full_size_512_properties():
     assert torch.equal(sdf, again)
 
 
+def _sub_lattice(g, n, step):
+    first, size = g.get_first_cell(), g.get_cell_size()
+    ii = np.arange(0, n, step, dtype=np.float32)
+    X, Y, Z = np.meshgrid(first[0] + ii * size[0], first[1] + ii * size[1], first[2] + ii * size[2], indexing="ij")
+    return np.stack([X, Y, Z], -1).reshape(-1, 3).astype(F)
+
+
+def test_full_size_config4_blob1M_512_raycast():
+    """BASELINE config 4 at full size on one GPU: blob-1M (triangles a third of a voxel wide), 512^3, Raycast, computed
+    as the eight 64-layer x-slabs the 8-GPU run would use.  Every 8th cell per axis bit-exactly against the oracle's
+    generic path, three whole sign planes against the oracle's grid-line parity, slabs == one call."""
+    import torch
+
+    from mesh_to_sdf_amd import Mesh
+
+    v, idx = meshes.named("blob-1M")
+    n = 512
+    g = grid_of(v, [n, n, n])
+    dv, di = torch.as_tensor(v, device="cuda"), torch.as_tensor(idx.astype(np.int64), device="cuda")
+    sdf = torch.empty(n ** 3, dtype=torch.float32, device="cuda")
+    with Mesh(dv, Topology.TriangleList(di)) as m:
+        for r in range(8):
+            m.generate_grid_sdf(g, SignMethod.Raycast, x_slab=(64 * r, 64 * r + 64), out=sdf)
+    s3 = sdf.view(n, n, n)
+    sub = s3[::8, ::8, ::8].contiguous().cpu().numpy().reshape(-1)
+    mag = orc.generate_sdf(v, idx, _sub_lattice(g, n, 8), accel=1, sign=0, fast=True)
+    assert_bit_equal(np.abs(sub), np.abs(mag), "blob-1M 512^3 sub-lattice magnitudes")
+    par = orc.grid_ray_parity(v, idx, g.get_first_cell(), g.get_cell_size(), [n, n, n]).reshape(n, n, n, 3)
+    inside = par.sum(-1) >= 2
+    for x in (3, 255, 256, 470):
+        assert np.array_equal(np.signbit(s3[x].cpu().numpy()), inside[x]), f"sign plane x={x}"
+    whole = generate_grid_sdf(dv, Topology.TriangleList(di), g, SignMethod.Raycast)
+    assert torch.equal(sdf, whole)
+
+
+def test_full_size_config5_sheet100k_1024_normal():
+    """BASELINE config 5 at full size on one GPU: open surface, 1024^3 (4 GiB of f32), Normal sign, computed as the
+    eight 128-layer x-slabs of the 8-GPU run.  Every 8th cell per axis (128^3 cells) bit-exactly — magnitude AND sign,
+    i.e. zero sign leaks — against the oracle's compare_distances fold over all triangles at the same points."""
+    import torch
+
+    from mesh_to_sdf_amd import Mesh
+
+    v, idx = meshes.named("sheet-100k")
+    n = 1024
+    g = grid_of(v, [n, n, n])
+    dv, di = torch.as_tensor(v, device="cuda"), torch.as_tensor(idx.astype(np.int64), device="cuda")
+    sdf = torch.empty(n ** 3, dtype=torch.float32, device="cuda")
+    with Mesh(dv, Topology.TriangleList(di)) as m:
+        for r in range(8):
+            m.generate_grid_sdf(g, SignMethod.Normal, x_slab=(128 * r, 128 * r + 128), out=sdf)
+    s3 = sdf.view(n, n, n)
+    sub = s3[::8, ::8, ::8].contiguous().cpu().numpy().reshape(-1)
+    want = orc.generate_sdf(v, idx, _sub_lattice(g, n, 8), accel=1, sign=1, fast=True)
+    assert_bit_equal(sub, want, "sheet-100k 1024^3 sub-lattice, Normal sign")
+    cs = float(g.get_cell_size()[2])
+    dz = 0.0
+    for x0 in range(0, n, 128):   # 1-Lipschitz along z on the whole grid, slab by slab (keeps the temporaries small)
+        a = s3[x0 : x0 + 128].abs()
+        dz = max(dz, float((a[:, :, 1:] - a[:, :, :-1]).abs().max()))
+    assert dz <= cs + 2e-6
+    del sdf, s3
+
+
 # ---- persistent mesh (include/m2s.h m2s_mesh) -----------------------------------------------------
 def test_persistent_mesh_matches_one_shot(suzanne):
     import torch
