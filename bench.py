@@ -4,7 +4,8 @@
 
 One "step" = one complete generate_grid_sdf call through the C ABI with the mesh and the output
 resident in HBM (device pointers): topology flatten + LBVH build + sign planes + nearest-triangle
-kernel for this rank's x-slab, then the RCCL all-gather that leaves the full grid on every GPU.
+kernel for this rank's x-slab, then the RCCL all-gather that leaves the full grid on every GPU
+(N = 1: one m2s_generate_grid_sdf call; N > 1: mesh_to_sdf_amd/distributed.py).
 The work is FIXED as N grows (strong scaling): rank r computes cells x in [r*512/N, (r+1)*512/N).
 
     python bench.py --gpus 1 --steps 10 --warmup 2
@@ -121,13 +122,23 @@ def main():
 
     chunks = args.chunks if args.chunks > 0 else (4 if (world > 1 or force_pg) else 1)
 
+    sharded = world > 1 or force_pg
+
     def step():
-        # one complete call: LBVH build, sign planes, seed passes, nearest-triangle launches for this rank's
-        # pieces, and the all-gathers (asynchronous per chunk, overlapping the next chunk's compute)
+        # one complete call: LBVH build, sign planes, seed passes, nearest-triangle launches.
+        # N = 1: exactly the reference's call, one m2s_generate_grid_sdf through the C ABI (device pointers).
+        # N > 1: this rank's x-pieces through the persistent mesh + the all-gathers (asynchronous per chunk,
+        # overlapping the next chunk's compute).
+        if not sharded:
+            t = M2STimings()
+            generate_grid_sdf(dv, topo, grid, sign, out=out, timings=t)
+            return t
         _, mesh = generate_grid_sdf_sharded(dv, topo, grid, sign, out=out, chunks=chunks, return_mesh=True)
         return mesh
 
     def finish(mesh):
+        if not sharded:
+            return mesh   # the call was synchronous and filled its timings
         t = mesh.drain_timings()   # waits for the launches of this step, reads their HIP-event durations
         mesh.close()
         return t
