@@ -539,6 +539,11 @@ void m2s_release_workspace(void) {
     if (hipSetDevice(kv.first) != hipSuccess) continue;
     (void)hipDeviceSynchronize();
     release_scratch(kv.second);
+    if (kv.second.spare_plane) (void)hipFree(kv.second.spare_plane);
+    kv.second.spare_plane = nullptr;
+    kv.second.spare_plane_bytes = 0;
+    for (auto e : kv.second.timing_events) (void)hipEventDestroy(e);
+    kv.second.timing_events.clear();
     if (kv.second.spare_mesh) (void)hipFree(kv.second.spare_mesh);
     kv.second.spare_mesh = nullptr;
     kv.second.spare_mesh_bytes = 0;
@@ -771,10 +776,17 @@ void m2s_mesh_destroy(m2s_mesh* m) {
     DeviceState& ds = g_dev[m->device];
     if (m->mem && !ds.spare_mesh) { ds.spare_mesh = m->mem; ds.spare_mesh_bytes = m->mem_bytes; }
     else if (m->mem) (void)hipFree(m->mem);
-    if (m->plane_mem) (void)hipFree(m->plane_mem);
+    if (m->plane_mem && (!ds.spare_plane || ds.spare_plane_bytes < m->plane_bytes)) {
+      if (ds.spare_plane) (void)hipFree(ds.spare_plane);
+      ds.spare_plane = m->plane_mem;
+      ds.spare_plane_bytes = m->plane_bytes;
+    } else if (m->plane_mem) (void)hipFree(m->plane_mem);
     if (m->plane_ready) (void)hipEventDestroy(m->plane_ready);
-    for (auto& p : m->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
-    for (auto e : m->free_events) (void)hipEventDestroy(e);
+    for (auto& p : m->pending) { m->free_events.push_back(p.a); m->free_events.push_back(p.b); }
+    for (auto e : m->free_events) {
+      if (ds.timing_events.size() < 64) ds.timing_events.push_back(e);
+      else (void)hipEventDestroy(e);
+    }
   }
   delete m;
 }
@@ -833,9 +845,16 @@ int m2s_mesh_generate_grid_sdf(m2s_mesh* m, const m2s_grid* grid, int sign_metho
       if (m->multi_stream) { M2S_HIP_CHECK(hipDeviceSynchronize()); m->multi_stream = false; }   // readers on other streams
       const size_t bytes = sign_workspace_bytes(g, m->n_tris);
       if (bytes > m->plane_bytes) {
-        if (m->plane_mem) { M2S_HIP_CHECK(hipDeviceSynchronize()); M2S_HIP_CHECK(hipFree(m->plane_mem)); m->plane_mem = nullptr; }
-        M2S_HIP_CHECK(hipMalloc((void**)&m->plane_mem, bytes));
-        m->plane_bytes = bytes;
+        if (m->plane_mem) { M2S_HIP_CHECK(hipDeviceSynchronize()); M2S_HIP_CHECK(hipFree(m->plane_mem)); m->plane_mem = nullptr; m->plane_bytes = 0; }
+        if (st->spare_plane && st->spare_plane_bytes >= bytes) {   // recycled from the last destroyed mesh (idle since then)
+          m->plane_mem = st->spare_plane;
+          m->plane_bytes = st->spare_plane_bytes;
+          st->spare_plane = nullptr;
+          st->spare_plane_bytes = 0;
+        } else {
+          M2S_HIP_CHECK(hipMalloc((void**)&m->plane_mem, bytes));
+          m->plane_bytes = bytes;
+        }
       }
       Arena pw{m->plane_mem, m->plane_bytes, 0};
       rc = build_grid_sign_plane(pw, c.stream, m->dm, g, &m->plane);
@@ -874,6 +893,7 @@ int m2s_mesh_generate_grid_sdf(m2s_mesh* m, const m2s_grid* grid, int sign_metho
     hipEvent_t stop, fresh;
     for (hipEvent_t* e : {&stop, &fresh}) {
       if (!m->free_events.empty()) { *e = m->free_events.back(); m->free_events.pop_back(); }
+      else if (!st->timing_events.empty()) { *e = st->timing_events.back(); st->timing_events.pop_back(); }
       else M2S_HIP_CHECK(hipEventCreate(e));
     }
     M2S_HIP_CHECK(hipEventRecord(stop, c.stream));

@@ -3,6 +3,7 @@
 #pragma once
 #include <cstdio>
 #include <mutex>
+#include <vector>
 
 #include "../../include/m2s.h"
 #include "common.h"
@@ -30,6 +31,9 @@ struct DeviceState {
   int* h_err = nullptr;  // pinned
   char* spare_mesh = nullptr;  // last destroyed m2s_mesh block, recycled by the next m2s_mesh_create
   size_t spare_mesh_bytes = 0;
+  char* spare_plane = nullptr;  // sign-plane block of the last destroyed m2s_mesh (hipFree / hipMalloc cost 0.2 + 0.1 ms per mesh)
+  size_t spare_plane_bytes = 0;
+  std::vector<hipEvent_t> timing_events;   // timing-enabled events handed back by destroyed meshes
   // host-pointer calls: pinned ring + copy stream for the pipelined D2H of the result (capi.hip)
   static constexpr int RING = 3;
   char* ring[RING] = {nullptr, nullptr, nullptr};
