@@ -213,6 +213,9 @@ def main():
                 "sign_method": args.sign,
                 "parallelism": f"xslab{world}",
                 "gather_chunks": chunks,
+                # N > 1: a rank's x-pieces run on two alternating streams, so consecutive launches of the dominant kernel
+                # overlap and their individual durations (roofline.avg_launch_ms) are longer than when run alone
+                "piece_streams": (int(os.environ.get("M2S_PIECE_STREAMS", "2")) if sharded and chunks > 1 else 1),
             },
             "phases_ms": {"accel_build": round(build_ms, 4), "sign_planes": round(sign_ms, 4), "seed_passes": round(seed_ms, 4),
                           "distance_per_launch": round(dist_ms, 4), "launches_per_step": launches // max(args.steps, 1),
