@@ -232,6 +232,24 @@ __device__ __forceinline__ uint32_t stab_count(const DeviceMesh& mesh, f3 p) {
   return count;
 }
 
+// ---- cut lists ------------------------------------------------------------------------------
+// A third of a packet's node tests fall on nodes much larger than the packet (512^3 x blob-100k: 46 of 158 on nodes
+// wider than 28 voxels, 69 on nodes wider than 14), and neighbouring packets repeat them with the same outcome.
+// k_cut walks that top part of the tree ONCE per block of 2^log bricks per axis, against a bound that holds for every
+// voxel of the block, and leaves at most CUT_MAX pre-order ranges [start, end) of NodeExt byte offsets per block: the
+// subtrees that can still matter there.  k_packet then walks those ranges instead of starting at the root.
+// A subtree is dropped only if   bound(block centre, subtree) - r_block  >  D + margins,   where D bounds the
+// distance of every voxel of the block to the seed triangle of its own packet (which k_packet evaluates first):
+// such a subtree cannot hold a triangle nearer than, or tied with, any voxel's final minimum.
+#ifndef M2S_CUT_MAX
+#define M2S_CUT_MAX 15   // 7: 12.0 ms, 15: 11.7 ms (512^3 x blob-100k)
+#endif
+constexpr uint32_t CUT_MAX = M2S_CUT_MAX, CUT_WORDS = 2 * (M2S_CUT_MAX + 1);   // [0] = number of ranges, then (start, end) pairs
+struct CutList {
+  const uint32_t* lists;   // CUT_WORDS words per block, nullptr: walk the whole tree
+  uint32_t log, ny, nz;    // bricks per block per axis = 2^log; blocks along y and z
+};
+
 // ---- k_packet -------------------------------------------------------------------------------
 // `seed_in` (one TriRec slot per 2^seed_shift bricks per axis, may be null) replaces the greedy descent:
 // the packet starts from a triangle near its own centre (jump-flooding seed pass below).
@@ -242,7 +260,7 @@ __global__ __launch_bounds__(256) void k_packet(DeviceMesh mesh, GridParams g, c
                                                 int* __restrict__ err, uint32_t n_packets, uint32_t chunk,
                                                 const uint32_t* __restrict__ seed_in, uint32_t seed_shift,
                                                 uint32_t seed_ny, uint32_t seed_nz,
-                                                const GridParams* __restrict__ seed_lattice) {
+                                                const GridParams* __restrict__ seed_lattice, CutList cut) {
   const int lane = threadIdx.x & 63;
   const uint32_t block = xcd_remap(blockIdx.x, chunk);
   const uint32_t packet = block * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -320,8 +338,17 @@ __global__ __launch_bounds__(256) void k_packet(DeviceMesh mesh, GridParams g, c
     // The walk addresses NodeExt by BYTE offset (its skip links are stored that way): the scalar loads then take
     // the offset operand directly and the loop carries no address arithmetic.
     constexpr uint32_t NB = (uint32_t)sizeof(NodeExt);
-    const uint32_t end = mesh.n_nodes * NB;
-    uint32_t off = 0;
+    // pre-order ranges to walk: the block's cut list (grid path), or the whole tree
+    const uint32_t* cl = nullptr;
+    uint32_t n_ranges = 1;
+    if (GRID && cut.lists != nullptr) {
+      const uint32_t cb = __builtin_amdgcn_readfirstlane(((vox.bx >> cut.log) * cut.ny + (vox.by >> cut.log)) * cut.nz + (vox.bz >> cut.log));
+      cl = cut.lists + (size_t)cb * CUT_WORDS;
+      n_ranges = cl[0];
+    }
+    for (uint32_t range = 0; range < n_ranges; ++range) {
+    uint32_t off = cl ? cl[1 + 2 * range] : 0u;
+    const uint32_t end = cl ? cl[2 + 2 * range] : mesh.n_nodes * NB;
     while (off < end) {
       off = __builtin_amdgcn_readfirstlane(off);
       const NodeExt nr = *reinterpret_cast<const NodeExt*>(reinterpret_cast<const char*>(mesh.ext) + off);
@@ -344,6 +371,7 @@ __global__ __launch_bounds__(256) void k_packet(DeviceMesh mesh, GridParams g, c
       } else {
         off = off + NB;
       }
+    }
     }
     }
   }
@@ -501,6 +529,81 @@ __global__ __launch_bounds__(256) void k_jfa_pass(DeviceMesh mesh, GridParams g0
     }
   }
   out[i] = best;
+}
+
+// ---- k_cut: one lane per block of 2^log bricks per axis (see CutList) ------------------------------
+__global__ __launch_bounds__(256) void k_cut(DeviceMesh mesh, GridParams g, const uint32_t* __restrict__ seeds,
+                                             uint32_t seed_ny, uint32_t seed_nz, uint32_t log, uint32_t ncx, uint32_t ncy,
+                                             uint32_t ncz, uint32_t* __restrict__ lists, float emit_near, float emit_far) {
+  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= ncx * ncy * ncz) return;
+  const uint32_t cz = b % ncz, cy = (b / ncz) % ncy, cx = b / (ncz * ncy);
+  const uint32_t nb[3] = {bricks_along(g.xe - g.xb, g.bl[0]), bricks_along(g.n[1], g.bl[1]), bricks_along(g.n[2], g.bl[2])};
+  const uint32_t c0[3] = {cx << log, cy << log, cz << log};   // first brick of the block
+  const uint32_t origin[3] = {g.xb, 0u, 0u};
+  // half extents (between voxel centres) of a brick and of the block, and their half diagonals
+  float r_brick = 0.0f, r_block = 0.0f, centre[3];
+  for (int k = 0; k < 3; ++k) {
+    const float as = fabsf(g.size[k]);
+    const float hb = 0.5f * (float)((1u << g.bl[k]) - 1u) * as, hB = 0.5f * (float)((1u << (g.bl[k] + log)) - 1u) * as;
+    r_brick = __builtin_fmaf(hb, hb, r_brick);
+    r_block = __builtin_fmaf(hB, hB, r_block);
+    centre[k] = g.first[k] + ((float)(origin[k] + (c0[k] << g.bl[k])) + 0.5f * (float)((1u << (g.bl[k] + log)) - 1u)) * g.size[k];
+  }
+  r_brick = sqrtf(r_brick) * 1.0001f;
+  r_block = sqrtf(r_block) * 1.0001f;
+  // D: every voxel of every brick of the block is at most this far from the seed triangle of its own brick
+  // (the distance to a triangle is 1-Lipschitz: <= |voxel - brick centre| + distance(brick centre, triangle))
+  float D = 0.0f;
+  const uint32_t side = 1u << log;
+  for (uint32_t ix = 0; ix < side; ++ix)
+    for (uint32_t iy = 0; iy < side; ++iy)
+      for (uint32_t iz = 0; iz < side; ++iz) {
+        const uint32_t bk[3] = {c0[0] + ix, c0[1] + iy, c0[2] + iz};
+        if (bk[0] >= nb[0] || bk[1] >= nb[1] || bk[2] >= nb[2]) continue;
+        const uint32_t slot = min(seeds[(bk[0] * seed_ny + bk[1]) * seed_nz + bk[2]], mesh.n_tris - 1);
+        const TriRec& t = mesh.tris[slot];
+        float q[3];
+        for (int k = 0; k < 3; ++k)
+          q[k] = g.first[k] + ((float)(origin[k] + (bk[k] << g.bl[k])) + 0.5f * (float)((1u << g.bl[k]) - 1u)) * g.size[k];
+        const f3 a = mk3(t.ax, t.ay, t.az), bq = mk3(t.bx, t.by, t.bz), c = mk3(t.cx, t.cy, t.cz);
+        const TriEdges e = {mk3(t.abx, t.aby, t.abz), mk3(t.acx, t.acy, t.acz), mk3(t.bcx, t.bcy, t.bcz)};
+        float dmin = point_triangle_dist2(mk3(q[0], q[1], q[2]), a, bq, c, e, t.cls);   // what k_packet's seed evaluation finds at the brick centre
+        dmin = (dmin == dmin) ? sqrtf(dmin) : __builtin_inff();
+        D = fmaxf(D, r_brick + dmin * 1.0001f);
+      }
+  const float scale = fmaxf(mesh_scale(mesh), fmaxf(fabsf(centre[0]), fmaxf(fabsf(centre[1]), fabsf(centre[2]))) + r_block);
+  // the packet walk keeps a node while bound <= d * 1.00002 + slack (slack <= 4e-6 * scale + 2.5e-6): stay well above that
+  const float R = (D + r_block) * 1.0003f + 6.4e-5f * scale + 4.0e-5f;
+  const float R2 = R * R;                                    // inf: nothing is dropped
+  const float emit_radius = fmaxf(emit_near * r_block, R * emit_far);
+  const f3 cB = mk3(centre[0], centre[1], centre[2]);
+
+  constexpr uint32_t NB = (uint32_t)sizeof(NodeExt);
+  const uint32_t end = mesh.n_nodes * NB;
+  uint32_t* out = lists + (size_t)b * CUT_WORDS;
+  uint32_t n = 0, last_start = 0, last_end = 0;
+  uint32_t off = 0;
+  while (off < end) {
+    const NodeExt nr = *reinterpret_cast<const NodeExt*>(reinterpret_cast<const char*>(mesh.ext) + off);
+    const float ed2 = ext_dist2(cB, nr);
+    if (ed2 > R2) { off = nr.skip; continue; }               // NaN keeps the node
+    if (nr.tri >= 0 || fmaxf(nr.R, nr.half) <= emit_radius) {
+      // keep this subtree: [off, skip).  Adjacent subtrees merge; past CUT_MAX ranges the last one grows over the gap
+      if (n > 0 && (last_end == off || n == CUT_MAX)) last_end = nr.skip;
+      else {
+        if (n > 0) { out[1 + 2 * (n - 1)] = last_start; out[2 + 2 * (n - 1)] = last_end; }
+        ++n; last_start = off; last_end = nr.skip;
+      }
+      off = nr.skip;
+    } else {
+      off += NB;
+    }
+  }
+  if (n == 0) { n = 1; last_start = 0; last_end = end; }    // cannot happen with finite input; never walk nothing
+  out[1 + 2 * (n - 1)] = last_start;
+  out[2 + 2 * (n - 1)] = last_end;
+  out[0] = n;
 }
 
 // ---- k_brute --------------------------------------------------------------------------------
@@ -669,7 +772,7 @@ template <bool GRID, int MODE, int SIGN>
 void launch_packet(hipStream_t st, const DeviceMesh& mesh, const GridParams& g, const float4* qs, const uint32_t* perm,
                    uint32_t n_q, const uint32_t* plane, float* out, int* err, uint32_t n_packets,
                    const uint32_t* seed_in = nullptr, uint32_t seed_shift = 0, uint32_t seed_ny = 0,
-                   uint32_t seed_nz = 0, const GridParams* seed_lattice = nullptr) {
+                   uint32_t seed_nz = 0, const GridParams* seed_lattice = nullptr, CutList cut = {nullptr, 0, 0, 0}) {
   static const uint32_t wpb = getenv("M2S_WPB") ? std::min(4u, std::max(1u, (uint32_t)atoi(getenv("M2S_WPB")))) : 1u;   // waves (packets) per workgroup: single-wave groups free their slot as soon as the walk ends (4 -> 1: -3.8 %)
   const uint32_t blocks = (n_packets + wpb - 1) / wpb;
   // 2 (default): XCD x takes runs x, x+8, ... of 2^run_log packets; 1: one contiguous eighth per XCD; 0: plain order
@@ -684,18 +787,18 @@ void launch_packet(hipStream_t st, const DeviceMesh& mesh, const GridParams& g, 
     const uint32_t code = 0x80000000u | run_log;
     if (mesh.stats != nullptr)
       hipLaunchKernelGGL((k_packet<GRID, MODE, SIGN, true>), dim3(grid_blocks), dim3(64 * wpb), 0, st, mesh, g,
-                         qs, perm, n_q, plane, out, err, n_packets, code, seed_in, seed_shift, seed_ny, seed_nz, seed_lattice);
+                         qs, perm, n_q, plane, out, err, n_packets, code, seed_in, seed_shift, seed_ny, seed_nz, seed_lattice, cut);
     else
       hipLaunchKernelGGL((k_packet<GRID, MODE, SIGN, false>), dim3(grid_blocks), dim3(64 * wpb), 0, st, mesh, g,
-                         qs, perm, n_q, plane, out, err, n_packets, code, seed_in, seed_shift, seed_ny, seed_nz, seed_lattice);
+                         qs, perm, n_q, plane, out, err, n_packets, code, seed_in, seed_shift, seed_ny, seed_nz, seed_lattice, cut);
     return;
   }
   if (mesh.stats != nullptr)   // M2S_STATS: the counting variant (a few SALU ops more per node)
     hipLaunchKernelGGL((k_packet<GRID, MODE, SIGN, true>), dim3(remap ? chunk * 8 : blocks), dim3(64 * wpb), 0, st, mesh, g,
-                       qs, perm, n_q, plane, out, err, n_packets, chunk, seed_in, seed_shift, seed_ny, seed_nz, seed_lattice);
+                       qs, perm, n_q, plane, out, err, n_packets, chunk, seed_in, seed_shift, seed_ny, seed_nz, seed_lattice, cut);
   else
     hipLaunchKernelGGL((k_packet<GRID, MODE, SIGN, false>), dim3(remap ? chunk * 8 : blocks), dim3(64 * wpb), 0, st, mesh, g,
-                       qs, perm, n_q, plane, out, err, n_packets, chunk, seed_in, seed_shift, seed_ny, seed_nz, seed_lattice);
+                       qs, perm, n_q, plane, out, err, n_packets, chunk, seed_in, seed_shift, seed_ny, seed_nz, seed_lattice, cut);
 }
 template <bool GRID, int MODE, int SIGN>
 void launch_brute(hipStream_t st, const DeviceMesh& mesh, const GridParams& g, const float* q, uint32_t n_q,
@@ -728,9 +831,14 @@ static GridParams coarse_level(const GridParams& fine, const uint32_t log2_strid
   return c;
 }
 
+static size_t cut_blocks(const GridParams& g, uint32_t log) {
+  const uint32_t nbx = bricks_along(g.xe - g.xb, g.bl[0]), nby = bricks_along(g.n[1], g.bl[1]), nbz = bricks_along(g.n[2], g.bl[2]);
+  return (size_t)bricks_along(nbx, log) * bricks_along(nby, log) * bricks_along(nbz, log);
+}
+
 size_t grid_distance_workspace_bytes(const GridParams& g) {
   const size_t bricks = (size_t)host_brick_count(g);
-  return bricks * 16 + bricks + 16384;
+  return bricks * 16 + bricks + 16384 + cut_blocks(g, 1) * CUT_WORDS * 4 + 1024;   // seeds + cut lists (the smallest blocks)
 }
 
 int launch_grid_distance(Arena& ws, hipStream_t st, const DeviceMesh& mesh, const GridParams& g, int mode,
@@ -774,13 +882,28 @@ int launch_grid_distance(Arena& ws, hipStream_t st, const DeviceMesh& mesh, cons
     s1ny = g1.n[1];
     s1nz = g1.n[2];
   }
-  if (ev_before_final) M2S_HIP_CHECK(hipEventRecord(ev_before_final, st));
-
   // Walk flavour: bricks that each meet MANY triangles (triangles much smaller than voxels) are better served by
   // independent per-lane walks.  Estimate: triangles per surface brick ~ T / (6 * bricks^(2/3)).
   static const int lane_env = getenv("M2S_LANE_WALK") ? atoi(getenv("M2S_LANE_WALK")) : -1;   // -1 auto, 0 never, 1 always
   const double surface_bricks = 6.0 * pow((double)packets, 2.0 / 3.0);
   const bool lane_walk = !brute && mesh.n_tris && (lane_env >= 0 ? lane_env == 1 : (double)mesh.n_tris > 60.0 * surface_bricks);   // measured crossover: 40 per brick favours the packet walk, 65 the lane walk
+  // cut lists: the top of the tree is walked once per block of 2^log bricks per axis (k_cut)
+  CutList cut = {nullptr, 0, 0, 0};
+  static const int cut_env = getenv("M2S_CUT") ? atoi(getenv("M2S_CUT")) : 1;   // block = 2^M2S_CUT bricks per axis (1..3); < 0 = off
+  if (!brute && !lane_walk && seed1 != nullptr && sh1 == 0 && cut_env >= 0 && packets >= 4096) {
+    const uint32_t log = (uint32_t)std::min(std::max(cut_env, 1), 3);
+    static const float emit_near = getenv("M2S_CUT_NEAR") ? (float)atof(getenv("M2S_CUT_NEAR")) : 2.0f;
+    static const float emit_far = getenv("M2S_CUT_FAR") ? (float)atof(getenv("M2S_CUT_FAR")) : 1.0f / 3.0f;
+    const uint32_t nbx = bricks_along(g.xe - g.xb, g.bl[0]), nby = bricks_along(g.n[1], g.bl[1]), nbz = bricks_along(g.n[2], g.bl[2]);
+    const uint32_t ncx = bricks_along(nbx, log), ncy = bricks_along(nby, log), ncz = bricks_along(nbz, log);
+    const size_t blocks = (size_t)ncx * ncy * ncz;
+    uint32_t* lists = ws.take<uint32_t>(blocks * CUT_WORDS);
+    if (!lists) { set_error("internal: cut-list workspace too small"); return M2S_ERR_HIP_INTERNAL; }
+    hipLaunchKernelGGL(k_cut, dim3((unsigned)((blocks + 255) / 256)), dim3(256), 0, st, mesh, g, seed1, s1ny, s1nz, log, ncx, ncy, ncz, lists, emit_near, emit_far);
+    cut = {lists, log, ncy, ncz};
+  }
+  if (ev_before_final) M2S_HIP_CHECK(hipEventRecord(ev_before_final, st));
+
   if (lane_walk) {
     const unsigned blocks = (packets + 3) / 4;
     if (mode == MODE_UNSIGNED && d_inside_plane)
@@ -794,13 +917,13 @@ int launch_grid_distance(Arena& ws, hipStream_t st, const DeviceMesh& mesh, cons
   }
   if (mode == MODE_UNSIGNED && d_inside_plane) {
     if (brute) launch_brute<true, MODE_UNSIGNED, SIGN_GRID_PLANE>(st, mesh, g, nullptr, 0, d_inside_plane, d_out, d_err, packets);
-    else launch_packet<true, MODE_UNSIGNED, SIGN_GRID_PLANE>(st, mesh, g, nullptr, nullptr, 0, d_inside_plane, d_out, d_err, packets, seed1, sh1, s1ny, s1nz);
+    else launch_packet<true, MODE_UNSIGNED, SIGN_GRID_PLANE>(st, mesh, g, nullptr, nullptr, 0, d_inside_plane, d_out, d_err, packets, seed1, sh1, s1ny, s1nz, nullptr, cut);
   } else if (mode == MODE_UNSIGNED) {
     if (brute) launch_brute<true, MODE_UNSIGNED, SIGN_NONE>(st, mesh, g, nullptr, 0, nullptr, d_out, d_err, packets);
-    else launch_packet<true, MODE_UNSIGNED, SIGN_NONE>(st, mesh, g, nullptr, nullptr, 0, nullptr, d_out, d_err, packets, seed1, sh1, s1ny, s1nz);
+    else launch_packet<true, MODE_UNSIGNED, SIGN_NONE>(st, mesh, g, nullptr, nullptr, 0, nullptr, d_out, d_err, packets, seed1, sh1, s1ny, s1nz, nullptr, cut);
   } else {
     if (brute) launch_brute<true, MODE_NORMAL_FOLD, SIGN_NONE>(st, mesh, g, nullptr, 0, nullptr, d_out, d_err, packets);
-    else launch_packet<true, MODE_NORMAL_FOLD, SIGN_NONE>(st, mesh, g, nullptr, nullptr, 0, nullptr, d_out, d_err, packets, seed1, sh1, s1ny, s1nz);
+    else launch_packet<true, MODE_NORMAL_FOLD, SIGN_NONE>(st, mesh, g, nullptr, nullptr, 0, nullptr, d_out, d_err, packets, seed1, sh1, s1ny, s1nz, nullptr, cut);
   }
   M2S_HIP_CHECK(hipGetLastError());
   return 0;
