@@ -552,32 +552,35 @@ __global__ __launch_bounds__(256) void k_cut(DeviceMesh mesh, GridParams g, cons
   }
   r_brick = sqrtf(r_brick) * 1.0001f;
   r_block = sqrtf(r_block) * 1.0001f;
-  // D: every voxel of every brick of the block is at most this far from the seed triangle of its own brick
-  // (the distance to a triangle is 1-Lipschitz: <= |voxel - brick centre| + distance(brick centre, triangle))
-  float D = 0.0f;
-  const uint32_t side = 1u << log;
-  for (uint32_t ix = 0; ix < side; ++ix)
-    for (uint32_t iy = 0; iy < side; ++iy)
-      for (uint32_t iz = 0; iz < side; ++iz) {
-        const uint32_t bk[3] = {c0[0] + ix, c0[1] + iy, c0[2] + iz};
-        if (bk[0] >= nb[0] || bk[1] >= nb[1] || bk[2] >= nb[2]) continue;
-        const uint32_t slot = min(seeds[(bk[0] * seed_ny + bk[1]) * seed_nz + bk[2]], mesh.n_tris - 1);
-        const TriRec& t = mesh.tris[slot];
-        float q[3];
-        for (int k = 0; k < 3; ++k)
-          q[k] = g.first[k] + ((float)(origin[k] + (bk[k] << g.bl[k])) + 0.5f * (float)((1u << g.bl[k]) - 1u)) * g.size[k];
-        const f3 a = mk3(t.ax, t.ay, t.az), bq = mk3(t.bx, t.by, t.bz), c = mk3(t.cx, t.cy, t.cz);
-        const TriEdges e = {mk3(t.abx, t.aby, t.abz), mk3(t.acx, t.acy, t.acz), mk3(t.bcx, t.bcy, t.bcz)};
-        float dmin = point_triangle_dist2(mk3(q[0], q[1], q[2]), a, bq, c, e, t.cls);   // what k_packet's seed evaluation finds at the brick centre
-        dmin = (dmin == dmin) ? sqrtf(dmin) : __builtin_inff();
-        D = fmaxf(D, r_brick + dmin * 1.0001f);
-      }
+  // Per brick of the block: its centre q, and R with   |voxel - q| <= r_brick,   distance(voxel, seed triangle of the
+  // brick) <= r_brick + distance(q, seed triangle) =: D   (the distance to a triangle is 1-Lipschitz), so a subtree X
+  // with bound(q, X) > D + r_brick (+ margins) holds nothing within the final minimum of any voxel of that brick.
+  // A subtree is dropped when that holds for every brick of the block.  (log is 1: at most 8 bricks.)
+  float qx[8], qy[8], qz[8], R2[8];
+  float Rmax = 0.0f;
   const float scale = fmaxf(mesh_scale(mesh), fmaxf(fabsf(centre[0]), fmaxf(fabsf(centre[1]), fabsf(centre[2]))) + r_block);
-  // the packet walk keeps a node while bound <= d * 1.00002 + slack (slack <= 4e-6 * scale + 2.5e-6): stay well above that
-  const float R = (D + r_block) * 1.0003f + 6.4e-5f * scale + 4.0e-5f;
-  const float R2 = R * R;                                    // inf: nothing is dropped
-  const float emit_radius = fmaxf(emit_near * r_block, R * emit_far);
-  const f3 cB = mk3(centre[0], centre[1], centre[2]);
+#pragma unroll
+  for (uint32_t i = 0; i < 8; ++i) {
+    const uint32_t bk[3] = {c0[0] + (i >> 2), c0[1] + ((i >> 1) & 1u), c0[2] + (i & 1u)};
+    qx[i] = qy[i] = qz[i] = 0.0f;
+    R2[i] = -1.0f;                                           // brick outside the grid: never keeps anything
+    if (bk[0] >= nb[0] || bk[1] >= nb[1] || bk[2] >= nb[2]) continue;
+    const uint32_t slot = min(seeds[(bk[0] * seed_ny + bk[1]) * seed_nz + bk[2]], mesh.n_tris - 1);
+    const TriRec& t = mesh.tris[slot];
+    float q[3];
+    for (int k = 0; k < 3; ++k)
+      q[k] = g.first[k] + ((float)(origin[k] + (bk[k] << g.bl[k])) + 0.5f * (float)((1u << g.bl[k]) - 1u)) * g.size[k];
+    const f3 a = mk3(t.ax, t.ay, t.az), bq = mk3(t.bx, t.by, t.bz), c = mk3(t.cx, t.cy, t.cz);
+    const TriEdges e = {mk3(t.abx, t.aby, t.abz), mk3(t.acx, t.acy, t.acz), mk3(t.bcx, t.bcy, t.bcz)};
+    float d = point_triangle_dist2(mk3(q[0], q[1], q[2]), a, bq, c, e, t.cls);   // what k_packet's seed evaluation finds at the brick centre
+    d = (d == d) ? sqrtf(d) : __builtin_inff();
+    // the packet walk keeps a node while bound <= d * 1.00002 + slack (slack <= 4e-6 * scale + 2.5e-6): stay well above that
+    const float R = (d * 1.0001f + 2.0f * r_brick) * 1.0003f + 6.4e-5f * scale + 4.0e-5f;
+    qx[i] = q[0]; qy[i] = q[1]; qz[i] = q[2];
+    R2[i] = R * R;                                           // inf: nothing is dropped
+    Rmax = fmaxf(Rmax, R);
+  }
+  const float emit_radius = fmaxf(emit_near * r_block, Rmax * emit_far);
 
   constexpr uint32_t NB = (uint32_t)sizeof(NodeExt);
   const uint32_t end = mesh.n_nodes * NB;
@@ -586,8 +589,10 @@ __global__ __launch_bounds__(256) void k_cut(DeviceMesh mesh, GridParams g, cons
   uint32_t off = 0;
   while (off < end) {
     const NodeExt nr = *reinterpret_cast<const NodeExt*>(reinterpret_cast<const char*>(mesh.ext) + off);
-    const float ed2 = ext_dist2(cB, nr);
-    if (ed2 > R2) { off = nr.skip; continue; }               // NaN keeps the node
+    bool keep = false;
+#pragma unroll
+    for (uint32_t i = 0; i < 8; ++i) keep |= !(ext_dist2(mk3(qx[i], qy[i], qz[i]), nr) > R2[i]);   // NaN keeps the node
+    if (!keep) { off = nr.skip; continue; }
     if (nr.tri >= 0 || fmaxf(nr.R, nr.half) <= emit_radius) {
       // keep this subtree: [off, skip).  Adjacent subtrees merge; past CUT_MAX ranges the last one grows over the gap
       if (n > 0 && (last_end == off || n == CUT_MAX)) last_end = nr.skip;
@@ -889,9 +894,11 @@ int launch_grid_distance(Arena& ws, hipStream_t st, const DeviceMesh& mesh, cons
   const bool lane_walk = !brute && mesh.n_tris && (lane_env >= 0 ? lane_env == 1 : (double)mesh.n_tris > 60.0 * surface_bricks);   // measured crossover: 40 per brick favours the packet walk, 65 the lane walk
   // cut lists: the top of the tree is walked once per block of 2^log bricks per axis (k_cut)
   CutList cut = {nullptr, 0, 0, 0};
-  static const int cut_env = getenv("M2S_CUT") ? atoi(getenv("M2S_CUT")) : 1;   // block = 2^M2S_CUT bricks per axis (1..3); < 0 = off
-  if (!brute && !lane_walk && seed1 != nullptr && sh1 == 0 && cut_env >= 0 && packets >= 4096) {
-    const uint32_t log = (uint32_t)std::min(std::max(cut_env, 1), 3);
+  // below ~4096 packets the extra launch costs more than it saves (read per call: the tests lower it to cover small grids)
+  const uint32_t cut_min_packets = getenv("M2S_CUT_MIN_PACKETS") ? (uint32_t)atoi(getenv("M2S_CUT_MIN_PACKETS")) : 4096u;
+  static const int cut_env = getenv("M2S_CUT") ? atoi(getenv("M2S_CUT")) : 1;   // 0 = off
+  if (!brute && !lane_walk && seed1 != nullptr && sh1 == 0 && cut_env > 0 && packets >= cut_min_packets) {
+    const uint32_t log = 1;   // k_cut holds the block's bricks in registers: 2 x 2 x 2
     static const float emit_near = getenv("M2S_CUT_NEAR") ? (float)atof(getenv("M2S_CUT_NEAR")) : 2.0f;
     static const float emit_far = getenv("M2S_CUT_FAR") ? (float)atof(getenv("M2S_CUT_FAR")) : 1.0f / 3.0f;
     const uint32_t nbx = bricks_along(g.xe - g.xb, g.bl[0]), nby = bricks_along(g.n[1], g.bl[1]), nbz = bricks_along(g.n[2], g.bl[2]);

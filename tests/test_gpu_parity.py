@@ -606,10 +606,21 @@ def test_fuzz_tree_walk_equals_brute_force(seed):
     if seed % 5 == 2:
         lo[0], hi[0] = hi[0], lo[0]         # negative cell size along x
     grid = Grid.from_bounding_box(lo, hi, counts)
-    for sign in (SignMethod.Raycast, SignMethod.Normal):
-        a = generate_grid_sdf(v, Topology.TriangleList(idx), grid, sign, algorithm=0)
-        b = generate_grid_sdf(v, Topology.TriangleList(idx), grid, sign, algorithm=1)
-        assert_bit_equal(a, b, f"grid seed {seed} {sign.name} nt {nt} scale {scale:.3g}")
+    import os
+    os.environ["M2S_CUT_MIN_PACKETS"] = "8"   # cut lists (k_cut) also on these small grids
+    try:
+        for sign in (SignMethod.Raycast, SignMethod.Normal):
+            a = generate_grid_sdf(v, Topology.TriangleList(idx), grid, sign, algorithm=0)
+            b = generate_grid_sdf(v, Topology.TriangleList(idx), grid, sign, algorithm=1)
+            assert_bit_equal(a, b, f"grid seed {seed} {sign.name} nt {nt} scale {scale:.3g}")
+            if seed % 2 == 0:                   # the same grid in x-slab pieces: per-piece seeds and cut lists
+                xs = sorted({0, counts[0]} | {int(x) for x in rng.integers(0, counts[0] + 1, 2)})
+                c = np.full(grid.get_total_cell_count(), np.nan, F)
+                for x0, x1 in zip(xs[:-1], xs[1:]):
+                    generate_grid_sdf(v, Topology.TriangleList(idx), grid, sign, x_slab=(x0, x1), out=c)
+                assert_bit_equal(c, b, f"grid pieces seed {seed} {sign.name}")
+    finally:
+        del os.environ["M2S_CUT_MIN_PACKETS"]
     q = (lo + rng.uniform(-0.3, 1.3, (20000, 3)) * (hi - lo)).astype(F)
     for am in (AccelerationMethod.RtreeBvh, AccelerationMethod.Rtree, AccelerationMethod.Bvh(SignMethod.Normal)):
         a = generate_sdf(v, Topology.TriangleList(idx), q, am, algorithm=0)
