@@ -894,8 +894,9 @@ int launch_grid_distance(Arena& ws, hipStream_t st, const DeviceMesh& mesh, cons
   const bool lane_walk = !brute && mesh.n_tris && (lane_env >= 0 ? lane_env == 1 : (double)mesh.n_tris > 60.0 * surface_bricks);   // measured crossover: 40 per brick favours the packet walk, 65 the lane walk
   // cut lists: the top of the tree is walked once per block of 2^log bricks per axis (k_cut)
   CutList cut = {nullptr, 0, 0, 0};
-  // below ~4096 packets the extra launch costs more than it saves (read per call: the tests lower it to cover small grids)
-  const uint32_t cut_min_packets = getenv("M2S_CUT_MIN_PACKETS") ? (uint32_t)atoi(getenv("M2S_CUT_MIN_PACKETS")) : 4096u;
+  // k_cut is a chain of dependent loads (0.17-0.24 ms whatever the grid); below ~100k packets it costs more than the
+  // shorter walks save (128^3: +0.15 ms).  Read per call: the tests lower it to cover small grids.
+  const uint32_t cut_min_packets = getenv("M2S_CUT_MIN_PACKETS") ? (uint32_t)atoi(getenv("M2S_CUT_MIN_PACKETS")) : 100000u;
   static const int cut_env = getenv("M2S_CUT") ? atoi(getenv("M2S_CUT")) : 1;   // 0 = off
   if (!brute && !lane_walk && seed1 != nullptr && sh1 == 0 && cut_env > 0 && packets >= cut_min_packets) {
     const uint32_t log = 1;   // k_cut holds the block's bricks in registers: 2 x 2 x 2

@@ -34,7 +34,8 @@ with open(sec, "w") as f:
     for title, name in (("other BASELINE configs, device resident", "configs.txt"),
                         ("drop-in (host pointer) calls, numpy in / numpy out, wall time", "host_calls.txt"),
                         ("one rank's work of an N-GPU, 4-chunk step, run alone on one GPU (no collectives; pieces on two alternating streams)", "slabs.txt"),
-                        ("the 512^3 grid computed in x-pieces of L layers, one after the other on one stream: sums of the per-piece phase times", "piece_size.txt")):
+                        ("the 512^3 grid computed in x-pieces of L layers, one after the other on one stream: sums of the per-piece phase times", "piece_size.txt"),
+                        ("low-poly mesh (suzanne, 968 triangles): large and small grids", "suzanne.txt")):
         pth = os.path.join(ROOT, "gpurun_out", name)
         if os.path.exists(pth):
             f.write(f"## {title}\n" + open(pth).read())
