@@ -27,6 +27,10 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# HIP multiplexes the streams of a process onto 4 hardware queues by default.  A rank of the sharded run uses torch's
+# stream, two piece streams and RCCL's: one more stream anywhere and two of them share a queue and serialise (measured:
+# +0.4 ms per step of an 8-GPU rank).  Must be set before the HIP runtime starts.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 

@@ -38,14 +38,23 @@ int fail(int code, const char* fmt, ...) {
   return code;
 }
 
+// HIP multiplexes a process's streams onto a few hardware queues (4 by default): every stream this library creates can
+// end up sharing a queue with one of the caller's and serialise work the caller meant to overlap (measured: the two
+// alternating piece streams of the sharded driver lost their overlap, 2.5 -> 3.0 ms per step, once the library held
+// two streams of its own).  So streams are created only when a call really needs them.
 int get_state(int device, DeviceState** out) {
   DeviceState& s = g_dev[device];
-  if (!s.stream) {
-    M2S_HIP_CHECK(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+  if (!s.h_err) {
     for (auto& e : s.ev) M2S_HIP_CHECK(hipEventCreate(&e));
     M2S_HIP_CHECK(hipHostMalloc((void**)&s.h_err, 64, hipHostMallocDefault));
   }
   *out = &s;
+  return 0;
+}
+
+static int own_stream(DeviceState& s, hipStream_t* out) {
+  if (!s.stream) M2S_HIP_CHECK(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+  *out = s.stream;
   return 0;
 }
 
@@ -121,7 +130,8 @@ int resolve_ctx(const m2s_opts* opts, CallCtx* c, DeviceState** st) {
   c->device = dev;
   int rc = get_state(dev, st);
   if (rc) return rc;
-  c->stream = (opts && (opts->stream || opts->stream_mode == 1)) ? (hipStream_t)opts->stream : (*st)->stream;
+  if (opts && (opts->stream || opts->stream_mode == 1)) c->stream = (hipStream_t)opts->stream;
+  else if ((rc = own_stream(**st, &c->stream)) != 0) return rc;
   return select_scratch(**st, c->stream);
 }
 
@@ -167,6 +177,30 @@ int stage_mesh(Arena& ws, const CallCtx& c, const float* vertices, size_t n_vert
   return 0;
 }
 
+// Stream the sign planes of this call are built on: the device's side stream (ordered after everything enqueued on the
+// caller's stream so far), or the caller's stream itself with M2S_SIGN_OVERLAP=0.
+static int sign_stream_begin(DeviceState& st, hipStream_t main, bool synchronous_call, hipStream_t* out) {
+  static const bool overlap = !(getenv("M2S_SIGN_OVERLAP") && atoi(getenv("M2S_SIGN_OVERLAP")) == 0);
+  st.planes_done = nullptr;
+  *out = main;
+  // asynchronous calls are the pieces of a caller who overlaps them on streams of its own: leave the hardware queues to those
+  if (!overlap || !synchronous_call) return 0;
+  if (!st.side_stream) {
+    M2S_HIP_CHECK(hipStreamCreateWithFlags(&st.side_stream, hipStreamNonBlocking));
+    M2S_HIP_CHECK(hipEventCreateWithFlags(&st.fork_ev, hipEventDisableTiming));
+  }
+  M2S_HIP_CHECK(hipEventRecord(st.fork_ev, main));
+  M2S_HIP_CHECK(hipStreamWaitEvent(st.side_stream, st.fork_ev, 0));
+  *out = st.side_stream;
+  return 0;
+}
+// Records ev[2] ("planes done") on the stream that built them; the dominant launch will wait for it if that was the side stream.
+static int sign_stream_end(DeviceState& st, hipStream_t main, hipStream_t used) {
+  M2S_HIP_CHECK(hipEventRecord(st.ev[2], used));
+  st.planes_done = used != main ? st.ev[2] : nullptr;
+  return 0;
+}
+
 int finish_call(const CallCtx& c, DeviceState& st, int* d_err, m2s_timings* t, size_t n_tris, size_t n_units,
                 bool had_sign, bool had_seed_event = false) {
   if (!c.sync) return M2S_OK;
@@ -178,7 +212,9 @@ int finish_call(const CallCtx& c, DeviceState& st, int* d_err, m2s_timings* t, s
     (void)hipEventElapsedTime(&b, st.ev[1], st.ev[2]);
     float sd = 0;
     if (had_seed_event) {
-      (void)hipEventElapsedTime(&sd, st.ev[2], st.ev[4]);
+      // planes beside the seed passes: the seed phase then runs from the end of the build (ev[1]) to the dominant launch,
+      // which also waits for the planes; sign_ms and seed_ms overlap and do not add up to the total
+      (void)hipEventElapsedTime(&sd, st.planes_done ? st.ev[1] : st.ev[2], st.ev[4]);
       (void)hipEventElapsedTime(&d, st.ev[4], st.ev[3]);
     } else {
       (void)hipEventElapsedTime(&d, st.ev[2], st.ev[3]);
@@ -214,7 +250,7 @@ int run_grid_distance(Arena& ws, const CallCtx& c, DeviceState& st, DeviceMesh m
     mesh.stats = d_stats;
   }
   int rc = launch_grid_distance(ws, c.stream, mesh, g, sign_method == M2S_SIGN_RAYCAST ? MODE_UNSIGNED : MODE_NORMAL_FOLD,
-                                plane, c.algorithm, d_out, d_err, st.ev[4]);
+                                plane, c.algorithm, d_out, d_err, st.ev[4], st.planes_done);
   if (rc) return rc;
   M2S_HIP_CHECK(hipEventRecord(st.ev[3], c.stream));
   if (d_stats) {
@@ -343,7 +379,7 @@ int run_grid_distance_to_host(Arena& ws, const CallCtx& c, DeviceState& st, cons
     gp.xb = g.xb + (uint32_t)(i * lpp);
     gp.xe = (uint32_t)std::min<uint64_t>(g.xe, gp.xb + lpp);
     ws.off = ws_mark;                                              // pieces run one after the other on c.stream: same scratch
-    rc = launch_grid_distance(ws, c.stream, mesh, gp, mode, plane, c.algorithm, d_slab, d_err, nullptr);
+    rc = launch_grid_distance(ws, c.stream, mesh, gp, mode, plane, c.algorithm, d_slab, d_err, nullptr, st.planes_done);
     if (rc) { cleanup(); return rc; }
     if (hipEventRecord(done[i], c.stream) != hipSuccess) { cleanup(); return fail(M2S_ERR_HIP, "hipEventRecord failed"); }
   }
@@ -634,11 +670,18 @@ int m2s_generate_grid_sdf(const float* vertices, size_t n_vertices, const void* 
   if (rc) return rc;
   M2S_HIP_CHECK(hipEventRecord(st->ev[1], c.stream));
   const uint32_t* plane = nullptr;
+  st->planes_done = nullptr;
   if (sign_method == M2S_SIGN_RAYCAST) {
-    rc = build_grid_sign_plane(ws, c.stream, mesh, g, &plane);
+    hipStream_t ss;
+    rc = sign_stream_begin(*st, c.stream, c.sync, &ss);
     if (rc) return rc;
+    rc = build_grid_sign_plane(ws, ss, mesh, g, &plane);
+    if (rc) return rc;
+    rc = sign_stream_end(*st, c.stream, ss);
+    if (rc) return rc;
+  } else {
+    M2S_HIP_CHECK(hipEventRecord(st->ev[2], c.stream));
   }
-  M2S_HIP_CHECK(hipEventRecord(st->ev[2], c.stream));
   if (c.mem_kind == M2S_MEM_HOST && !getenv("M2S_STATS")) {
     uint32_t pieces = 1;
     rc = run_grid_distance_to_host(ws, c, *st, mesh, g, sign_method, plane, d_slab, d_err, out + (size_t)xb * ny * nz, &pieces);
@@ -838,6 +881,7 @@ int m2s_mesh_generate_grid_sdf(m2s_mesh* m, const m2s_grid* grid, int sign_metho
   }
   M2S_HIP_CHECK(hipEventRecord(st->ev[0], c.stream));
   M2S_HIP_CHECK(hipEventRecord(st->ev[1], c.stream));
+  st->planes_done = nullptr;
   bool built_planes = false;
   const uint32_t* plane = nullptr;
   if (sign_method == M2S_SIGN_RAYCAST) {
@@ -857,21 +901,26 @@ int m2s_mesh_generate_grid_sdf(m2s_mesh* m, const m2s_grid* grid, int sign_metho
         }
       }
       Arena pw{m->plane_mem, m->plane_bytes, 0};
-      rc = build_grid_sign_plane(pw, c.stream, m->dm, g, &m->plane);
+      hipStream_t ss;
+      rc = sign_stream_begin(*st, c.stream, c.sync, &ss);
+      if (rc) return rc;
+      rc = build_grid_sign_plane(pw, ss, m->dm, g, &m->plane);
       if (rc) return rc;
       m->plane_grid = *grid;
       m->plane_valid = true;
       built_planes = true;
       if (!m->plane_ready) M2S_HIP_CHECK(hipEventCreateWithFlags(&m->plane_ready, hipEventDisableTiming));
-      M2S_HIP_CHECK(hipEventRecord(m->plane_ready, c.stream));
-      m->plane_stream = c.stream;
+      M2S_HIP_CHECK(hipEventRecord(m->plane_ready, ss));
+      m->plane_stream = ss;
+      rc = sign_stream_end(*st, c.stream, ss);   // this call's walk waits for ev[2]
+      if (rc) return rc;
     } else if (c.stream != m->plane_stream) {   // built (perhaps still being built) on another stream
       M2S_HIP_CHECK(hipStreamWaitEvent(c.stream, m->plane_ready, 0));
       m->multi_stream = true;
     }
     plane = m->plane;
   }
-  M2S_HIP_CHECK(hipEventRecord(st->ev[2], c.stream));
+  if (!built_planes) M2S_HIP_CHECK(hipEventRecord(st->ev[2], c.stream));
   if (c.mem_kind == M2S_MEM_HOST && !getenv("M2S_STATS")) {   // host result: x-pieces stream out while the next computes
     uint32_t pieces = 1;
     rc = run_grid_distance_to_host(ws, c, *st, m->dm, g, sign_method, plane, d_slab, d_err, out + (size_t)xb * ny * nz, &pieces);

@@ -28,6 +28,11 @@ struct DeviceState {
   uint64_t tick = 0;
   hipStream_t stream = nullptr;
   hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  // Raycast sign planes depend on the mesh only: they are built on `side_stream` while the caller's stream runs the seed
+  // passes and cut lists; the dominant launch waits for ev[2], which is then recorded on the side stream.
+  hipStream_t side_stream = nullptr;
+  hipEvent_t fork_ev = nullptr;
+  hipEvent_t planes_done = nullptr;   // ev[2] while a call's planes are in flight on the side stream, else nullptr
   int* h_err = nullptr;  // pinned
   char* spare_mesh = nullptr;  // last destroyed m2s_mesh block, recycled by the next m2s_mesh_create
   size_t spare_mesh_bytes = 0;

@@ -848,7 +848,7 @@ size_t grid_distance_workspace_bytes(const GridParams& g) {
 
 int launch_grid_distance(Arena& ws, hipStream_t st, const DeviceMesh& mesh, const GridParams& g, int mode,
                          const uint32_t* d_inside_plane, int algorithm, float* d_out, int* d_err,
-                         hipEvent_t ev_before_final) {
+                         hipEvent_t ev_before_final, hipEvent_t wait_before_final) {
   if (g.xe <= g.xb || g.n[1] == 0 || g.n[2] == 0) {
     if (ev_before_final) M2S_HIP_CHECK(hipEventRecord(ev_before_final, st));
     return 0;
@@ -910,6 +910,8 @@ int launch_grid_distance(Arena& ws, hipStream_t st, const DeviceMesh& mesh, cons
     hipLaunchKernelGGL(k_cut, dim3((unsigned)((blocks + 255) / 256)), dim3(256), 0, st, mesh, g, seed1, s1ny, s1nz, log, ncx, ncy, ncz, lists, emit_near, emit_far);
     cut = {lists, log, ncy, ncz};
   }
+  // the sign planes may have been built beside the seed passes, on another stream (capi.hip): the walk needs them
+  if (wait_before_final) M2S_HIP_CHECK(hipStreamWaitEvent(st, wait_before_final, 0));
   if (ev_before_final) M2S_HIP_CHECK(hipEventRecord(ev_before_final, st));
 
   if (lane_walk) {
