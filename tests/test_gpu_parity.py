@@ -619,13 +619,13 @@ def test_fuzz_tree_walk_equals_brute_force(seed):
                 for x0, x1 in zip(xs[:-1], xs[1:]):
                     generate_grid_sdf(v, Topology.TriangleList(idx), grid, sign, x_slab=(x0, x1), out=c)
                 assert_bit_equal(c, b, f"grid pieces seed {seed} {sign.name}")
+        q = (lo + rng.uniform(-0.3, 1.3, (20000, 3)) * (hi - lo)).astype(F)
+        for am in (AccelerationMethod.RtreeBvh, AccelerationMethod.Rtree, AccelerationMethod.Bvh(SignMethod.Normal)):
+            a = generate_sdf(v, Topology.TriangleList(idx), q, am, algorithm=0)
+            b = generate_sdf(v, Topology.TriangleList(idx), q, am, algorithm=1)
+            assert_bit_equal(a, b, f"queries seed {seed} accel {am.kind}")
     finally:
         del os.environ["M2S_CUT_MIN_PACKETS"]
-    q = (lo + rng.uniform(-0.3, 1.3, (20000, 3)) * (hi - lo)).astype(F)
-    for am in (AccelerationMethod.RtreeBvh, AccelerationMethod.Rtree, AccelerationMethod.Bvh(SignMethod.Normal)):
-        a = generate_sdf(v, Topology.TriangleList(idx), q, am, algorithm=0)
-        b = generate_sdf(v, Topology.TriangleList(idx), q, am, algorithm=1)
-        assert_bit_equal(a, b, f"queries seed {seed} accel {am.kind}")
 
 
 @pytest.mark.parametrize("counts", [[260, 9, 33], [7, 300, 5], [3, 6, 500], [64, 1, 64]])
