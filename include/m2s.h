@@ -21,7 +21,9 @@
  * heap-ordered label propagation whose result depends on the thread count and is >= this
  * minimum on <0.5% of cells; see DESIGN.md "Exact vs propagation".)
  *
- * Threading: synchronous and re-entrant; calls on one device are serialised internally.
+ * Threading: synchronous and re-entrant; the entry points are serialised internally (one mutex), the work they
+ * enqueue is not: asynchronous calls (m2s_opts.synchronous = 0) on different streams use separate scratch blocks and
+ * may overlap on the device.
  */
 #ifndef M2S_H
 #define M2S_H
