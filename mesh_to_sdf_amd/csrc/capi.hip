@@ -250,7 +250,7 @@ int run_grid_distance(Arena& ws, const CallCtx& c, DeviceState& st, DeviceMesh m
     mesh.stats = d_stats;
   }
   int rc = launch_grid_distance(ws, c.stream, mesh, g, sign_method == M2S_SIGN_RAYCAST ? MODE_UNSIGNED : MODE_NORMAL_FOLD,
-                                plane, c.algorithm, d_out, d_err, st.ev[4], st.planes_done);
+                                plane, c.algorithm, d_out, d_err, st.ev[4], st.planes_done, !c.sync);
   if (rc) return rc;
   M2S_HIP_CHECK(hipEventRecord(st.ev[3], c.stream));
   if (d_stats) {

@@ -187,7 +187,7 @@ size_t grid_distance_workspace_bytes(const GridParams& g);
 // Records `ev_before_final` (if non-null) between the seed passes and the final k_packet launch.
 int launch_grid_distance(Arena& ws, hipStream_t st, const DeviceMesh& mesh, const GridParams& g, int mode,
                          const uint32_t* d_inside_plane, int algorithm, float* d_out, int* d_err,
-                         hipEvent_t ev_before_final, hipEvent_t wait_before_final = nullptr);
+                         hipEvent_t ev_before_final, hipEvent_t wait_before_final = nullptr, bool pipelined = false);
 size_t query_workspace_bytes(size_t n_q);
 int launch_query_distance(Arena& ws, hipStream_t st, const DeviceMesh& mesh, const float* d_queries, size_t n_q,
                           int mode, int sign_src, int algorithm, float* d_out, int* d_err);

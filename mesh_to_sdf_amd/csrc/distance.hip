@@ -848,7 +848,7 @@ size_t grid_distance_workspace_bytes(const GridParams& g) {
 
 int launch_grid_distance(Arena& ws, hipStream_t st, const DeviceMesh& mesh, const GridParams& g, int mode,
                          const uint32_t* d_inside_plane, int algorithm, float* d_out, int* d_err,
-                         hipEvent_t ev_before_final, hipEvent_t wait_before_final) {
+                         hipEvent_t ev_before_final, hipEvent_t wait_before_final, bool pipelined) {
   if (g.xe <= g.xb || g.n[1] == 0 || g.n[2] == 0) {
     if (ev_before_final) M2S_HIP_CHECK(hipEventRecord(ev_before_final, st));
     return 0;
@@ -896,7 +896,9 @@ int launch_grid_distance(Arena& ws, hipStream_t st, const DeviceMesh& mesh, cons
   CutList cut = {nullptr, 0, 0, 0};
   // k_cut is a chain of dependent loads (0.17-0.24 ms whatever the grid); below ~100k packets it costs more than the
   // shorter walks save (128^3: +0.15 ms).  Read per call: the tests lower it to cover small grids.
-  const uint32_t cut_min_packets = getenv("M2S_CUT_MIN_PACKETS") ? (uint32_t)atoi(getenv("M2S_CUT_MIN_PACKETS")) : 100000u;
+  // (asynchronous calls are the pieces of a caller who pipelines them on two streams: k_cut then runs under the previous
+  // piece's walk and pays from about half that size)
+  const uint32_t cut_min_packets = getenv("M2S_CUT_MIN_PACKETS") ? (uint32_t)atoi(getenv("M2S_CUT_MIN_PACKETS")) : (pipelined ? 50000u : 100000u);
   static const int cut_env = getenv("M2S_CUT") ? atoi(getenv("M2S_CUT")) : 1;   // 0 = off
   if (!brute && !lane_walk && seed1 != nullptr && sh1 == 0 && cut_env > 0 && packets >= cut_min_packets) {
     const uint32_t log = 1;   // k_cut holds the block's bricks in registers: 2 x 2 x 2
