@@ -302,6 +302,7 @@ int fill_grid_params(const m2s_grid* grid, const m2s_opts* opts, GridParams* g, 
   static const bool cube_only = getenv("M2S_BRICK_CUBE") && atoi(getenv("M2S_BRICK_CUBE")) != 0;
   if (cube_only) g->bl[0] = g->bl[1] = g->bl[2] = 2;
   else choose_brick_shape(g->size, g->bl);
+  set_super_brick_magic(*g);
   *slab_cells = (size_t)(xe - xb) * gy * gz;
   return 0;
 }

@@ -103,10 +103,25 @@ struct GridParams {
   // brick is as close to a cube in WORLD space as powers of two allow (anisotropic cell sizes): the walk's cost
   // grows with the brick's diameter, not its voxel count.
   uint32_t bl[3];
+  // ceil(2^32 / d) for d = super-bricks along z and along y (distance.hip brick_coords divides a packet's super-brick
+  // index by them: one multiply-high instead of a 30-instruction u32 division per wave); 0 = divide (d == 1, or a grid so
+  // large that the product could be off by one)
+  uint32_t sz_magic, sy_magic;
   uint32_t pad_;
 };
 
 // Brick shape for a cell size: minimises max/min of the world extents |size[k]| * 2^bl[k] over all splits of 6.
+// Exact for n * d < 2^32 (Granlund-Montgomery with a 32-bit multiplier): q = mulhi(n, ceil(2^32 / d)).
+inline void set_super_brick_magic(GridParams& g) {
+  const uint64_t nbx = (g.n[0] + (1u << g.bl[0]) - 1u) >> g.bl[0], nby = (g.n[1] + (1u << g.bl[1]) - 1u) >> g.bl[1],
+                 nbz = (g.n[2] + (1u << g.bl[2]) - 1u) >> g.bl[2];
+  const uint64_t sy = (nby + 7) >> 3, sz = (nbz + 7) >> 3, n_max = (nbx + 1) * sy * sz;   // super-brick indices stay below this
+  const uint64_t d_max = sy > sz ? sy : sz;
+  const bool safe = n_max * d_max < (1ull << 32);
+  g.sz_magic = (safe && sz > 1) ? (uint32_t)(((1ull << 32) + sz - 1) / sz) : 0u;
+  g.sy_magic = (safe && sy > 1) ? (uint32_t)(((1ull << 32) + sy - 1) / sy) : 0u;
+}
+
 inline void choose_brick_shape(const float size[3], uint32_t bl[3]) {
   bl[0] = bl[1] = bl[2] = 2;
   float s[3];

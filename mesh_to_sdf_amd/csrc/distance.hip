@@ -76,12 +76,16 @@ __host__ __device__ __forceinline__ uint32_t super_brick_xlog(uint32_t nbx) {
   }
   return 0;
 }
+__device__ __forceinline__ uint32_t div_magic(uint32_t n, uint32_t d, uint32_t magic) {
+  return magic ? __umulhi(n, magic) : n / d;   // common.h set_super_brick_magic
+}
 __device__ __forceinline__ void brick_coords(const GridParams& g, uint32_t brick, uint32_t* bx, uint32_t* by, uint32_t* bz) {
   const uint32_t nby = bricks_along(g.n[1], g.bl[1]), nbz = bricks_along(g.n[2], g.bl[2]);
   const uint32_t sy = (nby + 7) >> 3, sz = (nbz + 7) >> 3;
   const uint32_t xl = super_brick_xlog(bricks_along(g.xe - g.xb, g.bl[0]));
   const uint32_t sb = brick >> (6 + xl), in = brick & ((64u << xl) - 1u);   // super-brick index, position inside (padded grid)
-  const uint32_t sbz = sb % sz, sby = (sb / sz) % sy, sbx = sb / (sz * sy);
+  const uint32_t t = div_magic(sb, sz, g.sz_magic), sbz = sb - t * sz;
+  const uint32_t sbx = div_magic(t, sy, g.sy_magic), sby = t - sbx * sy;
   *bx = (sbx << xl) + (in >> 6);
   *by = sby * 8 + ((in >> 3) & 7u);
   *bz = sbz * 8 + (in & 7u);
