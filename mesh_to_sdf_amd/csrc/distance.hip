@@ -158,6 +158,41 @@ __device__ __forceinline__ void eval_triangle(Best<MODE>& best, f3 p, const TriR
   }
 }
 
+// eval_triangle for the leaf triangles of the packet walk.  `reach` = this lane's pre-test bound reaches the triangle;
+// a lane without it cannot be improved (that is what the pre-test's margin guarantees) and is left alone.  If every lane
+// that is reached lies in a VERTEX region of the triangle (geo.rs:97-111 — 40 % of the evaluations on the benchmark: the
+// fan of triangles around a voxel's nearest vertex, all at exactly the same distance), the closest point is that vertex
+// and the edge / interior half of the computation (selects, the division, the reconstruction) is skipped for the wave.
+// Same arithmetic for the lanes that count, so the result is bit-identical.
+template <int MODE>
+__device__ __forceinline__ void eval_triangle_leaf(Best<MODE>& best, f3 p, const TriRec& tr, bool reach) {
+  if (MODE == MODE_NEAREST_NORMAL || tr.cls != TRI_REGULAR) { eval_triangle<MODE>(best, p, tr); return; }
+  const f3 a = mk3(tr.ax, tr.ay, tr.az), b = mk3(tr.bx, tr.by, tr.bz), c = mk3(tr.cx, tr.cy, tr.cz);
+  const f3 ab = mk3(tr.abx, tr.aby, tr.abz), ac = mk3(tr.acx, tr.acy, tr.acz);
+  const RegularHead h = closest_point_regular_head(p, a, b, c, ab, ac);
+  const bool vertex = h.rA | h.rB | h.rC;
+  f3 q;
+  bool valid = true;
+  if (__ballot(reach & !vertex) == 0ull) {
+    q = closest_point_regular_vertex(h, a, b, c);
+    valid = vertex;                      // the other lanes are not reached: nothing to learn for them
+  } else {
+    q = closest_point_regular_tail(h, a, b, c, ab, ac, mk3(tr.bcx, tr.bcy, tr.bcz));
+  }
+  const f3 d = sub3(p, q);
+  float d2 = dot3(d, d);
+  if (MODE == MODE_UNSIGNED) {
+    d2 = valid ? d2 : __builtin_inff();
+    best.d2 = fminf(best.d2, d2);  // f32::min drops a NaN operand (default.rs:47)
+  } else {   // MODE_NORMAL_FOLD
+    const bool positive = dot3(d, mk3(tr.nrx, tr.nry, tr.nrz)) > 0.0f;
+    best.nan |= valid & !(d2 == d2);  // the reference panics: "NaN distance" (lib.rs:257)
+    d2 = valid ? d2 : __builtin_inff();
+    best.d2 = fminf(best.d2, d2);
+    if (positive) best.d2pos = fminf(best.d2pos, d2);
+  }
+}
+
 template <int MODE>
 __device__ __forceinline__ float finish(const Best<MODE>& best, bool negate_unsigned) {
   if (MODE == MODE_UNSIGNED) {
@@ -364,10 +399,11 @@ __global__ __launch_bounds__(256) void k_packet(DeviceMesh mesh, GridParams g, c
         for (uint32_t k = 0; k < cnt; ++k) {
           if (STATS) ++st_ext;
           const TriPlanes tp = record_at(mesh.planes, (uint32_t)nr.tri + k);   // scalar: small, needed for every leaf triangle
-          if (__ballot(!(planes_dist2(p, tp) > thr)) != 0ull) {   // some lane's bound reaches the triangle itself
+          const bool reach = !(planes_dist2(p, tp) > thr);
+          if (__ballot(reach) != 0ull) {   // some lane's bound reaches the triangle itself
             if (STATS) ++st_leaf;
             const TriRec tr = record_at_vec(mesh.tris, (uint32_t)nr.tri + k);
-            eval_triangle<MODE>(best, p, tr);
+            eval_triangle_leaf<MODE>(best, p, tr, reach);
             thr = prune_bound(best.d2, slack);
           }
         }

@@ -62,20 +62,34 @@ M2S_HD f3 closest_point_segment(f3 p, f3 a, f3 ab /* = b.sub(a) */) {
 
 // geo.rs:90-137 for a non-degenerate-class triangle.  One IEEE division per call, as in the
 // reference (each region divides once; the numerator / denominator pair is selected first).
-M2S_HD f3 closest_point_regular(f3 p, f3 a, f3 b, f3 c, f3 ab, f3 ac, f3 bc) {
+// In two halves, so that the packet walk can stop after the first one when every lane that still matters lies in a
+// vertex region (distance.hip eval_triangle_leaf): the head is the six dot products and the three vertex-region tests
+// the reference makes first (geo.rs:97, 104, 111), the tail the edge / interior regions.
+struct RegularHead {
+  float d1, d2, d3, d4, d5, d6;
+  bool rA, rB, rC;
+};
+M2S_HD RegularHead closest_point_regular_head(f3 p, f3 a, f3 b, f3 c, f3 ab, f3 ac) {
+  RegularHead h;
   const f3 ap = sub3(p, a);
-  const float d1 = dot3(ab, ap);
-  const float d2 = dot3(ac, ap);
+  h.d1 = dot3(ab, ap);
+  h.d2 = dot3(ac, ap);
   const f3 bp = sub3(p, b);
-  const float d3 = dot3(ab, bp);
-  const float d4 = dot3(ac, bp);
+  h.d3 = dot3(ab, bp);
+  h.d4 = dot3(ac, bp);
   const f3 cp = sub3(p, c);
-  const float d5 = dot3(ab, cp);
-  const float d6 = dot3(ac, cp);
-
-  const bool rA = (d1 <= 0.0f) & (d2 <= 0.0f);                       // geo.rs:97
-  const bool rB = (d3 >= 0.0f) & (d4 <= d3);                         // geo.rs:104
-  const bool rC = (d6 >= 0.0f) & (d5 <= d6);                         // geo.rs:111
+  h.d5 = dot3(ab, cp);
+  h.d6 = dot3(ac, cp);
+  h.rA = (h.d1 <= 0.0f) & (h.d2 <= 0.0f);                           // geo.rs:97
+  h.rB = (h.d3 >= 0.0f) & (h.d4 <= h.d3);                           // geo.rs:104
+  h.rC = (h.d6 >= 0.0f) & (h.d5 <= h.d6);                           // geo.rs:111
+  return h;
+}
+// The vertex a lane's closest point is, for lanes with rA | rB | rC (same precedence as the full selection below).
+M2S_HD f3 closest_point_regular_vertex(const RegularHead& h, f3 a, f3 b, f3 c) { return sel3(h.rA, a, sel3(h.rB, b, c)); }
+M2S_HD f3 closest_point_regular_tail(const RegularHead& h, f3 a, f3 b, f3 c, f3 ab, f3 ac, f3 bc) {
+  const float d1 = h.d1, d2 = h.d2, d3 = h.d3, d4 = h.d4, d5 = h.d5, d6 = h.d6;
+  const bool rA = h.rA, rB = h.rB, rC = h.rC;
   const float vc = d1 * d4 - d3 * d2;                                // geo.rs:115
   const bool rAB = (vc <= 0.0f) & (d1 >= 0.0f) & (d3 <= 0.0f);       // geo.rs:116
   const float vb = d5 * d2 - d1 * d6;                                // geo.rs:121
@@ -103,6 +117,9 @@ M2S_HD f3 closest_point_regular(f3 p, f3 a, f3 b, f3 c, f3 ab, f3 ac, f3 bc) {
   q = sel3(rB, b, q);
   q = sel3(rA, a, q);
   return q;
+}
+M2S_HD f3 closest_point_regular(f3 p, f3 a, f3 b, f3 c, f3 ab, f3 ac, f3 bc) {
+  return closest_point_regular_tail(closest_point_regular_head(p, a, b, c, ab, ac), a, b, c, ab, ac, bc);
 }
 
 // Closest point for any triangle class (cls is wave-uniform: one triangle per wave step).
