@@ -199,6 +199,19 @@ int build_grid_sign_plane(Arena& ws, hipStream_t st, const DeviceMesh& mesh, con
 
 // distance.hip
 size_t grid_distance_workspace_bytes(const GridParams& g);
+// What a grid walk needs besides the mesh: the seed lattice and the cut lists of a slab (device pointers into the call's arena).
+struct GridWalkPlan {
+  const uint32_t* seeds = nullptr;
+  uint32_t seed_shift = 0, seed_ny = 0, seed_nz = 0;
+  const uint32_t* cut_lists = nullptr;
+  uint32_t cut_log = 0, cut_ny = 0, cut_nz = 0;
+  bool lane_walk = false;
+};
+int prepare_grid_walk(Arena& ws, hipStream_t st, const DeviceMesh& mesh, const GridParams& g, int algorithm, bool pipelined,
+                      GridWalkPlan* plan);
+// `g` may be an x-piece of the slab the plan was prepared for, starting bx_off bricks into it (a multiple of 2 bricks).
+int launch_grid_walk(hipStream_t st, const DeviceMesh& mesh, const GridParams& g, int mode, const uint32_t* d_inside_plane,
+                     int algorithm, const GridWalkPlan& plan, uint32_t bx_off, float* d_out, int* d_err);
 // Records `ev_before_final` (if non-null) between the seed passes and the final k_packet launch.
 int launch_grid_distance(Arena& ws, hipStream_t st, const DeviceMesh& mesh, const GridParams& g, int mode,
                          const uint32_t* d_inside_plane, int algorithm, float* d_out, int* d_err,

@@ -287,6 +287,8 @@ constexpr uint32_t CUT_MAX = M2S_CUT_MAX, CUT_WORDS = 2 * (M2S_CUT_MAX + 1);   /
 struct CutList {
   const uint32_t* lists;   // CUT_WORDS words per block, nullptr: walk the whole tree
   uint32_t log, ny, nz;    // bricks per block per axis = 2^log; blocks along y and z
+  uint32_t bx_off;         // grid: this launch covers a piece of the slab the seed lattice and the lists were built for,
+                           // starting bx_off bricks into it along x (a multiple of 2^log)
 };
 
 // ---- k_packet -------------------------------------------------------------------------------
@@ -333,7 +335,7 @@ __global__ __launch_bounds__(256) void k_packet(DeviceMesh mesh, GridParams g, c
       // seed: a triangle near this packet's centre, from the seed pass
       uint32_t sidx = packet;
       if (GRID) {  // 2^seed_shift bricks per axis share one seed point
-        sidx = ((vox.bx >> seed_shift) * seed_ny + (vox.by >> seed_shift)) * seed_nz + (vox.bz >> seed_shift);
+        sidx = (((vox.bx + cut.bx_off) >> seed_shift) * seed_ny + (vox.by >> seed_shift)) * seed_nz + (vox.bz >> seed_shift);
       } else {     // generic queries: the lattice cell that holds the packet's first point
         const GridParams L = *seed_lattice;
         const float q0[3] = {__shfl(p.x, 0), __shfl(p.y, 0), __shfl(p.z, 0)};
@@ -381,7 +383,7 @@ __global__ __launch_bounds__(256) void k_packet(DeviceMesh mesh, GridParams g, c
     const uint32_t* cl = nullptr;
     uint32_t n_ranges = 1;
     if (GRID && cut.lists != nullptr) {
-      const uint32_t cb = __builtin_amdgcn_readfirstlane(((vox.bx >> cut.log) * cut.ny + (vox.by >> cut.log)) * cut.nz + (vox.bz >> cut.log));
+      const uint32_t cb = __builtin_amdgcn_readfirstlane((((vox.bx + cut.bx_off) >> cut.log) * cut.ny + (vox.by >> cut.log)) * cut.nz + (vox.bz >> cut.log));
       cl = cut.lists + (size_t)cb * CUT_WORDS;
       n_ranges = cl[0];
     }
@@ -450,7 +452,7 @@ __global__ __launch_bounds__(256) void k_packet(DeviceMesh mesh, GridParams g, c
 template <int MODE, int SIGN>
 __global__ __launch_bounds__(256) void k_lane(DeviceMesh mesh, GridParams g, const uint32_t* __restrict__ plane,
                                               float* __restrict__ out, int* __restrict__ err, uint32_t n_packets,
-                                              const uint32_t* __restrict__ seed_in, uint32_t seed_ny, uint32_t seed_nz) {
+                                              const uint32_t* __restrict__ seed_in, uint32_t seed_ny, uint32_t seed_nz, uint32_t bx_off) {
   const int lane = threadIdx.x & 63;
   const uint32_t packet = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (packet >= n_packets) return;
@@ -464,7 +466,7 @@ __global__ __launch_bounds__(256) void k_lane(DeviceMesh mesh, GridParams g, con
     const float scale = fmaxf(mesh_scale(mesh), fmaxf(fabsf(p.x), fmaxf(fabsf(p.y), fabsf(p.z))));
     const float slack = 4.0e-6f * scale + (MODE == MODE_NORMAL_FOLD ? 2.5e-6f : 0.0f);
     uint32_t slot = 0;
-    if (seed_in != nullptr) slot = min(seed_in[(vox.bx * seed_ny + vox.by) * seed_nz + vox.bz], mesh.n_tris - 1);
+    if (seed_in != nullptr) slot = min(seed_in[((vox.bx + bx_off) * seed_ny + vox.by) * seed_nz + vox.bz], mesh.n_tris - 1);
     eval_triangle<MODE>(best, p, mesh.tris[slot]);
     float thr = prune_bound(best.d2, slack);
     constexpr uint32_t NB = (uint32_t)sizeof(NodeExt);
@@ -817,7 +819,7 @@ template <bool GRID, int MODE, int SIGN>
 void launch_packet(hipStream_t st, const DeviceMesh& mesh, const GridParams& g, const float4* qs, const uint32_t* perm,
                    uint32_t n_q, const uint32_t* plane, float* out, int* err, uint32_t n_packets,
                    const uint32_t* seed_in = nullptr, uint32_t seed_shift = 0, uint32_t seed_ny = 0,
-                   uint32_t seed_nz = 0, const GridParams* seed_lattice = nullptr, CutList cut = {nullptr, 0, 0, 0}) {
+                   uint32_t seed_nz = 0, const GridParams* seed_lattice = nullptr, CutList cut = {nullptr, 0, 0, 0, 0}) {
   static const uint32_t wpb = getenv("M2S_WPB") ? std::min(4u, std::max(1u, (uint32_t)atoi(getenv("M2S_WPB")))) : 1u;   // waves (packets) per workgroup: single-wave groups free their slot as soon as the walk ends (4 -> 1: -3.8 %)
   const uint32_t blocks = (n_packets + wpb - 1) / wpb;
   // 2 (default): XCD x takes runs x, x+8, ... of 2^run_log packets; 1: one contiguous eighth per XCD; 0: plain order
@@ -886,13 +888,12 @@ size_t grid_distance_workspace_bytes(const GridParams& g) {
   return bricks * 16 + bricks + 16384 + cut_blocks(g, 1) * CUT_WORDS * 4 + 1024;   // seeds + cut lists (the smallest blocks)
 }
 
-int launch_grid_distance(Arena& ws, hipStream_t st, const DeviceMesh& mesh, const GridParams& g, int mode,
-                         const uint32_t* d_inside_plane, int algorithm, float* d_out, int* d_err,
-                         hipEvent_t ev_before_final, hipEvent_t wait_before_final, bool pipelined) {
-  if (g.xe <= g.xb || g.n[1] == 0 || g.n[2] == 0) {
-    if (ev_before_final) M2S_HIP_CHECK(hipEventRecord(ev_before_final, st));
-    return 0;
-  }
+// Seeds and cut lists for the slab [g.xb, g.xe) (everything a walk needs besides the mesh); `launch_grid_walk` then
+// walks the slab, or any x-piece of it that starts on a block boundary.
+int prepare_grid_walk(Arena& ws, hipStream_t st, const DeviceMesh& mesh, const GridParams& g, int algorithm, bool pipelined,
+                      GridWalkPlan* plan) {
+  *plan = GridWalkPlan{};
+  if (g.xe <= g.xb || g.n[1] == 0 || g.n[2] == 0) return 0;
   const uint32_t packets = host_brick_count(g);
   const bool brute = algorithm == 1;
 
@@ -933,7 +934,7 @@ int launch_grid_distance(Arena& ws, hipStream_t st, const DeviceMesh& mesh, cons
   const double surface_bricks = 6.0 * pow((double)packets, 2.0 / 3.0);
   const bool lane_walk = !brute && mesh.n_tris && (lane_env >= 0 ? lane_env == 1 : (double)mesh.n_tris > 60.0 * surface_bricks);   // measured crossover: 40 per brick favours the packet walk, 65 the lane walk
   // cut lists: the top of the tree is walked once per block of 2^log bricks per axis (k_cut)
-  CutList cut = {nullptr, 0, 0, 0};
+  CutList cut = {nullptr, 0, 0, 0, 0};
   // k_cut is a chain of dependent loads (0.17-0.24 ms whatever the grid); below ~100k packets it costs more than the
   // shorter walks save (128^3: +0.15 ms).  Read per call: the tests lower it to cover small grids.
   // (asynchronous calls are the pieces of a caller who pipelines them on two streams: k_cut then runs under the previous
@@ -950,20 +951,30 @@ int launch_grid_distance(Arena& ws, hipStream_t st, const DeviceMesh& mesh, cons
     uint32_t* lists = ws.take<uint32_t>(blocks * CUT_WORDS);
     if (!lists) { set_error("internal: cut-list workspace too small"); return M2S_ERR_HIP_INTERNAL; }
     hipLaunchKernelGGL(k_cut, dim3((unsigned)((blocks + 255) / 256)), dim3(256), 0, st, mesh, g, seed1, s1ny, s1nz, log, ncx, ncy, ncz, lists, emit_near, emit_far);
-    cut = {lists, log, ncy, ncz};
+    cut = {lists, log, ncy, ncz, 0};
   }
-  // the sign planes may have been built beside the seed passes, on another stream (capi.hip): the walk needs them
-  if (wait_before_final) M2S_HIP_CHECK(hipStreamWaitEvent(st, wait_before_final, 0));
-  if (ev_before_final) M2S_HIP_CHECK(hipEventRecord(ev_before_final, st));
+  plan->seeds = seed1; plan->seed_shift = sh1; plan->seed_ny = s1ny; plan->seed_nz = s1nz;
+  plan->cut_lists = cut.lists; plan->cut_log = cut.log; plan->cut_ny = cut.ny; plan->cut_nz = cut.nz;
+  plan->lane_walk = lane_walk;
+  return 0;
+}
 
-  if (lane_walk) {
+int launch_grid_walk(hipStream_t st, const DeviceMesh& mesh, const GridParams& g, int mode, const uint32_t* d_inside_plane,
+                     int algorithm, const GridWalkPlan& plan, uint32_t bx_off, float* d_out, int* d_err) {
+  if (g.xe <= g.xb || g.n[1] == 0 || g.n[2] == 0) return 0;
+  const uint32_t packets = host_brick_count(g);
+  const bool brute = algorithm == 1;
+  const uint32_t* seed1 = plan.seeds;
+  const uint32_t sh1 = plan.seed_shift, s1ny = plan.seed_ny, s1nz = plan.seed_nz;
+  const CutList cut = {plan.cut_lists, plan.cut_log, plan.cut_ny, plan.cut_nz, bx_off};
+  if (plan.lane_walk) {
     const unsigned blocks = (packets + 3) / 4;
     if (mode == MODE_UNSIGNED && d_inside_plane)
-      hipLaunchKernelGGL((k_lane<MODE_UNSIGNED, SIGN_GRID_PLANE>), dim3(blocks), dim3(256), 0, st, mesh, g, d_inside_plane, d_out, d_err, packets, seed1, s1ny, s1nz);
+      hipLaunchKernelGGL((k_lane<MODE_UNSIGNED, SIGN_GRID_PLANE>), dim3(blocks), dim3(256), 0, st, mesh, g, d_inside_plane, d_out, d_err, packets, seed1, s1ny, s1nz, bx_off);
     else if (mode == MODE_UNSIGNED)
-      hipLaunchKernelGGL((k_lane<MODE_UNSIGNED, SIGN_NONE>), dim3(blocks), dim3(256), 0, st, mesh, g, nullptr, d_out, d_err, packets, seed1, s1ny, s1nz);
+      hipLaunchKernelGGL((k_lane<MODE_UNSIGNED, SIGN_NONE>), dim3(blocks), dim3(256), 0, st, mesh, g, nullptr, d_out, d_err, packets, seed1, s1ny, s1nz, bx_off);
     else
-      hipLaunchKernelGGL((k_lane<MODE_NORMAL_FOLD, SIGN_NONE>), dim3(blocks), dim3(256), 0, st, mesh, g, nullptr, d_out, d_err, packets, seed1, s1ny, s1nz);
+      hipLaunchKernelGGL((k_lane<MODE_NORMAL_FOLD, SIGN_NONE>), dim3(blocks), dim3(256), 0, st, mesh, g, nullptr, d_out, d_err, packets, seed1, s1ny, s1nz, bx_off);
     M2S_HIP_CHECK(hipGetLastError());
     return 0;
   }
@@ -979,6 +990,18 @@ int launch_grid_distance(Arena& ws, hipStream_t st, const DeviceMesh& mesh, cons
   }
   M2S_HIP_CHECK(hipGetLastError());
   return 0;
+}
+
+int launch_grid_distance(Arena& ws, hipStream_t st, const DeviceMesh& mesh, const GridParams& g, int mode,
+                         const uint32_t* d_inside_plane, int algorithm, float* d_out, int* d_err,
+                         hipEvent_t ev_before_final, hipEvent_t wait_before_final, bool pipelined) {
+  GridWalkPlan plan;
+  int rc = prepare_grid_walk(ws, st, mesh, g, algorithm, pipelined, &plan);
+  if (rc) return rc;
+  // the sign planes may have been built beside the seed passes, on another stream (capi.hip): the walk needs them
+  if (wait_before_final) M2S_HIP_CHECK(hipStreamWaitEvent(st, wait_before_final, 0));
+  if (ev_before_final) M2S_HIP_CHECK(hipEventRecord(ev_before_final, st));
+  return launch_grid_walk(st, mesh, g, mode, d_inside_plane, algorithm, plan, 0, d_out, d_err);
 }
 
 size_t query_workspace_bytes(size_t n_q) {

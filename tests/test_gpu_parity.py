@@ -415,6 +415,23 @@ def test_full_size_config5_sheet100k_1024_normal():
     del sdf, s3
 
 
+@pytest.mark.parametrize("sign", [SignMethod.Raycast, SignMethod.Normal])
+def test_host_pointer_result_in_pieces(suzanne, sign):
+    """A host-pointer result of 16 MiB or more leaves the device in x-pieces (capi.hip run_grid_distance_to_host): seeds
+    and cut lists are prepared once for the slab, every piece is a walk with its brick offset into them.  172 x 160 x 160
+    cells = 4 pieces (the last one ragged), also as an x-slab that does not start at 0."""
+    v, idx = suzanne
+    g = grid_of(v, [172, 160, 160])
+    want = oracle_grid(v, idx, g, sign)
+    got = generate_grid_sdf(v, Topology.TriangleList(idx), g, sign)
+    assert_bit_equal(got, want, f"host pieces {sign.name}")
+    out = np.full(g.get_total_cell_count(), np.nan, F)
+    generate_grid_sdf(v, Topology.TriangleList(idx), g, sign, x_slab=(3, 171), out=out)
+    row = 160 * 160
+    assert_bit_equal(out[3 * row : 171 * row], want[3 * row : 171 * row], f"host pieces of a slab {sign.name}")
+    assert np.isnan(out[: 3 * row]).all() and np.isnan(out[171 * row :]).all()
+
+
 # ---- persistent mesh (include/m2s.h m2s_mesh) -----------------------------------------------------
 def test_persistent_mesh_matches_one_shot(suzanne):
     import torch
