@@ -496,6 +496,134 @@ __global__ __launch_bounds__(256) void k_node_ext(const NodeRec* __restrict__ no
   }
 }
 
+// ---- treelet pass ---------------------------------------------------------------------------------------
+// The LBVH's top is fine, what costs node tests is how groups of 16-512 triangles are partitioned (DESIGN.md §4,
+// tools/exp_tree.py: LBVH splits down to nodes of <= 64 triangles with sweep splits inside them make the walk 5 % shorter).
+// k_treelet_roots lists the maximal LBVH nodes of at most TREELET_MAX triangles; k_treelet rebuilds each with one wave:
+// top-down, every segment split along the widest axis of its triangle-box centres at the position that minimises
+// (sum of box extents) x (triangle count) over both sides.  The triangles of the node are reordered inside its range
+// of the sorted arrays and their keys keep the node's Morton prefix followed by the path in the new treelet (prefix-free
+// codes), so the radix tree over the keys (k_karras, run again) is the old tree above the node and the new one inside.
+#ifndef M2S_TREELET_MAX
+#define M2S_TREELET_MAX 64
+#endif
+constexpr int TREELET_MAX = M2S_TREELET_MAX;
+
+__global__ __launch_bounds__(256) void k_treelet_roots(int n, const int2* __restrict__ range, const int* __restrict__ parent,
+                                                        int2* __restrict__ roots, int* __restrict__ n_roots) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n - 1) return;
+  const int2 r = range[i];
+  const int cnt = r.y - r.x + 1;
+  if (cnt > TREELET_MAX || cnt < 3) return;
+  const int p = parent[i];
+  bool is_root = p == INT32_MIN;
+  if (!is_root) {
+    const int pi = p >= 0 ? p : -p - 2;
+    const int2 pr = range[pi];
+    is_root = pr.y - pr.x + 1 > TREELET_MAX;
+  }
+  if (is_root) roots[atomicAdd(n_roots, 1)] = make_int2(r.x, cnt);
+}
+
+__global__ __launch_bounds__(TREELET_MAX) void k_treelet(const int2* __restrict__ roots, const int* __restrict__ n_roots,
+                                                const Box* __restrict__ boxes, uint64_t* __restrict__ keys,
+                                                uint32_t* __restrict__ order) {
+  // the treelet's items by POSITION (a segment is a contiguous range of positions, so a lane loops over its own segment only:
+  // the trip counts halve from level to level instead of staying at the treelet size)
+  __shared__ float s_box[6][TREELET_MAX];
+  __shared__ float s_cen[3][TREELET_MAX];
+  __shared__ int s_key[TREELET_MAX], s_rank[TREELET_MAX], s_cost[TREELET_MAX];
+  if ((int)blockIdx.x >= *n_roots) return;
+  const int2 root = roots[blockIdx.x];
+  const int first = root.x, m = root.y, lane = threadIdx.x;
+  const bool live = lane < m;
+  const uint64_t k_first = keys[first], k_last = keys[first + m - 1];
+  if (k_first == k_last) return;                                  // identical centres: no room below the prefix
+  const int prefix = __clzll((long long)(k_first ^ k_last));      // bits the node's keys share
+  const int room = 64 - prefix;                                   // bits left for the path inside the treelet
+  const uint32_t tri = live ? order[first + lane] : 0u;
+  const uint64_t old_key = live ? keys[first + lane] : 0ull;
+  Box b = {0, 0, 0, 0, 0, 0};
+  if (live) b = boxes[tri];
+  const float cen[3] = {0.5f * (b.mnx + b.mxx), 0.5f * (b.mny + b.mxy), 0.5f * (b.mnz + b.mxz)};
+  const int ck[3] = {ord(cen[0]), ord(cen[1]), ord(cen[2])};      // total order, NaN included
+  int pos = lane, s = 0, e = live ? m : 0;                        // my position; my segment [s, e) of positions
+  uint64_t code = 0;
+  int depth = 0;
+  for (int level = 0; level < 64; ++level) {
+    const bool open = live && e - s > 1 && depth < room;
+    if (__syncthreads_or(open ? 1 : 0) == 0) break;
+    if (live) {
+      s_box[0][pos] = b.mnx; s_box[1][pos] = b.mny; s_box[2][pos] = b.mnz; s_box[3][pos] = b.mxx; s_box[4][pos] = b.mxy; s_box[5][pos] = b.mxz;
+      s_cen[0][pos] = cen[0]; s_cen[1][pos] = cen[1]; s_cen[2][pos] = cen[2];
+    }
+    __syncthreads();
+    // widest axis of the centres of my segment
+    int axis = 2;
+    if (open) {
+      float mn0 = __builtin_inff(), mn1 = mn0, mn2 = mn0, mx0 = -mn0, mx1 = -mn0, mx2 = -mn0;
+      for (int j = s; j < e; ++j) {
+        const float ox = s_cen[0][j], oy = s_cen[1][j], oz = s_cen[2][j];
+        mn0 = fminf(mn0, ox); mx0 = fmaxf(mx0, ox); mn1 = fminf(mn1, oy); mx1 = fmaxf(mx1, oy); mn2 = fminf(mn2, oz); mx2 = fmaxf(mx2, oz);
+      }
+      const float e0 = mx0 - mn0, e1 = mx1 - mn1, e2 = mx2 - mn2;
+      axis = (e0 >= e1 && e0 >= e2) ? 0 : (e1 >= e2 ? 1 : 2);   // NaN extents: comparisons false -> axis 2; any axis is valid
+    }
+    const int key = axis == 0 ? ck[0] : (axis == 1 ? ck[1] : ck[2]);
+    if (live) s_key[pos] = key;
+    __syncthreads();
+    // my rank inside my segment along that axis (strict order by (key, position))
+    int rank = pos;
+    if (open) {
+      rank = s;
+      for (int j = s; j < e; ++j) {
+        const int oj = s_key[j];
+        rank += (oj < key || (oj == key && j < pos)) ? 1 : 0;
+      }
+    }
+    if (live) s_rank[pos] = rank;
+    __syncthreads();
+    // the split after me: boxes of the triangles up to my rank and of the rest
+    int cost_key = INT32_MAX;
+    if (open) {
+      float l0 = __builtin_inff(), l1 = l0, l2 = l0, l3 = -l0, l4 = -l0, l5 = -l0;
+      float r0 = l0, r1 = l0, r2 = l0, r3 = -l0, r4 = -l0, r5 = -l0;
+      for (int j = s; j < e; ++j) {
+        const bool left = s_rank[j] <= rank;
+        const float a0 = s_box[0][j], a1 = s_box[1][j], a2 = s_box[2][j], a3 = s_box[3][j], a4 = s_box[4][j], a5 = s_box[5][j];
+        if (left) { l0 = fminf(l0, a0); l1 = fminf(l1, a1); l2 = fminf(l2, a2); l3 = fmaxf(l3, a3); l4 = fmaxf(l4, a4); l5 = fmaxf(l5, a5); }
+        else { r0 = fminf(r0, a0); r1 = fminf(r1, a1); r2 = fminf(r2, a2); r3 = fmaxf(r3, a3); r4 = fmaxf(r4, a4); r5 = fmaxf(r5, a5); }
+      }
+      const int n_left = rank - s + 1, n_right = e - rank - 1;
+      const float cost = ((l3 - l0) + (l4 - l1) + (l5 - l2)) * (float)n_left + ((r3 - r0) + (r4 - r1) + (r5 - r2)) * (float)n_right;
+      if (n_right > 0) cost_key = ord(cost);                      // the last rank is not a split
+    }
+    if (live) s_cost[pos] = cost_key;
+    __syncthreads();
+    if (open) {
+      // the best split of my segment: smallest (cost, rank)
+      int best_cost = INT32_MAX, best_rank = s + (e - s) / 2 - 1;   // fallback (cannot be needed: a segment of 2+ has a valid split)
+      for (int j = s; j < e; ++j) {
+        const int cj = s_cost[j], rj = s_rank[j];
+        if (cj < best_cost || (cj == best_cost && cj != INT32_MAX && rj < best_rank)) { best_cost = cj; best_rank = rj; }
+      }
+      const bool right = rank > best_rank;
+      pos = rank;
+      code = (code << 1) | (right ? 1ull : 0ull);
+      ++depth;
+      if (right) s = best_rank + 1; else e = best_rank + 1;
+    }
+  }
+  if (live) {
+    // Morton prefix of the node, then the path inside the treelet, left aligned (depth <= room)
+    const uint64_t mask = ~0ull << room;
+    const uint64_t path = depth ? code << (room - depth) : 0ull;
+    keys[first + pos] = (old_key & mask) | path;
+    order[first + pos] = tri;
+  }
+}
+
 __global__ void k_init_scene(int* scene, int* parent, int n_nodes) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < 3) scene[i] = INT32_MAX;
@@ -584,6 +712,15 @@ int build_device_mesh(Arena& ws, hipStream_t st, const float* d_verts, size_t n_
   }
   M2S_HIP_CHECK(rocprim::radix_sort_pairs(tmp, sort_tmp, keys, keys2, vals, order, n_tris, 0, 64, st));
   if (n > 1) hipLaunchKernelGGL(k_karras, dim3(cdiv(n_tris - 1, B)), dim3(B), 0, st, keys2, n, range, child, parent);
+  static const bool treelets = !(getenv("M2S_TREELETS") && atoi(getenv("M2S_TREELETS")) == 0);
+  if (n > 2 && treelets && !getenv("M2S_KEYS_FILE")) {
+    // treelet pass: the nodes of at most TREELET_MAX triangles are rebuilt by sweep splits, then the hierarchy is derived again
+    int2* roots = reinterpret_cast<int2*>(child);   // child[] is not used by the kernels below and is rewritten by the second k_karras
+    M2S_HIP_CHECK(hipMemsetAsync(scene + 7, 0, sizeof(int), st));
+    hipLaunchKernelGGL(k_treelet_roots, dim3(cdiv(n_tris - 1, B)), dim3(B), 0, st, n, range, parent, roots, scene + 7);
+    hipLaunchKernelGGL(k_treelet, dim3((unsigned)((n_tris + 2) / 3)), dim3(TREELET_MAX), 0, st, roots, scene + 7, boxes, keys2, order);
+    hipLaunchKernelGGL(k_karras, dim3(cdiv(n_tris - 1, B)), dim3(B), 0, st, keys2, n, range, child, parent);
+  }
 
   SegLevels lv;
   lv.levels = 0;

@@ -40,7 +40,7 @@ def sweep_tree(v, idx, cost="sa", max_depth=62, top_levels=None, bottom_size=Non
     def measure(ext):
         if cost == "sa":
             return ext[:, 0] * ext[:, 1] + ext[:, 1] * ext[:, 2] + ext[:, 2] * ext[:, 0]
-        if cost == "width":
+        if cost in ("width", "width1"):
             return ext.sum(1)
         if cost == "sawidth":   # box grown by a margin: what a query ball of that radius sees
             m = margin
@@ -87,7 +87,10 @@ def sweep_tree(v, idx, cost="sa", max_depth=62, top_levels=None, bottom_size=Non
             continue
         best = None
         if depth < max_depth - 20 or m <= 2:
-            for ax in range(3):
+            axes = range(3)
+            if cost.endswith("1"):   # sweep along the widest axis of the centroids only
+                ce = cen[ids]; axes = [int(np.argmax(ce.max(0) - ce.min(0)))]
+            for ax in axes:
                 o = ids[np.argsort(cen[ids, ax], kind="stable")]
                 llo = np.minimum.accumulate(lo[o], 0); lhi = np.maximum.accumulate(hi[o], 0)
                 rlo = np.minimum.accumulate(lo[o][::-1], 0)[::-1]; rhi = np.maximum.accumulate(hi[o][::-1], 0)[::-1]
