@@ -16,6 +16,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <cstdio>
+#include <functional>
 #include <vector>
 
 #include <rocprim/rocprim.hpp>
@@ -56,6 +57,7 @@ __device__ __forceinline__ uint32_t load_index(const void* idx, int index_bytes,
 __global__ __launch_bounds__(256) void k_tri_setup(const float* __restrict__ verts, uint32_t n_verts,
                                                    const void* __restrict__ indices, int index_bytes, int topology,
                                                    uint32_t n_tris, TriRec* __restrict__ raw, Box* __restrict__ boxes,
+                                                   float4* __restrict__ cen_raw,
                                                    int* __restrict__ scene /*6 final + 6 per block*/, int* __restrict__ err) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   int lo[3] = {INT32_MAX, INT32_MAX, INT32_MAX}, hi[3] = {INT32_MIN, INT32_MIN, INT32_MIN};
@@ -87,6 +89,9 @@ __global__ __launch_bounds__(256) void k_tri_setup(const float* __restrict__ ver
     const float sx = 0.5f * (mn.x + mx.x), sy = 0.5f * (mn.y + mx.y), sz = 0.5f * (mn.z + mx.z);
     raw[t] = r;
     boxes[t] = {mn.x, mn.y, mn.z, mx.x, mx.y, mx.z};
+    // centroid in INPUT order (k_emit writes the same values in sorted order): lets the seed passes start before the sort
+    cen_raw[t] = make_float4((r.ax + r.bx + r.cx) * (1.0f / 3.0f), (r.ay + r.by + r.cy) * (1.0f / 3.0f),
+                             (r.az + r.bz + r.cz) * (1.0f / 3.0f), 0.0f);
     const float cen[3] = {sx, sy, sz};
     for (int k = 0; k < 3; ++k)
       if (cen[k] == cen[k] && fabsf(cen[k]) < 3.0e38f) { lo[k] = ord(cen[k]); hi[k] = lo[k]; }
@@ -287,7 +292,7 @@ __global__ __launch_bounds__(256) void k_emit(int n, const int2* __restrict__ ra
                                               const uint32_t* __restrict__ order, const TriRec* __restrict__ raw,
                                               NodeRec* __restrict__ nodes, TriRec* __restrict__ tris,
                                               uint32_t* __restrict__ slot_first, float4* __restrict__ cen,
-                                              TriPlanes* __restrict__ planes, uint32_t leaf_max) {
+                                              TriPlanes* __restrict__ planes, uint32_t leaf_max, uint32_t* __restrict__ slot_of) {
   const int id = blockIdx.x * blockDim.x + threadIdx.x;
   if (id >= 2 * n - 1) return;
   const bool leaf = id >= n - 1;
@@ -317,6 +322,7 @@ __global__ __launch_bounds__(256) void k_emit(int n, const int2* __restrict__ ra
   if (leaf) {
     const TriRec r = raw[order[first]];
     tris[first] = r;
+    slot_of[order[first]] = (uint32_t)first;   // input triangle -> its slot in the sorted arrays
     cen[first] = make_float4((r.ax + r.bx + r.cx) * (1.0f / 3.0f), (r.ay + r.by + r.cy) * (1.0f / 3.0f),
                              (r.az + r.bz + r.cz) * (1.0f / 3.0f), 0.0f);
     // leaf pre-test planes (common.h TriPlanes); all zero (= always evaluate) unless everything is well defined
@@ -641,14 +647,17 @@ size_t bvh_workspace_bytes(size_t n_tris) {
   (void)rocprim::radix_sort_pairs(nullptr, sort_tmp, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr,
                             (uint32_t*)nullptr, n, 0, 64, (hipStream_t)0);
   size_t b = 0;
-  b += n * sizeof(TriRec) * 2 + n * 16 + 256 + n * sizeof(TriPlanes) + 256 + n * sizeof(Box) * 3 + n * (8 + 4) * 2 + sort_tmp;
+  b += n * sizeof(TriRec) * 2 + n * 16 + 256 + n * 16 + 256 + n * 4 + 256 + n * sizeof(TriPlanes) + 256 + n * sizeof(Box) * 3 + n * (8 + 4) * 2 + sort_tmp;
   b += n * (sizeof(int2) * 2) + 2 * n * sizeof(int) + 2 * n * sizeof(NodeRec) + 2 * n * (sizeof(NodeExt) + 4);
   return b + 64 * 256 + 4096 + 24 * ((n + 255) / 256) + 256;
 }
 
 int build_device_mesh(Arena& ws, hipStream_t st, const float* d_verts, size_t n_verts, const void* d_indices,
-                      size_t n_indices, int index_bytes, int topology, size_t n_tris, int* d_err, DeviceMesh* out) {
+                      size_t n_indices, int index_bytes, int topology, size_t n_tris, int* d_err, DeviceMesh* out,
+                      const std::function<int(const float4*)>* after_setup) {
   (void)n_indices;
+  out->cen_raw = nullptr;
+  out->slot_of = nullptr;
   out->tris = nullptr;
   out->cen = nullptr;
   out->planes = nullptr;
@@ -668,6 +677,8 @@ int build_device_mesh(Arena& ws, hipStream_t st, const float* d_verts, size_t n_
   TriRec* raw = ws.take<TriRec>(n_tris);
   TriRec* tris = ws.take<TriRec>(n_tris);
   float4* cen = ws.take<float4>(n_tris);
+  float4* cen_raw = ws.take<float4>(n_tris);
+  uint32_t* slot_of = ws.take<uint32_t>(n_tris);
   TriPlanes* planes = ws.take<TriPlanes>(n_tris);
   Box* boxes = ws.take<Box>(n_tris);
   Box* seg = ws.take<Box>(2 * n_tris + 64);
@@ -686,7 +697,7 @@ int build_device_mesh(Arena& ws, hipStream_t st, const float* d_verts, size_t n_
   (void)rocprim::radix_sort_pairs(nullptr, sort_tmp, keys, keys2, vals, order, n_tris, 0, 64, st);
   void* tmp = ws.take<char>(sort_tmp ? sort_tmp : 1);
   if (!raw || !tris || !boxes || !seg || !keys || !keys2 || !vals || !order || !range || !child || !parent || !nodes ||
-      !scene || !tmp || !ext || !slot_first || !cen || !planes) {
+      !scene || !tmp || !ext || !cen_raw || !slot_of || !slot_first || !cen || !planes) {
     set_error("internal: BVH workspace too small");
     return M2S_ERR_HIP_INTERNAL;
   }
@@ -695,8 +706,14 @@ int build_device_mesh(Arena& ws, hipStream_t st, const float* d_verts, size_t n_
   static const uint32_t leaf_max = getenv("M2S_LEAF_MAX") ? std::max(1u, (uint32_t)atoi(getenv("M2S_LEAF_MAX"))) : 2u;
   hipLaunchKernelGGL(k_init_scene, dim3(cdiv(2 * n_tris, B)), dim3(B), 0, st, scene, parent, 2 * n - 1);
   hipLaunchKernelGGL(k_tri_setup, dim3(cdiv(n_tris, B)), dim3(B), 0, st, d_verts, (uint32_t)n_verts, d_indices,
-                     index_bytes, topology, (uint32_t)n_tris, raw, boxes, scene, d_err);
+                     index_bytes, topology, (uint32_t)n_tris, raw, boxes, cen_raw, scene, d_err);
   hipLaunchKernelGGL(k_scene_reduce, dim3(1), dim3(256), 0, st, scene, (uint32_t)cdiv(n_tris, B));
+  out->cen_raw = cen_raw;
+  out->slot_of = slot_of;
+  if (after_setup) {   // the caller's seed passes only need the centroids: they run beside the sort and the hierarchy
+    const int rc = (*after_setup)(cen_raw);
+    if (rc) return rc;
+  }
   hipLaunchKernelGGL(k_morton, dim3(cdiv(n_tris, B)), dim3(B), 0, st, boxes, (uint32_t)n_tris, scene, keys, vals);
   if (const char* kf = getenv("M2S_KEYS_FILE")) {
     // Experiment knob (tools/exp_tree.py): one 64-bit key per triangle from a file instead of the Morton keys.  The
@@ -745,7 +762,7 @@ int build_device_mesh(Arena& ws, hipStream_t st, const float* d_verts, size_t n_
                        n2, o3, n3);
   }
   hipLaunchKernelGGL(k_emit, dim3(cdiv(2 * n_tris - 1, B)), dim3(B), 0, st, n, range, parent, seg, lv, order, raw,
-                     nodes, tris, slot_first, cen, planes, leaf_max);
+                     nodes, tris, slot_first, cen, planes, leaf_max, slot_of);
   hipLaunchKernelGGL(k_node_ext_small, dim3(cdiv(2 * n_tris - 1, B)), dim3(B), 0, st, nodes, slot_first, tris,
                      (uint32_t)(2 * n_tris - 1), ext);
   hipLaunchKernelGGL(k_node_ext, dim3(cdiv(2 * n_tris - 1, 4)), dim3(B), 0, st, nodes, slot_first, tris,

@@ -250,7 +250,9 @@ int run_grid_distance(Arena& ws, const CallCtx& c, DeviceState& st, DeviceMesh m
     mesh.stats = d_stats;
   }
   int rc = launch_grid_distance(ws, c.stream, mesh, g, sign_method == M2S_SIGN_RAYCAST ? MODE_UNSIGNED : MODE_NORMAL_FOLD,
-                                plane, c.algorithm, d_out, d_err, st.ev[4], st.planes_done, !c.sync);
+                                plane, c.algorithm, d_out, d_err, st.ev[4], st.planes_done, !c.sync,
+                                st.have_raw_seeds ? &st.raw_seeds : nullptr, st.have_raw_seeds ? st.seeds_done : nullptr);
+  st.have_raw_seeds = false;
   if (rc) return rc;
   M2S_HIP_CHECK(hipEventRecord(st.ev[3], c.stream));
   if (d_stats) {
@@ -377,7 +379,9 @@ int run_grid_distance_to_host(Arena& ws, const CallCtx& c, DeviceState& st, cons
   // seeds and cut lists once for the whole slab; the pieces are then nothing but walks (a piece of its own would pay the
   // 0.5 ms of dependent small kernels again: 16.6 -> 14 ms for the 512^3 call)
   GridWalkPlan plan;
-  rc = prepare_grid_walk(ws, c.stream, mesh, g, c.algorithm, false, &plan);
+  if (st.have_raw_seeds && hipStreamWaitEvent(c.stream, st.seeds_done, 0) != hipSuccess) { cleanup(); return fail(M2S_ERR_HIP, "hipStreamWaitEvent failed"); }
+  rc = prepare_grid_walk(ws, c.stream, mesh, g, c.algorithm, false, &plan, st.have_raw_seeds ? &st.raw_seeds : nullptr);
+  st.have_raw_seeds = false;
   if (rc) { cleanup(); return rc; }
   if (st.planes_done && hipStreamWaitEvent(c.stream, st.planes_done, 0) != hipSuccess) { cleanup(); return fail(M2S_ERR_HIP, "hipStreamWaitEvent failed"); }
   for (uint32_t i = 0; i < pieces; ++i) {                          // all kernels first: the GPU never waits for the host
@@ -671,7 +675,26 @@ int m2s_generate_grid_sdf(const float* vertices, size_t n_vertices, const void* 
 
   M2S_HIP_CHECK(hipEventRecord(st->ev[0], c.stream));
   DeviceMesh mesh;
-  rc = build_device_mesh(ws, c.stream, sm.d_verts, n_vertices, sm.d_indices, n_indices, index_bytes, topology, n_tris, d_err, &mesh);
+  // Seed passes beside the build: jump flooding needs the triangle centroids only, which exist (in input order) right after
+  // the first kernels of the build; its 0.5 ms of small dependent kernels then run on the side stream while the caller's
+  // stream sorts, derives the hierarchy and fits the bounds (0.3 ms).  The ids are translated to sorted slots afterwards.
+  st->have_raw_seeds = false;
+  static const bool seed_overlap = !(getenv("M2S_SEED_OVERLAP") && atoi(getenv("M2S_SEED_OVERLAP")) == 0);
+  const std::function<int(const float4*)> seeds_beside_build = [&](const float4* cen_raw) -> int {
+    hipStream_t ss;
+    int r = sign_stream_begin(*st, c.stream, c.sync, &ss);   // orders the side stream after the centroid kernels
+    if (r) return r;
+    if (ss == c.stream) return 0;                            // no side stream for this call: seeds as part of the walk's preparation
+    if (!st->seeds_done) M2S_HIP_CHECK(hipEventCreateWithFlags(&st->seeds_done, hipEventDisableTiming));
+    r = launch_grid_seeds(ws, ss, cen_raw, (uint32_t)n_tris, g, &st->raw_seeds);
+    if (r) return r;
+    M2S_HIP_CHECK(hipEventRecord(st->seeds_done, ss));
+    st->have_raw_seeds = true;
+    return 0;
+  };
+  const bool beside = seed_overlap && c.algorithm == 0 && !getenv("M2S_STATS") && grid_walk_wants_seeds(g, n_tris, c.algorithm);
+  rc = build_device_mesh(ws, c.stream, sm.d_verts, n_vertices, sm.d_indices, n_indices, index_bytes, topology, n_tris, d_err, &mesh,
+                         beside ? &seeds_beside_build : nullptr);
   if (rc) return rc;
   M2S_HIP_CHECK(hipEventRecord(st->ev[1], c.stream));
   const uint32_t* plane = nullptr;
@@ -887,6 +910,7 @@ int m2s_mesh_generate_grid_sdf(m2s_mesh* m, const m2s_grid* grid, int sign_metho
   M2S_HIP_CHECK(hipEventRecord(st->ev[0], c.stream));
   M2S_HIP_CHECK(hipEventRecord(st->ev[1], c.stream));
   st->planes_done = nullptr;
+  st->have_raw_seeds = false;
   bool built_planes = false;
   const uint32_t* plane = nullptr;
   if (sign_method == M2S_SIGN_RAYCAST) {

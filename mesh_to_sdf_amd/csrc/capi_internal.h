@@ -33,6 +33,11 @@ struct DeviceState {
   hipStream_t side_stream = nullptr;
   hipEvent_t fork_ev = nullptr;
   hipEvent_t planes_done = nullptr;   // ev[2] while a call's planes are in flight on the side stream, else nullptr
+  // one-shot grid calls also run the jump-flooding seed passes on the side stream, beside the sort / hierarchy of the build
+  // (they only need the input-order centroids): the lattice, and the event recorded after the last pass
+  SeedLattice raw_seeds;
+  hipEvent_t seeds_done = nullptr;
+  bool have_raw_seeds = false;
   int* h_err = nullptr;  // pinned
   char* spare_mesh = nullptr;  // last destroyed m2s_mesh block, recycled by the next m2s_mesh_create
   size_t spare_mesh_bytes = 0;

@@ -1,5 +1,6 @@
 // common.h — records shared by the host orchestration and the gfx950 kernels.
 #pragma once
+#include <functional>
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 #include <stdint.h>
@@ -80,6 +81,8 @@ struct DeviceMesh {
   const TriRec* tris;   // n_tris records, Morton order
   const TriPlanes* planes;  // n_tris leaf pre-test records
   const float4* cen;    // n_tris triangle centroids (same order), for the jump-flooding seed pass
+  const float4* cen_raw;     // the same centroids in INPUT triangle order (available before the sort)
+  const uint32_t* slot_of;   // input triangle -> slot in the sorted arrays
   const NodeRec* nodes; // n_nodes = 2*n_tris - 1 (0 if n_tris == 0)
   const NodeExt* ext;   // n_nodes oriented bounds
   unsigned long long* stats;  // optional traversal counters (M2S_STATS=1), else nullptr
@@ -189,8 +192,11 @@ struct Arena {
 // ---- host launchers implemented in the .hip files ------------------------------------------
 // bvh.hip: flatten topology, build triangle records + LBVH in pre-order layout.
 size_t bvh_workspace_bytes(size_t n_tris);
+// `after_setup` (optional) is called once the kernels that fill the input-order centroids are enqueued on `st`, with
+// that array: whatever it enqueues elsewhere (the seed passes) may wait for an event recorded on `st` at that point.
 int build_device_mesh(Arena& ws, hipStream_t st, const float* d_verts, size_t n_verts, const void* d_indices,
-                      size_t n_indices, int index_bytes, int topology, size_t n_tris, int* d_err, DeviceMesh* out);
+                      size_t n_indices, int index_bytes, int topology, size_t n_tris, int* d_err, DeviceMesh* out,
+                      const std::function<int(const float4*)>* after_setup = nullptr);
 
 // sign.hip: grid-line ray parity -> one "inside" bit per voxel (bit plane in grid layout).
 size_t sign_workspace_bytes(const GridParams& g, size_t n_tris);
@@ -207,15 +213,24 @@ struct GridWalkPlan {
   uint32_t cut_log = 0, cut_ny = 0, cut_nz = 0;
   bool lane_walk = false;
 };
+// Seed lattice of a slab: one triangle id per packet brick (ids index the centroid array it was computed from).
+struct SeedLattice {
+  uint32_t* ids = nullptr;
+  uint32_t ny = 0, nz = 0;
+  size_t points = 0;
+};
+bool grid_walk_wants_seeds(const GridParams& g, size_t n_tris, int algorithm);
+int launch_grid_seeds(Arena& ws, hipStream_t st, const float4* cen, uint32_t n_tris, const GridParams& g, SeedLattice* out);
 int prepare_grid_walk(Arena& ws, hipStream_t st, const DeviceMesh& mesh, const GridParams& g, int algorithm, bool pipelined,
-                      GridWalkPlan* plan);
+                      GridWalkPlan* plan, const SeedLattice* raw_seeds = nullptr);
 // `g` may be an x-piece of the slab the plan was prepared for, starting bx_off bricks into it (a multiple of 2 bricks).
 int launch_grid_walk(hipStream_t st, const DeviceMesh& mesh, const GridParams& g, int mode, const uint32_t* d_inside_plane,
                      int algorithm, const GridWalkPlan& plan, uint32_t bx_off, float* d_out, int* d_err);
 // Records `ev_before_final` (if non-null) between the seed passes and the final k_packet launch.
 int launch_grid_distance(Arena& ws, hipStream_t st, const DeviceMesh& mesh, const GridParams& g, int mode,
                          const uint32_t* d_inside_plane, int algorithm, float* d_out, int* d_err,
-                         hipEvent_t ev_before_final, hipEvent_t wait_before_final = nullptr, bool pipelined = false);
+                         hipEvent_t ev_before_final, hipEvent_t wait_before_final = nullptr, bool pipelined = false,
+                         const SeedLattice* raw_seeds = nullptr, hipEvent_t wait_raw_seeds = nullptr);
 size_t query_workspace_bytes(size_t n_q);
 int launch_query_distance(Arena& ws, hipStream_t st, const DeviceMesh& mesh, const float* d_queries, size_t n_q,
                           int mode, int sign_src, int algorithm, float* d_out, int* d_err);

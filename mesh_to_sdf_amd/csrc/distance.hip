@@ -888,45 +888,77 @@ size_t grid_distance_workspace_bytes(const GridParams& g) {
   return bricks * 16 + bricks + 16384 + cut_blocks(g, 1) * CUT_WORDS * 4 + 1024;   // seeds + cut lists (the smallest blocks)
 }
 
+__global__ __launch_bounds__(256) void k_seed_remap(uint32_t* __restrict__ ids, size_t n, const uint32_t* __restrict__ slot_of, uint32_t n_tris) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t t = ids[i];
+  ids[i] = t < n_tris ? slot_of[t] : 0xffffffffu;
+}
+
+bool grid_walk_wants_seeds(const GridParams& g, size_t n_tris, int algorithm) {
+  static const bool use_seeds = !(getenv("M2S_SEEDS") && atoi(getenv("M2S_SEEDS")) == 0);
+  if (g.xe <= g.xb || g.n[1] == 0 || g.n[2] == 0) return false;
+  return algorithm != 1 && n_tris && host_brick_count(g) >= 8 && use_seeds;
+}
+
+// Seeding: every 4^3 brick starts its walk from a triangle near its own centre (jump flooding over the lattice of brick
+// centres); that halves the nodes visited compared with a greedy descent.  `cen` are the triangle centroids the ids of
+// the result refer to: the sorted array of the finished mesh, or the input-order array while the mesh is still being built.
+int launch_grid_seeds(Arena& ws, hipStream_t st, const float4* cen, uint32_t n_tris, const GridParams& g, SeedLattice* out) {
+  DeviceMesh mesh{};
+  mesh.cen = cen;
+  mesh.n_tris = n_tris;
+  const GridParams g1 = coarse_level(g, g.bl, g.xb);   // one lattice point per packet brick, at its centre
+  const size_t points1 = (size_t)g1.n[0] * g1.n[1] * g1.n[2];
+  uint32_t* s1 = ws.take<uint32_t>(points1);
+  uint32_t* s1b = ws.take<uint32_t>(points1);
+  if (!s1 || !s1b) { set_error("internal: seed workspace too small"); return M2S_ERR_HIP_INTERNAL; }
+  unsigned long long* keys = ws.take<unsigned long long>(points1);
+  if (!keys) { set_error("internal: seed workspace too small"); return M2S_ERR_HIP_INTERNAL; }
+  const unsigned nb1 = (unsigned)((points1 + 255) / 256);
+  M2S_HIP_CHECK(hipMemsetAsync(keys, 0xff, points1 * 8, st));
+  hipLaunchKernelGGL(k_jfa_splat, dim3((mesh.n_tris + 255) / 256), dim3(256), 0, st, mesh, g1, nullptr, keys);
+  hipLaunchKernelGGL(k_jfa_unpack, dim3(nb1), dim3(256), 0, st, keys, points1, s1);
+  const uint32_t maxdim = max(g1.n[0], max(g1.n[1], g1.n[2]));
+  int step = 1;
+  while ((uint32_t)step * 2 < maxdim) step *= 2;
+  uint32_t *src = s1, *dst = s1b;
+  const unsigned nb = (unsigned)((points1 + 255) / 256);
+  for (; step >= 1; step /= 2) {
+    hipLaunchKernelGGL(k_jfa_pass, dim3(nb), dim3(256), 0, st, mesh, g1, nullptr, src, dst, step);
+    uint32_t* t = src; src = dst; dst = t;
+  }
+  hipLaunchKernelGGL(k_jfa_pass, dim3(nb), dim3(256), 0, st, mesh, g1, nullptr, src, dst, 1);   // "JFA+1": one more unit pass
+  out->ids = dst;
+  out->ny = g1.n[1];
+  out->nz = g1.n[2];
+  out->points = points1;
+  return 0;
+}
+
 // Seeds and cut lists for the slab [g.xb, g.xe) (everything a walk needs besides the mesh); `launch_grid_walk` then
-// walks the slab, or any x-piece of it that starts on a block boundary.
+// walks the slab, or any x-piece of it that starts on a block boundary.  `raw_seeds` (optional): a seed lattice computed
+// from the input-order centroids while the mesh was being built; its ids are translated to sorted slots here.
 int prepare_grid_walk(Arena& ws, hipStream_t st, const DeviceMesh& mesh, const GridParams& g, int algorithm, bool pipelined,
-                      GridWalkPlan* plan) {
+                      GridWalkPlan* plan, const SeedLattice* raw_seeds) {
   *plan = GridWalkPlan{};
   if (g.xe <= g.xb || g.n[1] == 0 || g.n[2] == 0) return 0;
   const uint32_t packets = host_brick_count(g);
   const bool brute = algorithm == 1;
-
-  // Seeding: every 4^3 brick starts its walk from a triangle near its own centre (jump flooding over
-  // the lattice of brick centres, below); that halves the nodes visited compared with a greedy descent.
   const uint32_t* seed1 = nullptr;
   uint32_t sh1 = 0, s1ny = 0, s1nz = 0;
-  static const bool use_seeds = !(getenv("M2S_SEEDS") && atoi(getenv("M2S_SEEDS")) == 0);
-  if (!brute && mesh.n_tris && packets >= 8 && use_seeds) {
-    const GridParams g1 = coarse_level(g, g.bl, g.xb);   // one lattice point per packet brick, at its centre
-    const size_t points1 = (size_t)g1.n[0] * g1.n[1] * g1.n[2];
-    uint32_t* s1 = ws.take<uint32_t>(points1);
-    uint32_t* s1b = ws.take<uint32_t>(points1);
-    if (!s1 || !s1b) { set_error("internal: seed workspace too small"); return M2S_ERR_HIP_INTERNAL; }
-    unsigned long long* keys = ws.take<unsigned long long>(points1);
-    if (!keys) { set_error("internal: seed workspace too small"); return M2S_ERR_HIP_INTERNAL; }
-    const unsigned nb1 = (unsigned)((points1 + 255) / 256);
-    M2S_HIP_CHECK(hipMemsetAsync(keys, 0xff, points1 * 8, st));
-    hipLaunchKernelGGL(k_jfa_splat, dim3((mesh.n_tris + 255) / 256), dim3(256), 0, st, mesh, g1, nullptr, keys);
-    hipLaunchKernelGGL(k_jfa_unpack, dim3(nb1), dim3(256), 0, st, keys, points1, s1);
-    const uint32_t maxdim = max(g1.n[0], max(g1.n[1], g1.n[2]));
-    int step = 1;
-    while ((uint32_t)step * 2 < maxdim) step *= 2;
-    uint32_t *src = s1, *dst = s1b;
-    const unsigned nb = (unsigned)((points1 + 255) / 256);
-    for (; step >= 1; step /= 2) {
-      hipLaunchKernelGGL(k_jfa_pass, dim3(nb), dim3(256), 0, st, mesh, g1, nullptr, src, dst, step);
-      uint32_t* t = src; src = dst; dst = t;
+  if (grid_walk_wants_seeds(g, mesh.n_tris, algorithm)) {
+    SeedLattice lat;
+    if (raw_seeds && raw_seeds->ids) {
+      lat = *raw_seeds;
+      hipLaunchKernelGGL(k_seed_remap, dim3((unsigned)((lat.points + 255) / 256)), dim3(256), 0, st, lat.ids, lat.points, mesh.slot_of, mesh.n_tris);
+    } else {
+      const int rc = launch_grid_seeds(ws, st, mesh.cen, mesh.n_tris, g, &lat);
+      if (rc) return rc;
     }
-    hipLaunchKernelGGL(k_jfa_pass, dim3(nb), dim3(256), 0, st, mesh, g1, nullptr, src, dst, 1);   // "JFA+1": one more unit pass
-    seed1 = dst;
-    s1ny = g1.n[1];
-    s1nz = g1.n[2];
+    seed1 = lat.ids;
+    s1ny = lat.ny;
+    s1nz = lat.nz;
   }
   // Walk flavour: bricks that each meet MANY triangles (triangles much smaller than voxels) are better served by
   // independent per-lane walks.  Estimate: triangles per surface brick ~ T / (6 * bricks^(2/3)).
@@ -994,9 +1026,11 @@ int launch_grid_walk(hipStream_t st, const DeviceMesh& mesh, const GridParams& g
 
 int launch_grid_distance(Arena& ws, hipStream_t st, const DeviceMesh& mesh, const GridParams& g, int mode,
                          const uint32_t* d_inside_plane, int algorithm, float* d_out, int* d_err,
-                         hipEvent_t ev_before_final, hipEvent_t wait_before_final, bool pipelined) {
+                         hipEvent_t ev_before_final, hipEvent_t wait_before_final, bool pipelined,
+                         const SeedLattice* raw_seeds, hipEvent_t wait_raw_seeds) {
   GridWalkPlan plan;
-  int rc = prepare_grid_walk(ws, st, mesh, g, algorithm, pipelined, &plan);
+  if (raw_seeds && wait_raw_seeds) M2S_HIP_CHECK(hipStreamWaitEvent(st, wait_raw_seeds, 0));   // computed on another stream
+  int rc = prepare_grid_walk(ws, st, mesh, g, algorithm, pipelined, &plan, raw_seeds);
   if (rc) return rc;
   // the sign planes may have been built beside the seed passes, on another stream (capi.hip): the walk needs them
   if (wait_before_final) M2S_HIP_CHECK(hipStreamWaitEvent(st, wait_before_final, 0));

@@ -42,6 +42,12 @@ def sweep_tree(v, idx, cost="sa", max_depth=62, top_levels=None, bottom_size=Non
             return ext[:, 0] * ext[:, 1] + ext[:, 1] * ext[:, 2] + ext[:, 2] * ext[:, 0]
         if cost in ("width", "width1"):
             return ext.sum(1)
+        if cost == "diag1":
+            return np.sqrt((ext * ext).sum(1))
+        if cost == "max1":
+            return ext.max(1)
+        if cost == "sa1":
+            return ext[:, 0] * ext[:, 1] + ext[:, 1] * ext[:, 2] + ext[:, 2] * ext[:, 0]
         if cost == "sawidth":   # box grown by a margin: what a query ball of that radius sees
             m = margin
             e = ext + 2 * m
