@@ -44,15 +44,16 @@ def parse():
     ap.add_argument("--mesh", default="blob-100k")
     ap.add_argument("--sign", default="Raycast", choices=["Raycast", "Normal"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=25.0, help="budget for the CPU baseline sample")
+    ap.add_argument("--cpu-seconds", type=float, default=150.0, help="budget for the CPU baseline run (512^3 needs ~40-60 s)")
     ap.add_argument("--chunks", type=int, default=0, help="x-chunks per step whose all-gathers overlap compute (0 = auto)")
     return ap.parse_args()
 
 
-def cpu_baseline(v, idx, lo, hi, sign, budget_s):
+def cpu_baseline(v, idx, lo, hi, sign, budget_s, headline_n):
     """Times the oracle's faithful multi-threaded restatement of generate/grid.rs:265-642 (one heap
-    per thread, like rayon::current_num_threads()) on the largest cubic sample of the SAME mesh and
-    bbox that fits the time budget."""
+    per thread, like rayon::current_num_threads()) on the SAME mesh and bbox: directly on the headline
+    grid when the time budget allows (512^3: ~40 s, ~2 GB), else on the largest cubic sample that fits.
+    Returns (json dict, n, the propagation's output on the n^3 grid) — the output feeds `reference_parity`."""
     import oracle as orc
     from mesh_to_sdf_amd import meshes
 
@@ -62,30 +63,43 @@ def cpu_baseline(v, idx, lo, hi, sign, budget_s):
         first, size, cnt = meshes.grid_from_bounding_box(lo, hi, [n, n, n])
         t0 = time.perf_counter()
         # heaps == threads: the reference makes one heap per rayon thread (generate/grid.rs:318-339)
-        orc.generate_grid_sdf(v, idx, first, size, cnt, sign=sign, semantics=orc.PROPAGATE, heaps=th, threads=th)
-        return time.perf_counter() - t0
+        ref = orc.generate_grid_sdf(v, idx, first, size, cnt, sign=sign, semantics=orc.PROPAGATE, heaps=th, threads=th)
+        return time.perf_counter() - t0, ref
 
     # The port does not scale to every core count (more heaps = more redundant propagation, and the
     # algorithm has serial O(N^3) passes, as the reference does): probe a few thread counts on 128^3 and
-    # report the FASTEST configuration, so the baseline is the strongest CPU number, not the weakest.
+    # report the FASTEST configuration, so the baseline is the strongest CPU number, not the weakest;
+    # the all-cores figure (what rayon's default pool would use) is printed beside it.
     probe = {}
     for th in sorted({min(cores, t) for t in (16, 32, 64, cores)}):
-        probe[th] = run(128, th)
+        probe[th] = run(128, th)[0]
     best_th = min(probe, key=probe.get)
     rate = 128 ** 3 / probe[best_th]
-    n, dt = 128, probe[best_th]
-    for cand in (256, 224, 192, 160):
-        if cand ** 3 / rate <= budget_s:
-            n, dt = cand, run(cand, best_th)
+    n, dt, ref = 128, probe[best_th], None
+    for cand in (headline_n, 384, 256, 192):
+        if cand <= headline_n and cand ** 3 / rate * 1.25 <= budget_s:
+            n = cand
+            dt, ref = run(cand, best_th)
             break
-    return {
+    if ref is None:
+        dt, ref = run(n, best_th)
+    all_cores = None
+    if cores != best_th:
+        m = min(n, 256)
+        all_cores = round(m ** 3 / run(m, cores)[0] / 1e6, 4)
+    res = {
         "value": round(n ** 3 / dt / 1e6, 4),
         "unit": "Mvoxels/s",
         "cores": best_th,
         "kind": "port",
-        "sample": f"{n}^3 grid ({n ** 3 / 512 ** 3:.4f} of the 512^3 voxels), same mesh and bbox, C++ restatement of the reference's "
+        "sample": f"{n}^3 grid ({n ** 3 / headline_n ** 3:.4f} of the {headline_n}^3 voxels), same mesh and bbox, C++ restatement of the reference's "
                   f"3-phase propagation algorithm (oracle/), {best_th} threads = fastest of {sorted(probe)} on this {cores}-thread host, {dt:.2f} s",
+        "all_cores_value": all_cores,
+        "all_cores": cores,
+        "all_cores_note": f"rayon-equivalent pool (one heap per hardware thread), {min(n, 256)}^3 sample",
+        "probe_128_s": {str(k): round(x, 3) for k, x in sorted(probe.items())},
     }
+    return res, n, ref
 
 
 def main():
@@ -187,12 +201,14 @@ def main():
         achieved = b_alg / (dist_ms * 1e-3) / 1e9
         traffic = None
         valu_frac = None
+        pmc_src = None
         pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
         # the PMC figure is per launch over the WHOLE 512^3 grid: it only applies to the 1-GPU, 1-launch step
         if os.path.exists(pmc) and world == 1 and launches == args.steps and n == 512 and args.mesh == "blob-100k":
             try:
                 pj = json.load(open(pmc))
                 traffic = pj.get("k_packet_hbm_bytes_per_launch")
+                pmc_src = f"static: profiles/pmc_latest.json ({pj.get('source', 'rocprofv3 --pmc')}), not collected in this run"
                 valu_frac = pj.get("valu_issue_frac")
             except Exception:
                 traffic = None
@@ -232,6 +248,8 @@ def main():
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 6),
                 "traffic": traffic,
+                # NOT measured in this run: constants from the last committed rocprofv3 --pmc passes of this same command
+                "traffic_source": (pmc_src if traffic is not None else None),
                 "algorithmic_bytes_per_launch": b_alg,
                 "avg_launch_ms": round(dist_ms, 4),
                 # context, from the same PMC passes: the kernel's real ceiling is VALU issue
@@ -239,7 +257,16 @@ def main():
             },
         }
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(v, idx, lo, hi, int(sign), args.cpu_seconds)
+            res["cpu_baseline"], rn, ref = cpu_baseline(v, idx, lo, hi, int(sign), args.cpu_seconds, n)
+            # What a user switching from the reference sees (SURVEY.md header fact 2, §8c): this library's exact minimum
+            # against the reference's propagation semantics (the CPU run above, kept) on the same grid.
+            from mesh_to_sdf_amd.report import reference_parity
+            rgrid = Grid.from_bounding_box(lo, hi, [rn, rn, rn])
+            ours = generate_grid_sdf(dv, topo, rgrid, sign).cpu().numpy()
+            res["reference_parity"] = {"grid": [rn, rn, rn], "mesh": args.mesh, "sign_method": args.sign,
+                                       "reference": f"oracle PROPAGATE (generate/grid.rs:383-558 restated), {res['cpu_baseline']['cores']} heaps",
+                                       **reference_parity(ours, ref, normal_sign=(args.sign == "Normal"))}
+            del ours, ref
             # the PCIe-inclusive drop-in call (host pointers in/out), reported for DESIGN.md; never `value`
             host_out = np.empty(n ** 3, np.float32)
             times = []

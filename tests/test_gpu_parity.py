@@ -289,6 +289,62 @@ def test_grid_sheet100k_normal_open_surface():
     assert_bit_equal(got, oracle_grid(v, idx, g, SignMethod.Normal), "sheet-100k Normal")
 
 
+def _propagation_report(name, n, sign):
+    """GPU (exact minimum) against the oracle's restatement of the reference's OWN grid semantics — the label
+    propagation of generate/grid.rs:495-558, deterministic 1-heap form — on a BASELINE workload."""
+    from mesh_to_sdf_amd.report import reference_parity
+
+    v, idx = meshes.named(name)
+    g = grid_of(v, [n, n, n])
+    got = generate_grid_sdf(v, Topology.TriangleList(idx), g, sign)
+    prop = oracle_grid(v, idx, g, sign, semantics=orc.PROPAGATE, heaps=1, threads=1)
+    rep = reference_parity(got, prop, normal_sign=(sign == SignMethod.Normal))
+    print(f"\n[reference-propagation parity] {name} {n}^3 {sign.name}: {rep}")
+    return got, prop, rep
+
+
+def test_reference_propagation_parity_blob100k_128_raycast():
+    # config 2's mesh and sign rule at 128^3 (cells 3x a triangle: the regime where the propagation is least exact)
+    got, prop, rep = _propagation_report("blob-100k", 128, SignMethod.Raycast)
+    assert rep["ours_le_ref_everywhere"]            # the exact minimum never exceeds the propagated value
+    assert rep["sign_mismatches"] == 0              # Raycast sign is independent of the magnitude path (grid.rs:568-684)
+    assert rep["max_dev"] < 0.01                    # the reference's own cross-method tolerance (generic/bvh.rs:237-248)
+    assert rep["pct_within_1e-5"] > 70.0            # measured 80.6 % (oracle EXACT vs oracle PROPAGATE, CPU); see DESIGN.md §2
+
+
+def test_reference_propagation_parity_sheet100k_96_normal():
+    # config 5's mesh and sign rule (open surface, Normal) at 96^3
+    got, prop, rep = _propagation_report("sheet-100k", 96, SignMethod.Normal)
+    assert rep["ours_le_ref_everywhere"]
+    assert rep["max_dev"] < 0.01
+    # Normal sign comes from the triangle that wins the fold; the propagation sometimes ends on another triangle than the
+    # nearest one, so a few cells next to the sheet's ridges differ in sign between the reference's two semantics
+    # (oracle EXACT vs oracle PROPAGATE on the CPU: 289 of 884 736 cells).  The GPU must reproduce the EXACT signs bit for bit:
+    v, idx = meshes.named("sheet-100k")
+    exact = oracle_grid(v, idx, grid_of(v, [96, 96, 96]), SignMethod.Normal)
+    assert np.array_equal(np.signbit(got), np.signbit(exact))
+    assert rep["sign_mismatches"] == int(np.count_nonzero(np.signbit(exact) != np.signbit(prop)))
+    assert rep["sign_mismatches"] < 1000
+
+
+def test_config2_256_sub_lattice():
+    """BASELINE config 2 at its literal size (256^3 x blob-100k, Raycast): every 4th cell per axis bit for bit against
+    the oracle, signs included (whole sign lattice from the oracle's grid-line parity)."""
+    import torch
+
+    v, idx = meshes.named("blob-100k")
+    n = 256
+    g = grid_of(v, [n, n, n])
+    sdf = generate_grid_sdf(torch.as_tensor(v, device="cuda"), Topology.TriangleList(torch.as_tensor(idx.astype(np.int64), device="cuda")),
+                            g, SignMethod.Raycast).view(n, n, n)
+    sub = sdf[::4, ::4, ::4].contiguous().cpu().numpy().reshape(-1)
+    mag = orc.generate_sdf(v, idx, _sub_lattice(g, n, 4), accel=1, sign=0, fast=True)
+    assert_bit_equal(np.abs(sub), np.abs(mag), "256^3 sub-lattice magnitudes")
+    par = orc.grid_ray_parity(v, idx, g.get_first_cell(), g.get_cell_size(), [n, n, n]).reshape(n, n, n, 3)
+    inside = (par.sum(-1) >= 2)
+    assert np.array_equal(np.signbit(sdf.cpu().numpy()), inside), "256^3 signs (all cells)"
+
+
 def test_x_slabs_concatenate(suzanne):
     # multi-GPU sharding unit: x-slabs are contiguous ranges of the reference layout (grid.rs:122-124)
     v, idx = suzanne
