@@ -21,9 +21,16 @@
  * heap-ordered label propagation whose result depends on the thread count and is >= this
  * minimum on <0.5% of cells; see DESIGN.md "Exact vs propagation".)
  *
- * Threading: synchronous and re-entrant; the entry points are serialised internally (one mutex), the work they
- * enqueue is not: asynchronous calls (m2s_opts.synchronous = 0) on different streams use separate scratch blocks and
- * may overlap on the device.
+ * Threading: synchronous and re-entrant.  The library keeps one context (workspace, streams, events) per
+ * (device, m2s_opts.lane); an entry point holds only ITS context's lock, so calls on different devices — or on
+ * different lanes of one device — run concurrently from different host threads (m2s_generate_grid_sdf_multi does
+ * exactly that, one thread per device).  Calls on the same (device, lane) are serialised; the work they enqueue is
+ * not: asynchronous calls (m2s_opts.synchronous = 0) on different streams use separate scratch blocks and may
+ * overlap on the device.
+ *
+ * Limits (validated, M2S_ERR_BAD_ARG): n_vertices < 2^31, n_indices < 3 * 2^31, at most 2^25 triangles per mesh
+ * (32-bit byte offsets into the 96-byte triangle records), n_queries < 2^32 - 64 per call, every cell_count < 2^31
+ * and every product of two cell counts < 2^32 (grid lines per face are counted in 32 bits).
  */
 #ifndef M2S_H
 #define M2S_H
@@ -36,7 +43,7 @@ extern "C" {
 #endif
 
 #define M2S_VERSION_MAJOR 0
-#define M2S_VERSION_MINOR 1
+#define M2S_VERSION_MINOR 2
 
 /* Return codes.  The reference panics where this ABI returns a negative code; the Rust shim
  * turns a negative code back into panic!(m2s_last_error()). */
@@ -86,7 +93,8 @@ typedef struct m2s_timings {
   float sign_ms;         /* grid-line ray parity planes (Raycast grid path) */
   float distance_ms;     /* nearest-triangle search (+ fused sign resolve) — the dominant kernel's launch */
   float total_ms;        /* first kernel to last kernel, device side */
-  float seed_ms;         /* grid path: the two coarse seed passes that precede the dominant launch */
+  float seed_ms;         /* grid path: what precedes the dominant launch besides the build — jump-flooding seed lattice
+                            (one triangle per packet brick) and the cut lists (k_cut) */
   float reserved_f;
   uint64_t n_triangles;
   uint64_t n_units;      /* voxels or queries produced by this call */
@@ -112,7 +120,23 @@ typedef struct m2s_opts {
                            1: `stream` is used exactly as given, and NULL means the device's default (null) stream —
                               needed by callers whose "current stream" IS the default stream (torch does this) and who
                               order other work (e.g. an RCCL collective) after this call without a host sync */
+  /* ---- fields below exist when struct_size >= sizeof(m2s_opts) of version 0.2 (M2S_OPTS_V1_SIZE bytes = version 0.1) ---- */
+  int32_t lane;         /* context lane on `device`, 0 .. M2S_MAX_LANES-1: calls on different lanes do not serialise (Threading) */
+  uint32_t n_peer_out;  /* grid path, device memory: number of entries of peer_out (<= M2S_MAX_PEERS) */
+  float* const* peer_out; /* whole-grid buffers like `out`, on OTHER devices (peer access enabled: same process after
+                             hipDeviceEnablePeerAccess, or mapped from another process with m2s_ipc_open) or on this one:
+                             the x-slab this call computes is written to each of them as well, so that after every shard's
+                             call each buffer holds the whole grid with no separate all-gather */
+  int32_t peer_mode;    /* how: 0 = M2S_PEER_PUSH, one copy kernel per slab piece after its walk, 16 B per lane = 1 KiB per wave
+                                    store instruction (xGMI-friendly request size; the default);
+                                1 = M2S_PEER_STORE, the walk's epilogue stores every value to every peer itself (no extra pass over
+                                    the slab, but 16-byte runs: a 4x4x4 brick row) */
+  int32_t reserved2;
 } m2s_opts;
+#define M2S_OPTS_V1_SIZE 56
+#define M2S_MAX_LANES 16
+#define M2S_MAX_PEERS 15
+enum m2s_peer_mode { M2S_PEER_PUSH = 0, M2S_PEER_STORE = 1 };
 
 /* generate_sdf — lib.rs:291-311.
  * vertices: n_vertices packed xyz f32.  indices: n_indices values of index_bytes (2 or 4) each, or NULL.
@@ -127,6 +151,56 @@ int m2s_generate_sdf(const float* vertices, size_t n_vertices, const void* indic
 int m2s_generate_grid_sdf(const float* vertices, size_t n_vertices, const void* indices, size_t n_indices,
                           int index_bytes, int topology, const m2s_grid* grid, int sign_method, float* out,
                           const m2s_opts* opts);
+
+/* ---- multi-GPU generate_grid_sdf (SURVEY.md 8b "device list", 8e) -----------------------------------------
+ * generate/grid.rs:265-274 is the one signature a caller of the reference has; this is the same call spread over the
+ * GPUs of one node from ONE process: one host thread per listed device, the mesh replicated (every device builds its own
+ * LBVH: the build is sub-millisecond and needs no exchange), the grid cut into contiguous x-slabs (cell axis 0 is the
+ * slowest axis of the output, grid.rs:122-124, so a slab is one contiguous range), sign planes marked per device for
+ * the whole grid (hits are slab independent).  No data-path collective:
+ *   mem_kind == M2S_MEM_HOST   vertices / indices / outs[0] are host pointers.  Every device uploads the mesh and streams
+ *                              its finished slab straight into the caller's array over its own PCIe link (pinned ring,
+ *                              pipelined with the compute) — the drop-in form behind generate_grid_sdf's Vec<f32>.
+ *   mem_kind == M2S_MEM_DEVICE vertices / indices live on devices[0]; outs[k] is a whole-grid buffer on devices[k].
+ *                              On return EVERY buffer holds the whole grid:
+ *                                exchange M2S_XCHG_PEER  each device writes its slab into all buffers itself over xGMI
+ *                                                        (hipDeviceEnablePeerAccess; m2s_opts.peer_out / peer_mode);
+ *                                exchange M2S_XCHG_RCCL  ncclAllGather from librccl (loaded on first use), in place;
+ *                                exchange M2S_XCHG_NONE  nothing: buffer k holds slab k only;
+ *                                exchange M2S_XCHG_AUTO  PEER when every pair of devices can access each other, else RCCL.
+ * `devices` may name a device more than once (two shards on one GPU: how the path is tested on a 1-GPU box).
+ * Errors as m2s_generate_grid_sdf; the first failing shard's code is returned. */
+enum m2s_exchange { M2S_XCHG_AUTO = 0, M2S_XCHG_PEER = 1, M2S_XCHG_RCCL = 2, M2S_XCHG_NONE = 3 };
+typedef struct m2s_multi_opts {
+  uint32_t struct_size;
+  int32_t n_devices;        /* number of shards; 0 = one per visible device */
+  const int32_t* devices;   /* n_devices HIP ordinals; NULL = 0 .. n_devices-1 */
+  int32_t mem_kind;         /* enum m2s_mem_kind */
+  int32_t exchange;         /* enum m2s_exchange; device memory only */
+  int32_t peer_mode;        /* enum m2s_peer_mode for M2S_XCHG_PEER */
+  int32_t algorithm;        /* as m2s_opts.algorithm */
+  m2s_timings* timings;     /* optional, n_devices entries: per-shard phase timings */
+  float* wall_ms;           /* optional: host wall time of the whole call */
+  int32_t* exchange_used;   /* optional: the exchange that ran (M2S_XCHG_PEER / RCCL / NONE) */
+} m2s_multi_opts;
+int m2s_generate_grid_sdf_multi(const float* vertices, size_t n_vertices, const void* indices, size_t n_indices,
+                                int index_bytes, int topology, const m2s_grid* grid, int sign_method, float* const* outs,
+                                const m2s_multi_opts* opts);
+/* x-slab [*x_begin, *x_end) of shard `k` out of `n` for a grid with `nx` layers (sizes differ by at most one layer). */
+void m2s_slab_bounds(uint64_t nx, int n, int k, uint64_t* x_begin, uint64_t* x_end);
+
+/* One process per GPU (torch.distributed / MPI launchers): the same no-collective exchange across processes.
+ * Every rank allocates its whole-grid buffer with m2s_shared_alloc (a dedicated hipMalloc block, so that its IPC handle
+ * maps exactly this buffer), exports it, exchanges the 64-byte handles by any host-side means, opens the other ranks'
+ * handles and passes the mapped pointers as m2s_opts.peer_out.  A host-side barrier after the local stream has drained
+ * tells a rank that its own buffer is complete (the peers' pushes are ordinary device writes, finished when their
+ * streams are). */
+#define M2S_IPC_HANDLE_BYTES 64
+int m2s_shared_alloc(size_t bytes, int device, void** device_ptr);
+int m2s_shared_free(void* device_ptr, int device);
+int m2s_ipc_export(const void* device_ptr, uint8_t handle[M2S_IPC_HANDLE_BYTES]);
+int m2s_ipc_open(const uint8_t handle[M2S_IPC_HANDLE_BYTES], int device, void** device_ptr);
+int m2s_ipc_close(void* device_ptr, int device);
 
 /* ---- persistent mesh (optional) ------------------------------------------------------------------
  * The reference rebuilds its acceleration structures inside every call (generate/grid.rs:95-111,
@@ -145,7 +219,9 @@ int m2s_mesh_generate_sdf(m2s_mesh* mesh, const float* queries, size_t n_queries
                           size_t* n_out, const m2s_opts* opts);
 /* Device-memory calls made with opts->synchronous == 0 return before the GPU has finished and report no
  * per-call timings; this sums the dominant-kernel durations of all such calls since the last drain
- * (distance_ms, distance_launches, n_units; accel_build_ms = the mesh build).  Blocks until they finished. */
+ * (distance_ms, distance_launches, n_units; accel_build_ms = the mesh build).  Blocks until they finished.
+ * Asynchronous calls also DEFER their device-side error report to this call: M2S_ERR_NAN if any of them met a
+ * NaN distance in SignMethod::Normal (the reference panics, lib.rs:257). */
 int m2s_mesh_drain_timings(m2s_mesh* mesh, m2s_timings* timings);
 
 /* Grid helpers with the reference's exact f32 arithmetic (so callers need not re-derive it).

@@ -48,6 +48,34 @@ class M2SOpts(C.Structure):
         ("timings", C.POINTER(M2STimings)),
         ("synchronous", C.c_int32),
         ("stream_mode", C.c_int32),
+        # version 0.2 (struct_size >= sizeof): context lane, peer outputs
+        ("lane", C.c_int32),
+        ("n_peer_out", C.c_uint32),
+        ("peer_out", C.POINTER(C.c_void_p)),
+        ("peer_mode", C.c_int32),
+        ("reserved2", C.c_int32),
+    ]
+
+
+OPTS_V1_SIZE = 56
+MAX_PEERS = 15
+PEER_PUSH, PEER_STORE = 0, 1
+XCHG_AUTO, XCHG_PEER, XCHG_RCCL, XCHG_NONE = 0, 1, 2, 3
+IPC_HANDLE_BYTES = 64
+
+
+class M2SMultiOpts(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32),
+        ("n_devices", C.c_int32),
+        ("devices", C.POINTER(C.c_int32)),
+        ("mem_kind", C.c_int32),
+        ("exchange", C.c_int32),
+        ("peer_mode", C.c_int32),
+        ("algorithm", C.c_int32),
+        ("timings", C.POINTER(M2STimings)),
+        ("wall_ms", C.POINTER(C.c_float)),
+        ("exchange_used", C.POINTER(C.c_int32)),
     ]
 
 
@@ -112,6 +140,13 @@ EXPORTS = [
     "m2s_gltf_open",
     "m2s_gltf_instances",
     "m2s_gltf_close",
+    "m2s_generate_grid_sdf_multi",
+    "m2s_slab_bounds",
+    "m2s_shared_alloc",
+    "m2s_shared_free",
+    "m2s_ipc_export",
+    "m2s_ipc_open",
+    "m2s_ipc_close",
 ]
 
 
@@ -208,6 +243,21 @@ def lib():
         L.m2s_gltf_instances.argtypes = [C.c_void_p, C.POINTER(M2SInstance), C.c_size_t]
         L.m2s_gltf_close.restype = None
         L.m2s_gltf_close.argtypes = [C.c_void_p]
+        L.m2s_generate_grid_sdf_multi.restype = C.c_int
+        L.m2s_generate_grid_sdf_multi.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_int,
+                                                  C.POINTER(M2SGrid), C.c_int, C.POINTER(C.c_void_p), C.POINTER(M2SMultiOpts)]
+        L.m2s_slab_bounds.restype = None
+        L.m2s_slab_bounds.argtypes = [C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.m2s_shared_alloc.restype = C.c_int
+        L.m2s_shared_alloc.argtypes = [C.c_size_t, C.c_int, C.POINTER(C.c_void_p)]
+        L.m2s_shared_free.restype = C.c_int
+        L.m2s_shared_free.argtypes = [C.c_void_p, C.c_int]
+        L.m2s_ipc_export.restype = C.c_int
+        L.m2s_ipc_export.argtypes = [C.c_void_p, C.c_char_p]
+        L.m2s_ipc_open.restype = C.c_int
+        L.m2s_ipc_open.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]
+        L.m2s_ipc_close.restype = C.c_int
+        L.m2s_ipc_close.argtypes = [C.c_void_p, C.c_int]
         _lib = L
     return _lib
 

@@ -221,12 +221,20 @@ class _Args:
                 self.keep.append(q)
         self.topology = topology.kind
 
-    def opts(self, timings=None, algorithm=0, x_begin=0, x_end=0, synchronous=True):
+    def opts(self, timings=None, algorithm=0, x_begin=0, x_end=0, synchronous=True, peer_out=None, peer_mode=0, lane=0):
         o = M2SOpts()
         o.struct_size = C.sizeof(M2SOpts)
         o.algorithm = int(algorithm)
         o.x_begin, o.x_end = int(x_begin), int(x_end)
         o.synchronous = 1 if synchronous else 0
+        o.lane = int(lane)
+        if peer_out:
+            ptrs = [int(p.data_ptr()) if hasattr(p, "data_ptr") else int(p) for p in peer_out]
+            arr = (C.c_void_p * len(ptrs))(*ptrs)
+            self.keep.append(arr)
+            o.n_peer_out = len(ptrs)
+            o.peer_out = C.cast(arr, C.POINTER(C.c_void_p))
+            o.peer_mode = int(peer_mode)
         if timings is not None:
             o.timings = C.pointer(timings)
         if self.device:
@@ -268,10 +276,26 @@ def generate_sdf(vertices, indices: Topology, query_points, acceleration_method:
     return out[: n_out.value]
 
 
+class PeerMode(enum.IntEnum):
+    """include/m2s.h `m2s_peer_mode`: how a slab reaches the peers' whole-grid buffers."""
+    Push = 0    # one wide copy kernel per slab piece, overlapped with the next piece's walk
+    Store = 1   # the walk's epilogue stores every value to every peer
+
+
+class Exchange(enum.IntEnum):
+    """include/m2s.h `m2s_exchange` (device-resident results of generate_grid_sdf_multi)."""
+    Auto = 0
+    Peer = 1
+    Rccl = 2
+    Nothing = 3
+
+
 def generate_grid_sdf(vertices, indices: Topology, grid: Grid, sign_method: SignMethod = SignMethod.Raycast, *,
-                      timings: M2STimings = None, algorithm: int = 0, x_slab: Sequence[int] = None, out=None):
+                      timings: M2STimings = None, algorithm: int = 0, x_slab: Sequence[int] = None, out=None,
+                      peer_out=None, peer_mode: PeerMode = PeerMode.Push, lane: int = 0, synchronous: bool = True):
     """generate/grid.rs:265-378.  `x_slab=(x0, x1)` computes only cells with x0 <= x < x1 (the rest
-    of `out` is left untouched); used by the multi-GPU driver in distributed.py."""
+    of `out` is left untouched); used by the multi-GPU driver in distributed.py.  `peer_out`: whole-grid device
+    buffers (tensors or raw pointers, usually on other GPUs) that receive the same slab (m2s_opts.peer_out)."""
     a = _Args(vertices, indices)
     total = grid.get_total_cell_count()
     if out is None:
@@ -288,12 +312,138 @@ def generate_grid_sdf(vertices, indices: Topology, grid: Grid, sign_method: Sign
     xb, xe = (0, 0) if x_slab is None else (int(x_slab[0]), int(x_slab[1]))
     if x_slab is not None and xb == xe:
         return out
-    o = a.opts(timings, algorithm, xb, xe)
+    o = a.opts(timings, algorithm, xb, xe, synchronous or not a.device, peer_out, peer_mode, lane)
     rc = _lib.lib().m2s_generate_grid_sdf(a.p_verts, a.n_verts, a.p_idx, a.n_idx, a.index_bytes, a.topology,
                                           C.byref(grid._g), int(sign_method), p_out, C.byref(o))
     if rc != _lib.M2S_OK:
         _raise(rc)
     return out
+
+
+def slab_bounds(nx: int, n: int, k: int):
+    """m2s_slab_bounds: contiguous x-slab [x0, x1) of shard k out of n (sizes differ by at most one layer)."""
+    a, b = C.c_uint64(0), C.c_uint64(0)
+    _lib.lib().m2s_slab_bounds(int(nx), int(n), int(k), C.byref(a), C.byref(b))
+    return int(a.value), int(b.value)
+
+
+def generate_grid_sdf_multi(vertices, indices: Topology, grid: Grid, sign_method: SignMethod = SignMethod.Raycast, *,
+                            devices: Sequence[int] = None, outs=None, exchange: Exchange = Exchange.Auto,
+                            peer_mode: PeerMode = PeerMode.Push, algorithm: int = 0, info: dict = None):
+    """generate_grid_sdf over several GPUs from this one process (m2s_generate_grid_sdf_multi): one host thread per
+    device inside the library, contiguous x-slabs, no data-path collective.
+
+    numpy in  -> one numpy array out (every device streams its slab into it over its own PCIe link);
+    torch CUDA tensors in (on devices[0]) -> a list of whole-grid CUDA tensors, one per entry of `devices`, each
+    holding the WHOLE grid on return (peer writes over xGMI, or RCCL where peer access is unavailable).
+    `devices` may repeat a device (two shards on one GPU).  `info` (optional dict) receives wall_ms, exchange, timings."""
+    a = _Args(vertices, indices)
+    total = grid.get_total_cell_count()
+    L = _lib.lib()
+    if devices is None:
+        devices = list(range(L.m2s_device_count()))
+    devices = [int(d) for d in devices]
+    n = len(devices)
+    mo = _lib.M2SMultiOpts()
+    mo.struct_size = C.sizeof(_lib.M2SMultiOpts)
+    mo.n_devices = n
+    dev_arr = (C.c_int32 * max(n, 1))(*devices)
+    mo.devices = C.cast(dev_arr, C.POINTER(C.c_int32))
+    mo.exchange = int(exchange)
+    mo.peer_mode = int(peer_mode)
+    mo.algorithm = int(algorithm)
+    tims = (M2STimings * max(n, 1))()
+    mo.timings = C.cast(tims, C.POINTER(M2STimings))
+    wall, used = C.c_float(0.0), C.c_int32(-1)
+    mo.wall_ms = C.pointer(wall)
+    mo.exchange_used = C.pointer(used)
+    if a.device:
+        mo.mem_kind = _lib.MEM_DEVICE
+        dev0 = a.dev.index if a.dev.index is not None else a.torch.cuda.current_device()
+        assert n == 0 or devices[0] == dev0, "the mesh tensors must live on devices[0]"
+        if outs is None:
+            outs = [a.torch.empty(total, dtype=a.torch.float32, device=f"cuda:{d}") for d in devices]
+        assert len(outs) == n and all(o.is_cuda and o.dtype == a.torch.float32 and o.numel() == total and o.is_contiguous() for o in outs)
+        a.torch.cuda.synchronize(a.dev)      # the library uses streams of its own: inputs must be complete
+        ptrs = (C.c_void_p * max(n, 1))(*[(o.data_ptr() if total else None) for o in outs])
+        result = outs
+    else:
+        mo.mem_kind = _lib.MEM_HOST
+        if outs is None:
+            outs = np.empty(total, np.float32)
+        assert outs.dtype == np.float32 and outs.size == total and outs.flags["C_CONTIGUOUS"]
+        ptrs = (C.c_void_p * 1)(outs.ctypes.data if total else None)
+        result = outs
+    rc = L.m2s_generate_grid_sdf_multi(a.p_verts, a.n_verts, a.p_idx, a.n_idx, a.index_bytes, a.topology, C.byref(grid._g),
+                                       int(sign_method), C.cast(ptrs, C.POINTER(C.c_void_p)), C.byref(mo))
+    if rc != _lib.M2S_OK:
+        _raise(rc)
+    if info is not None:
+        info["wall_ms"] = float(wall.value)
+        info["exchange"] = Exchange(used.value).name if used.value >= 0 else None
+        info["timings"] = [tims[k] for k in range(n)]
+        info["_keep"] = tims
+    return result
+
+
+class SharedGrid:
+    """A whole-grid device buffer other PROCESSES can map (m2s_shared_alloc / m2s_ipc_*): the one-process-per-GPU form of
+    the peer exchange.  `tensor` views it as a torch CUDA tensor; `handle` is the 64-byte token to send to the other ranks;
+    `SharedGrid.open(handle, device)` maps a peer's buffer and returns its device pointer wrapper."""
+
+    def __init__(self, n_cells: int, device: int):
+        self.n, self.device, self.owner = int(n_cells), int(device), True
+        p = C.c_void_p()
+        rc = _lib.lib().m2s_shared_alloc(self.n * 4, self.device, C.byref(p))
+        if rc != _lib.M2S_OK:
+            _raise(rc)
+        self.ptr = int(p.value)
+
+    @property
+    def handle(self) -> bytes:
+        buf = C.create_string_buffer(_lib.IPC_HANDLE_BYTES)
+        rc = _lib.lib().m2s_ipc_export(self.ptr, buf)
+        if rc != _lib.M2S_OK:
+            _raise(rc)
+        return bytes(buf.raw)
+
+    @classmethod
+    def open(cls, handle: bytes, n_cells: int, device: int):
+        g = cls.__new__(cls)
+        g.n, g.device, g.owner = int(n_cells), int(device), False
+        p = C.c_void_p()
+        rc = _lib.lib().m2s_ipc_open(C.create_string_buffer(bytes(handle), _lib.IPC_HANDLE_BYTES), g.device, C.byref(p))
+        if rc != _lib.M2S_OK:
+            _raise(rc)
+        g.ptr = int(p.value)
+        return g
+
+    def data_ptr(self):
+        return self.ptr
+
+    @property
+    def __cuda_array_interface__(self):
+        return {"shape": (self.n,), "typestr": "<f4", "data": (self.ptr, False), "version": 2, "strides": None}
+
+    @property
+    def tensor(self):
+        import torch
+
+        t = torch.as_tensor(self, device=f"cuda:{self.device}")
+        assert t.data_ptr() == self.ptr, "torch copied the buffer instead of wrapping it"
+        return t
+
+    def close(self):
+        if getattr(self, "ptr", 0):
+            L = _lib.lib()
+            (L.m2s_shared_free if self.owner else L.m2s_ipc_close)(self.ptr, self.device)
+            self.ptr = 0
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class Mesh:
@@ -321,7 +471,8 @@ class Mesh:
         return int(_lib.lib().m2s_mesh_triangle_count(self._h))
 
     def generate_grid_sdf(self, grid: Grid, sign_method: SignMethod = SignMethod.Raycast, *, timings: M2STimings = None,
-                          algorithm: int = 0, x_slab: Sequence[int] = None, out=None, synchronous: bool = True):
+                          algorithm: int = 0, x_slab: Sequence[int] = None, out=None, synchronous: bool = True,
+                          peer_out=None, peer_mode: PeerMode = PeerMode.Push):
         a = self._a
         total = grid.get_total_cell_count()
         if out is None:
@@ -330,7 +481,7 @@ class Mesh:
         xb, xe = (0, 0) if x_slab is None else (int(x_slab[0]), int(x_slab[1]))
         if x_slab is not None and xb == xe:
             return out
-        o = a.opts(timings, algorithm, xb, xe, synchronous or not a.device)
+        o = a.opts(timings, algorithm, xb, xe, synchronous or not a.device, peer_out, peer_mode)
         rc = _lib.lib().m2s_mesh_generate_grid_sdf(self._h, C.byref(grid._g), int(sign_method), p_out, C.byref(o))
         if rc != _lib.M2S_OK:
             _raise(rc)

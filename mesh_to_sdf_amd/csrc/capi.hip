@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -28,7 +29,14 @@ void set_error(const char* fmt, ...) {
 void clear_error() { g_err[0] = 0; }
 
 std::mutex g_mu;
-std::map<int, DeviceState> g_dev;
+std::map<std::pair<int, int>, std::unique_ptr<DeviceState>> g_dev;   // (device, lane) -> context
+
+DeviceState* find_state(int device, int lane) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  auto& p = g_dev[{device, lane}];
+  if (!p) p.reset(new DeviceState());
+  return p.get();
+}
 
 int fail(int code, const char* fmt, ...) {
   va_list ap;
@@ -42,13 +50,11 @@ int fail(int code, const char* fmt, ...) {
 // end up sharing a queue with one of the caller's and serialise work the caller meant to overlap (measured: the two
 // alternating piece streams of the sharded driver lost their overlap, 2.5 -> 3.0 ms per step, once the library held
 // two streams of its own).  So streams are created only when a call really needs them.
-int get_state(int device, DeviceState** out) {
-  DeviceState& s = g_dev[device];
+static int init_state(DeviceState& s) {   // caller holds s.mu; the device is current
   if (!s.h_err) {
     for (auto& e : s.ev) M2S_HIP_CHECK(hipEventCreate(&e));
     M2S_HIP_CHECK(hipHostMalloc((void**)&s.h_err, 64, hipHostMallocDefault));
   }
-  *out = &s;
   return 0;
 }
 
@@ -113,7 +119,21 @@ int resolve_ctx(const m2s_opts* opts, CallCtx* c, DeviceState** st) {
     return fail(M2S_ERR_HIP, "no HIP device available: the MI355X kernels cannot run (there is no CPU fallback)");
   int dev = -1;
   if (opts) {
-    if (opts->struct_size != 0 && opts->struct_size < sizeof(m2s_opts)) return fail(M2S_ERR_BAD_ARG, "m2s_opts.struct_size too small");
+    // struct_size 0 or M2S_OPTS_V1_SIZE: a version-0.1 caller, the fields after stream_mode do not exist
+    if (opts->struct_size != 0 && opts->struct_size < M2S_OPTS_V1_SIZE) return fail(M2S_ERR_BAD_ARG, "m2s_opts.struct_size too small");
+    if (opts->struct_size >= sizeof(m2s_opts)) {
+      if (opts->lane < 0 || opts->lane >= M2S_MAX_LANES) return fail(M2S_ERR_BAD_ARG, "m2s_opts.lane %d outside [0, %d)", opts->lane, M2S_MAX_LANES);
+      if (opts->n_peer_out > M2S_MAX_PEERS) return fail(M2S_ERR_BAD_ARG, "m2s_opts.n_peer_out %u > %d", opts->n_peer_out, M2S_MAX_PEERS);
+      if (opts->n_peer_out && !opts->peer_out) return fail(M2S_ERR_BAD_ARG, "m2s_opts.peer_out is NULL");
+      if (opts->peer_mode != M2S_PEER_PUSH && opts->peer_mode != M2S_PEER_STORE) return fail(M2S_ERR_BAD_ARG, "bad m2s_opts.peer_mode");
+      c->lane = opts->lane;
+      c->peer_mode = opts->peer_mode;
+      c->peers.n = opts->n_peer_out;
+      for (uint32_t i = 0; i < opts->n_peer_out; ++i) {
+        if (!opts->peer_out[i]) return fail(M2S_ERR_BAD_ARG, "m2s_opts.peer_out[%u] is NULL", i);
+        c->peers.p[i] = opts->peer_out[i];
+      }
+    }
     dev = opts->device;
     c->mem_kind = opts->mem_kind;
     c->algorithm = opts->algorithm;
@@ -128,7 +148,10 @@ int resolve_ctx(const m2s_opts* opts, CallCtx* c, DeviceState** st) {
   if (dev >= ndev) return fail(M2S_ERR_BAD_ARG, "device %d out of range (%d devices)", dev, ndev);
   M2S_HIP_CHECK(hipSetDevice(dev));
   c->device = dev;
-  int rc = get_state(dev, st);
+  if (c->peers.n && c->mem_kind != M2S_MEM_DEVICE) return fail(M2S_ERR_BAD_ARG, "m2s_opts.peer_out needs mem_kind == M2S_MEM_DEVICE");
+  *st = find_state(dev, c->lane);
+  c->lock = std::unique_lock<std::mutex>((*st)->mu);
+  int rc = init_state(**st);
   if (rc) return rc;
   if (opts && (opts->stream || opts->stream_mode == 1)) c->stream = (hipStream_t)opts->stream;
   else if ((rc = own_stream(**st, &c->stream)) != 0) return rc;
@@ -249,9 +272,11 @@ int run_grid_distance(Arena& ws, const CallCtx& c, DeviceState& st, DeviceMesh m
     M2S_HIP_CHECK(hipStreamSynchronize(c.stream));
     mesh.stats = d_stats;
   }
+  // peers: M2S_PEER_STORE hands them to the walk's epilogue; M2S_PEER_PUSH (run_grid_distance_push) never comes here with any
   int rc = launch_grid_distance(ws, c.stream, mesh, g, sign_method == M2S_SIGN_RAYCAST ? MODE_UNSIGNED : MODE_NORMAL_FOLD,
                                 plane, c.algorithm, d_out, d_err, st.ev[4], st.planes_done, !c.sync,
-                                st.have_raw_seeds ? &st.raw_seeds : nullptr, st.have_raw_seeds ? st.seeds_done : nullptr);
+                                st.have_raw_seeds ? &st.raw_seeds : nullptr, st.have_raw_seeds ? st.seeds_done : nullptr,
+                                c.peers.n ? &c.peers : nullptr);
   st.have_raw_seeds = false;
   if (rc) return rc;
   M2S_HIP_CHECK(hipEventRecord(st.ev[3], c.stream));
@@ -265,6 +290,53 @@ int run_grid_distance(Arena& ws, const CallCtx& c, DeviceState& st, DeviceMesh m
   return 0;
 }
 
+
+// M2S_PEER_PUSH: the slab is walked in x-pieces on the call's stream; every finished piece is copied to all peers by one
+// wide-store kernel on the context's copy stream while the next piece is being walked, so that only the last piece's
+// push is exposed (xGMI is point-to-point: 7 peers = 7 links in parallel, ~1/8 of the grid over each).  Seeds and cut
+// lists are prepared once for the slab (the pieces are nothing but walks).  Records ev[4] before the first and ev[3]
+// after the last walk; on return the call's stream also waits for the last push.
+int run_grid_distance_push(Arena& ws, const CallCtx& c, DeviceState& st, const DeviceMesh& mesh, const GridParams& g,
+                           int sign_method, const uint32_t* plane, float* d_out, int* d_err, uint32_t* pieces_out) {
+  const uint64_t row = (uint64_t)g.n[1] * g.n[2];
+  const uint32_t layers = g.xe - g.xb;
+  static const uint32_t want_pieces = getenv("M2S_PUSH_PIECES") ? (uint32_t)std::max(1, atoi(getenv("M2S_PUSH_PIECES"))) : 4u;
+  const uint64_t bx = 2ull << g.bl[0];                              // whole cut-list blocks (2 bricks) along x
+  uint64_t lpp = (layers + want_pieces - 1) / want_pieces;
+  lpp = std::max<uint64_t>(bx, (lpp + bx - 1) / bx * bx);
+  if ((uint64_t)layers * row * 4 < (8u << 20)) lpp = std::max<uint64_t>(lpp, layers);   // small slabs: one piece
+  const uint32_t pieces = (uint32_t)((layers + lpp - 1) / lpp);
+  *pieces_out = pieces;
+  if (!st.copy_stream) M2S_HIP_CHECK(hipStreamCreateWithFlags(&st.copy_stream, hipStreamNonBlocking));
+  while (st.piece_events.size() < (size_t)pieces + 1) {
+    hipEvent_t e;
+    M2S_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    st.piece_events.push_back(e);
+  }
+  const int mode = sign_method == M2S_SIGN_RAYCAST ? MODE_UNSIGNED : MODE_NORMAL_FOLD;
+  GridWalkPlan plan;
+  if (st.have_raw_seeds) M2S_HIP_CHECK(hipStreamWaitEvent(c.stream, st.seeds_done, 0));
+  int rc = prepare_grid_walk(ws, c.stream, mesh, g, c.algorithm, !c.sync, &plan, st.have_raw_seeds ? &st.raw_seeds : nullptr);
+  st.have_raw_seeds = false;
+  if (rc) return rc;
+  if (st.planes_done) M2S_HIP_CHECK(hipStreamWaitEvent(c.stream, st.planes_done, 0));
+  M2S_HIP_CHECK(hipEventRecord(st.ev[4], c.stream));
+  for (uint32_t i = 0; i < pieces; ++i) {
+    GridParams gp = g;
+    gp.xb = g.xb + (uint32_t)(i * lpp);
+    gp.xe = (uint32_t)std::min<uint64_t>(g.xe, gp.xb + lpp);
+    rc = launch_grid_walk(c.stream, mesh, gp, mode, plane, c.algorithm, plan, (uint32_t)((i * lpp) >> g.bl[0]), d_out, d_err);
+    if (rc) return rc;
+    if (i + 1 == pieces) M2S_HIP_CHECK(hipEventRecord(st.ev[3], c.stream));
+    M2S_HIP_CHECK(hipEventRecord(st.piece_events[i], c.stream));
+    M2S_HIP_CHECK(hipStreamWaitEvent(st.copy_stream, st.piece_events[i], 0));
+    rc = launch_push_cells(st.copy_stream, d_out, c.peers, (uint64_t)gp.xb * row, (uint64_t)(gp.xe - gp.xb) * row);
+    if (rc) return rc;
+  }
+  M2S_HIP_CHECK(hipEventRecord(st.piece_events[pieces], st.copy_stream));
+  M2S_HIP_CHECK(hipStreamWaitEvent(c.stream, st.piece_events[pieces], 0));
+  return 0;
+}
 
 // AccelerationMethod + SignMethod -> kernel mode, sign source, algorithm (include/m2s.h lists the rules).
 void select_generic_mode(int accel, int sign_method, int req_algorithm, int* mode, int* sign_src, int* algorithm) {
@@ -290,6 +362,9 @@ int fill_grid_params(const m2s_grid* grid, const m2s_opts* opts, GridParams* g, 
   const uint64_t gx = grid->cell_count[0], gy = grid->cell_count[1], gz = grid->cell_count[2];
   if (gx >= 0x7fffffffull || gy >= 0x7fffffffull || gz >= 0x7fffffffull) return fail(M2S_ERR_BAD_ARG, "cell_count too large");
   const uint64_t xb = opts ? opts->x_begin : 0, xe = (opts && opts->x_end) ? opts->x_end : gx;
+  // sign.hip counts the grid lines a triangle's window covers (and hands them out in chunks) in 32 bits
+  if (gx * gy >= (1ull << 32) || gx * gz >= (1ull << 32) || gy * gz >= (1ull << 32))
+    return fail(M2S_ERR_BAD_ARG, "grid face with 2^32 or more lines (cell_count %llu x %llu x %llu)", (unsigned long long)gx, (unsigned long long)gy, (unsigned long long)gz);
   if (xb > xe || xe > gx) return fail(M2S_ERR_BAD_ARG, "x-slab [%llu,%llu) outside [0,%llu)", (unsigned long long)xb, (unsigned long long)xe, (unsigned long long)gx);
   for (int k = 0; k < 3; ++k) {
     g->first[k] = grid->first_cell[k];
@@ -536,7 +611,9 @@ int staged_d2h_to_file(DeviceState& st, hipStream_t stream, FILE* f, const char*
 // (it also lets one step be split into several slab calls whose all-gathers
 // overlap the next slab's compute).  Caches the sign planes of the last grid it was used with.
 struct m2s_mesh {
+  std::mutex mu;    // the mesh's own state (cached planes, pending timings); taken before the context's lock
   int device = -1;
+  int lane = 0;     // context whose spare blocks this mesh recycles
   char* mem = nullptr;
   size_t mem_bytes = 0;
   m2s::DeviceMesh dm{};
@@ -553,10 +630,40 @@ struct m2s_mesh {
   struct Pending {
     hipEvent_t a, b;
     uint64_t units;
+    uint32_t launches;
   };
   std::vector<Pending> pending;  // dominant-launch event pairs of asynchronous calls, not yet read
   std::vector<hipEvent_t> free_events;
+  // durations of asynchronous calls whose events have already been read and recycled (the list above stays bounded
+  // however long the mesh lives: completed pairs are folded in here at the start of every asynchronous call)
+  double acc_ms = 0.0;
+  uint64_t acc_units = 0;
+  uint32_t acc_launches = 0;
+  int* d_err_async = nullptr;     // device error word of asynchronous calls (inside `mem`), read by m2s_mesh_drain_timings
+  bool async_readers = false;     // asynchronous walks may still be reading the sign planes
 };
+
+// Folds the finished entries of m->pending into the accumulators and recycles their events.
+static void reap_pending(m2s_mesh* m, bool wait) {
+  size_t keep = 0;
+  for (size_t i = 0; i < m->pending.size(); ++i) {
+    auto& p = m->pending[i];
+    const hipError_t q = wait ? hipEventSynchronize(p.b) : hipEventQuery(p.b);
+    if (q == hipSuccess) {
+      float ms = 0.0f;
+      (void)hipEventElapsedTime(&ms, p.a, p.b);
+      m->acc_ms += ms;
+      m->acc_units += p.units;
+      m->acc_launches += p.launches;
+      m->free_events.push_back(p.a);
+      m->free_events.push_back(p.b);
+    } else {
+      if (q != hipErrorNotReady) (void)hipGetLastError();
+      m->pending[keep++] = p;
+    }
+  }
+  m->pending.resize(keep);
+}
 
 using namespace m2s;
 
@@ -581,22 +688,24 @@ const char* m2s_last_error(void) { return g_err; }
 void m2s_release_workspace(void) {
   std::lock_guard<std::mutex> lk(g_mu);
   for (auto& kv : g_dev) {
-    if (hipSetDevice(kv.first) != hipSuccess) continue;
+    DeviceState& ds = *kv.second;
+    std::lock_guard<std::mutex> lk2(ds.mu);
+    if (hipSetDevice(kv.first.first) != hipSuccess) continue;
     (void)hipDeviceSynchronize();
-    release_scratch(kv.second);
-    if (kv.second.spare_plane) (void)hipFree(kv.second.spare_plane);
-    kv.second.spare_plane = nullptr;
-    kv.second.spare_plane_bytes = 0;
-    for (auto e : kv.second.timing_events) (void)hipEventDestroy(e);
-    kv.second.timing_events.clear();
-    if (kv.second.spare_mesh) (void)hipFree(kv.second.spare_mesh);
-    kv.second.spare_mesh = nullptr;
-    kv.second.spare_mesh_bytes = 0;
-    for (auto& r : kv.second.ring) {
+    release_scratch(ds);
+    if (ds.spare_plane) (void)hipFree(ds.spare_plane);
+    ds.spare_plane = nullptr;
+    ds.spare_plane_bytes = 0;
+    for (auto e : ds.timing_events) (void)hipEventDestroy(e);
+    ds.timing_events.clear();
+    if (ds.spare_mesh) (void)hipFree(ds.spare_mesh);
+    ds.spare_mesh = nullptr;
+    ds.spare_mesh_bytes = 0;
+    for (auto& r : ds.ring) {
       if (r) (void)hipHostFree(r);
       r = nullptr;
     }
-    kv.second.ring_bytes = 0;
+    ds.ring_bytes = 0;
   }
 }
 
@@ -627,7 +736,6 @@ uint64_t m2s_grid_cell_idx(const m2s_grid* grid, const uint64_t cell[3]) {
 int m2s_generate_grid_sdf(const float* vertices, size_t n_vertices, const void* indices, size_t n_indices,
                           int index_bytes, int topology, const m2s_grid* grid, int sign_method, float* out,
                           const m2s_opts* opts) {
-  std::lock_guard<std::mutex> lk(g_mu);
   g_err[0] = 0;
   if (!grid) return fail(M2S_ERR_BAD_ARG, "grid is NULL");
   if (sign_method != M2S_SIGN_RAYCAST && sign_method != M2S_SIGN_NORMAL) return fail(M2S_ERR_BAD_ARG, "bad sign_method %d", sign_method);
@@ -718,6 +826,14 @@ int m2s_generate_grid_sdf(const float* vertices, size_t n_vertices, const void* 
     if (c.timings) c.timings->distance_launches = pieces;   // distance_ms then covers the seed passes of every piece too
     return rc;
   }
+  if (c.peers.n && c.peer_mode == M2S_PEER_PUSH && !getenv("M2S_STATS")) {
+    uint32_t pieces = 1;
+    rc = run_grid_distance_push(ws, c, *st, mesh, g, sign_method, plane, d_out, d_err, &pieces);
+    if (rc) return rc;
+    rc = finish_call(c, *st, d_err, c.timings, n_tris, slab_cells, sign_method == M2S_SIGN_RAYCAST, true);
+    if (c.timings) c.timings->distance_launches = pieces;
+    return rc;
+  }
   rc = run_grid_distance(ws, c, *st, mesh, g, sign_method, plane, d_out, d_err);
   if (rc) return rc;
   if (c.mem_kind == M2S_MEM_HOST)
@@ -728,7 +844,6 @@ int m2s_generate_grid_sdf(const float* vertices, size_t n_vertices, const void* 
 int m2s_generate_sdf(const float* vertices, size_t n_vertices, const void* indices, size_t n_indices, int index_bytes,
                      int topology, const float* queries, size_t n_queries, int accel, int sign_method, float* out,
                      size_t* n_out, const m2s_opts* opts) {
-  std::lock_guard<std::mutex> lk(g_mu);
   g_err[0] = 0;
   if (n_out) *n_out = 0;
   if (accel < M2S_ACCEL_NONE || accel > M2S_ACCEL_RTREE_BVH) return fail(M2S_ERR_BAD_ARG, "bad accel %d", accel);
@@ -793,7 +908,6 @@ int m2s_generate_sdf(const float* vertices, size_t n_vertices, const void* indic
 // ---- persistent mesh ---------------------------------------------------------------------------
 int m2s_mesh_create(const float* vertices, size_t n_vertices, const void* indices, size_t n_indices, int index_bytes,
                     int topology, const m2s_opts* opts, m2s_mesh** out_mesh) {
-  std::lock_guard<std::mutex> lk(g_mu);
   g_err[0] = 0;
   if (!out_mesh) return fail(M2S_ERR_BAD_ARG, "out_mesh is NULL");
   *out_mesh = nullptr;
@@ -806,6 +920,7 @@ int m2s_mesh_create(const float* vertices, size_t n_vertices, const void* indice
   if (rc) return rc;
   m2s_mesh* m = new m2s_mesh();
   m->device = c.device;
+  m->lane = c.lane;
   m->n_tris = n_tris;
   m->mem_bytes = bvh_workspace_bytes(n_tris) + 8192;
   if (c.mem_kind == M2S_MEM_HOST) m->mem_bytes += align_up(n_vertices * 12) + align_up(n_indices * (size_t)(indices ? index_bytes : 0)) + 1024;
@@ -820,9 +935,10 @@ int m2s_mesh_create(const float* vertices, size_t n_vertices, const void* indice
     return fail(M2S_ERR_HIP, "hipMalloc of %zu bytes for the mesh failed", want);
   }
   Arena ws{m->mem, m->mem_bytes, 0};
-  int* d_err = ws.take<int>(16);
+  int* d_err = ws.take<int>(32);
+  m->d_err_async = d_err + 16;
   auto bail = [&](int code) { (void)hipFree(m->mem); delete m; return code; };
-  if (hipMemsetAsync(d_err, 0, 64, c.stream) != hipSuccess) return bail(fail(M2S_ERR_HIP, "memset failed"));
+  if (hipMemsetAsync(d_err, 0, 128, c.stream) != hipSuccess) return bail(fail(M2S_ERR_HIP, "memset failed"));
   StagedMesh sm;
   rc = stage_mesh(ws, c, vertices, n_vertices, indices, n_indices, index_bytes, &sm);
   if (rc) return bail(rc);
@@ -841,10 +957,10 @@ int m2s_mesh_create(const float* vertices, size_t n_vertices, const void* indice
 
 void m2s_mesh_destroy(m2s_mesh* m) {
   if (!m) return;
-  std::lock_guard<std::mutex> lk(g_mu);
+  DeviceState& ds = *find_state(m->device, m->lane);
+  std::unique_lock<std::mutex> lk(ds.mu);
   if (hipSetDevice(m->device) == hipSuccess) {
     (void)hipDeviceSynchronize();
-    DeviceState& ds = g_dev[m->device];
     if (m->mem && !ds.spare_mesh) { ds.spare_mesh = m->mem; ds.spare_mesh_bytes = m->mem_bytes; }
     else if (m->mem) (void)hipFree(m->mem);
     if (m->plane_mem && (!ds.spare_plane || ds.spare_plane_bytes < m->plane_bytes)) {
@@ -859,6 +975,7 @@ void m2s_mesh_destroy(m2s_mesh* m) {
       else (void)hipEventDestroy(e);
     }
   }
+  lk.unlock();
   delete m;
 }
 
@@ -867,9 +984,9 @@ size_t m2s_mesh_triangle_count(const m2s_mesh* m) { return m ? m->n_tris : 0; }
 static bool same_grid(const m2s_grid& a, const m2s_grid& b) { return memcmp(&a, &b, sizeof(m2s_grid)) == 0; }
 
 int m2s_mesh_generate_grid_sdf(m2s_mesh* m, const m2s_grid* grid, int sign_method, float* out, const m2s_opts* opts) {
-  std::lock_guard<std::mutex> lk(g_mu);
   g_err[0] = 0;
   if (!m) return fail(M2S_ERR_BAD_ARG, "mesh is NULL");
+  std::lock_guard<std::mutex> mlk(m->mu);
   if (!grid) return fail(M2S_ERR_BAD_ARG, "grid is NULL");
   if (sign_method != M2S_SIGN_RAYCAST && sign_method != M2S_SIGN_NORMAL) return fail(M2S_ERR_BAD_ARG, "bad sign_method %d", sign_method);
   GridParams g;
@@ -882,7 +999,8 @@ int m2s_mesh_generate_grid_sdf(m2s_mesh* m, const m2s_grid* grid, int sign_metho
   }
   if (!out) return fail(M2S_ERR_BAD_ARG, "out is NULL");
   m2s_opts o{};
-  if (opts) o = *opts;
+  if (opts) memcpy(&o, opts, (opts->struct_size >= sizeof(m2s_opts)) ? sizeof(m2s_opts) : (size_t)M2S_OPTS_V1_SIZE);
+  else o.device = -1;
   if (o.device < 0) o.device = m->device;
   if (o.device != m->device) return fail(M2S_ERR_BAD_ARG, "mesh lives on device %d, call asked for %d", m->device, o.device);
   if (!opts) o.synchronous = 1;
@@ -898,7 +1016,8 @@ int m2s_mesh_generate_grid_sdf(m2s_mesh* m, const m2s_grid* grid, int sign_metho
   if (rc) return rc;
   Arena ws{st->base, st->cap, 0};
   int* d_err = ws.take<int>(16);
-  M2S_HIP_CHECK(hipMemsetAsync(d_err, 0, 64, c.stream));
+  if (c.sync) M2S_HIP_CHECK(hipMemsetAsync(d_err, 0, 64, c.stream));
+  else d_err = m->d_err_async;   // asynchronous calls report through the mesh: m2s_mesh_drain_timings reads and clears it
   float* d_out = out;
   float* d_slab = nullptr;
   if (c.mem_kind == M2S_MEM_HOST) {
@@ -907,6 +1026,7 @@ int m2s_mesh_generate_grid_sdf(m2s_mesh* m, const m2s_grid* grid, int sign_metho
     d_out = d_slab;
     g.out_off = (uint64_t)xb * ny * nz;
   }
+  if (!c.sync) reap_pending(m, false);
   M2S_HIP_CHECK(hipEventRecord(st->ev[0], c.stream));
   M2S_HIP_CHECK(hipEventRecord(st->ev[1], c.stream));
   st->planes_done = nullptr;
@@ -915,7 +1035,8 @@ int m2s_mesh_generate_grid_sdf(m2s_mesh* m, const m2s_grid* grid, int sign_metho
   const uint32_t* plane = nullptr;
   if (sign_method == M2S_SIGN_RAYCAST) {
     if (!m->plane_valid || !same_grid(m->plane_grid, *grid)) {
-      if (m->multi_stream) { M2S_HIP_CHECK(hipDeviceSynchronize()); m->multi_stream = false; }   // readers on other streams
+      // readers of the old planes may still be in flight: asynchronous walks (any stream), or walks on another stream
+      if (m->multi_stream || m->async_readers) { M2S_HIP_CHECK(hipDeviceSynchronize()); m->multi_stream = false; m->async_readers = false; }
       const size_t bytes = sign_workspace_bytes(g, m->n_tris);
       if (bytes > m->plane_bytes) {
         if (m->plane_mem) { M2S_HIP_CHECK(hipDeviceSynchronize()); M2S_HIP_CHECK(hipFree(m->plane_mem)); m->plane_mem = nullptr; m->plane_bytes = 0; }
@@ -958,56 +1079,67 @@ int m2s_mesh_generate_grid_sdf(m2s_mesh* m, const m2s_grid* grid, int sign_metho
     if (c.timings) c.timings->distance_launches = pieces;
     return rc;
   }
-  rc = run_grid_distance(ws, c, *st, m->dm, g, sign_method, plane, d_out, d_err);
+  uint32_t walk_launches = 1;
+  if (c.peers.n && c.peer_mode == M2S_PEER_PUSH && !getenv("M2S_STATS"))
+    rc = run_grid_distance_push(ws, c, *st, m->dm, g, sign_method, plane, d_out, d_err, &walk_launches);
+  else
+    rc = run_grid_distance(ws, c, *st, m->dm, g, sign_method, plane, d_out, d_err);
   if (rc) return rc;
   if (c.mem_kind == M2S_MEM_HOST) {
     rc = staged_d2h(*st, c.stream, reinterpret_cast<char*>(out + (size_t)xb * ny * nz), reinterpret_cast<const char*>(d_slab), slab_cells * 4);
     if (rc) return rc;
   }
   if (!c.sync) {
-    // Asynchronous call: no host sync now.  Keep the event pair around the dominant launch so that its
-    // duration can be read later (m2s_mesh_drain_timings): ev[4] was recorded just before that launch;
-    // it moves into `pending` and the device state gets a fresh event for the next call.
-    hipEvent_t stop, fresh;
-    for (hipEvent_t* e : {&stop, &fresh}) {
-      if (!m->free_events.empty()) { *e = m->free_events.back(); m->free_events.pop_back(); }
-      else if (!st->timing_events.empty()) { *e = st->timing_events.back(); st->timing_events.pop_back(); }
-      else M2S_HIP_CHECK(hipEventCreate(e));
+    if (plane) m->async_readers = true;
+    // Asynchronous call: no host sync now.  Keep the event pair around the dominant launch(es) so that their
+    // duration can be read later (m2s_mesh_drain_timings): ev[4] was recorded just before the first walk, ev[3]
+    // right after the last; both move into `pending` and the context gets fresh events for the next call.
+    hipEvent_t fresh[2];
+    for (hipEvent_t& e : fresh) {
+      if (!m->free_events.empty()) { e = m->free_events.back(); m->free_events.pop_back(); }
+      else if (!st->timing_events.empty()) { e = st->timing_events.back(); st->timing_events.pop_back(); }
+      else M2S_HIP_CHECK(hipEventCreate(&e));
     }
-    M2S_HIP_CHECK(hipEventRecord(stop, c.stream));
-    m->pending.push_back({st->ev[4], stop, (uint64_t)slab_cells});
-    st->ev[4] = fresh;
+    m->pending.push_back({st->ev[4], st->ev[3], (uint64_t)slab_cells, walk_launches});
+    st->ev[4] = fresh[0];
+    st->ev[3] = fresh[1];
     return M2S_OK;
   }
-  return finish_call(c, *st, d_err, c.timings, m->n_tris, slab_cells, built_planes, true);
+  rc = finish_call(c, *st, d_err, c.timings, m->n_tris, slab_cells, built_planes, true);
+  if (c.timings) c.timings->distance_launches = walk_launches;
+  return rc;
 }
 
 int m2s_mesh_drain_timings(m2s_mesh* m, m2s_timings* t) {
-  std::lock_guard<std::mutex> lk(g_mu);
   if (!m || !t) return fail(M2S_ERR_BAD_ARG, "NULL argument");
+  std::lock_guard<std::mutex> mlk(m->mu);
   memset(t, 0, sizeof(*t));
   t->accel_build_ms = m->build_ms;
   t->n_triangles = m->n_tris;
-  for (auto& p : m->pending) {
-    M2S_HIP_CHECK(hipEventSynchronize(p.b));
-    float ms = 0.0f;
-    (void)hipEventElapsedTime(&ms, p.a, p.b);
-    t->distance_ms += ms;
-    t->n_units += p.units;
-    t->distance_launches += 1;
-    m->free_events.push_back(p.a);
-    m->free_events.push_back(p.b);
-  }
-  m->pending.clear();
+  M2S_HIP_CHECK(hipSetDevice(m->device));
+  reap_pending(m, true);
+  if (!m->pending.empty()) return fail(M2S_ERR_HIP, "an asynchronous call failed on the device: %s", hipGetErrorString(hipGetLastError()));
+  t->distance_ms = (float)m->acc_ms;
+  t->n_units = m->acc_units;
+  t->distance_launches = m->acc_launches;
+  m->acc_ms = 0.0;
+  m->acc_units = 0;
+  m->acc_launches = 0;
+  m->async_readers = false;   // every asynchronous walk has finished
+  // deferred error report of the asynchronous calls since the last drain (the reference panics: lib.rs:257)
+  int e = 0;
+  M2S_HIP_CHECK(hipMemcpy(&e, m->d_err_async, sizeof(int), hipMemcpyDeviceToHost));
+  if (e) M2S_HIP_CHECK(hipMemset(m->d_err_async, 0, sizeof(int)));
+  if (e & ERRF_NAN) return fail(M2S_ERR_NAN, "NaN distance (lib.rs:257) in an asynchronous call since the last drain");
   return M2S_OK;
 }
 
 int m2s_mesh_generate_sdf(m2s_mesh* m, const float* queries, size_t n_queries, int accel, int sign_method, float* out,
                           size_t* n_out, const m2s_opts* opts) {
-  std::lock_guard<std::mutex> lk(g_mu);
   g_err[0] = 0;
   if (n_out) *n_out = 0;
   if (!m) return fail(M2S_ERR_BAD_ARG, "mesh is NULL");
+  std::lock_guard<std::mutex> mlk(m->mu);
   if (accel < M2S_ACCEL_NONE || accel > M2S_ACCEL_RTREE_BVH) return fail(M2S_ERR_BAD_ARG, "bad accel %d", accel);
   if (sign_method != M2S_SIGN_RAYCAST && sign_method != M2S_SIGN_NORMAL) return fail(M2S_ERR_BAD_ARG, "bad sign_method %d", sign_method);
   if (n_queries && !queries) return fail(M2S_ERR_BAD_ARG, "queries is NULL");
@@ -1017,7 +1149,8 @@ int m2s_mesh_generate_sdf(m2s_mesh* m, const float* queries, size_t n_queries, i
   if (n_queries == 0) return M2S_OK;
   if (!out) return fail(M2S_ERR_BAD_ARG, "out is NULL");
   m2s_opts o{};
-  if (opts) o = *opts;
+  if (opts) memcpy(&o, opts, (opts->struct_size >= sizeof(m2s_opts)) ? sizeof(m2s_opts) : (size_t)M2S_OPTS_V1_SIZE);
+  else o.device = -1;
   if (o.device < 0) o.device = m->device;
   if (o.device != m->device) return fail(M2S_ERR_BAD_ARG, "mesh lives on device %d, call asked for %d", m->device, o.device);
   if (!opts) o.synchronous = 1;

@@ -11,6 +11,7 @@
 namespace m2s {
 
 struct DeviceState {
+  std::mutex mu;   // held by an entry point for the whole call (CallCtx::lock); one context per (device, lane)
   // Scratch of the call in progress.  It belongs to the STREAM the call is enqueued on (resolve_ctx selects it):
   // calls on one stream are ordered by the stream and share one block, calls on different streams get different
   // blocks, so asynchronous calls on two streams (the x-pieces of a sharded grid) may overlap on the device.
@@ -49,6 +50,7 @@ struct DeviceState {
   char* ring[RING] = {nullptr, nullptr, nullptr};
   size_t ring_bytes = 0;
   hipStream_t copy_stream = nullptr;
+  std::vector<hipEvent_t> piece_events;   // M2S_PEER_PUSH: piece i walked / last push done (no timing)
 };
 
 struct CallCtx {
@@ -59,9 +61,14 @@ struct CallCtx {
   hipStream_t stream = nullptr;
   m2s_timings* timings = nullptr;
   uint64_t x_begin = 0, x_end = 0;
+  int lane = 0;
+  PeerOut peers{};                       // m2s_opts.peer_out (grid path, device memory)
+  int peer_mode = 0;
+  std::unique_lock<std::mutex> lock;     // the context's lock, taken by resolve_ctx, released when the CallCtx dies
 };
 
-extern std::mutex g_mu;                  // serialises the entry points (one workspace per device)
+extern std::mutex g_mu;                  // guards the table of contexts only; every context has its own lock
+DeviceState* find_state(int device, int lane);   // creates the context if needed; does NOT lock it
 void clear_error();
 int fail(int code, const char* fmt, ...);
 int resolve_ctx(const m2s_opts* opts, CallCtx* c, DeviceState** st);

@@ -166,6 +166,9 @@ int probe_impl(const uint8_t* bytes, size_t n, int bytes_kind, hipStream_t st, m
 // Scalar reader for containers whose numbers are not all `ca`-encoded.
 int decode_on_host(const uint8_t* hb, size_t n, const m2s_sdf_info& info, std::vector<float>* q, std::vector<float>* d) {
   wire::Reader r(hb, n);
+  // counts come from the untrusted envelope: an element takes at least 1 byte (a point at least 4), so anything
+  // larger than the container is malformed — checked BEFORE sizing the output (rmp-serde caps preallocation likewise)
+  if (info.n_distances > n || (info.kind == M2S_SDF_GENERIC && info.n_queries > n / 4)) return fail(M2S_ERR_BAD_ARG, "%s", kBadContainer);
   if (info.kind == M2S_SDF_GENERIC) {
     r.pos = info.queries_offset;
     q->resize(info.n_queries * 3);
@@ -321,7 +324,6 @@ size_t m2s_sdf_generic_encoded_size(size_t n_queries, size_t n_distances) {
 
 int m2s_sdf_encode_grid(const m2s_grid* grid, const float* distances, size_t n_distances, uint8_t* bytes,
                         size_t capacity, size_t* written, const m2s_opts* opts) {
-  std::lock_guard<std::mutex> lk(g_mu);
   clear_error();
   if (!grid) return fail(M2S_ERR_BAD_ARG, "grid is NULL");
   if (n_distances && !distances) return fail(M2S_ERR_BAD_ARG, "distances is NULL");
@@ -339,7 +341,6 @@ int m2s_sdf_encode_grid(const m2s_grid* grid, const float* distances, size_t n_d
 
 int m2s_sdf_encode_generic(const float* queries, size_t n_queries, const float* distances, size_t n_distances,
                            uint8_t* bytes, size_t capacity, size_t* written, const m2s_opts* opts) {
-  std::lock_guard<std::mutex> lk(g_mu);
   clear_error();
   if (n_queries && !queries) return fail(M2S_ERR_BAD_ARG, "queries is NULL");
   if (n_distances && !distances) return fail(M2S_ERR_BAD_ARG, "distances is NULL");
@@ -356,7 +357,6 @@ int m2s_sdf_encode_generic(const float* queries, size_t n_queries, const float* 
 }
 
 int m2s_sdf_probe(const uint8_t* bytes, size_t n_bytes, m2s_sdf_info* info, const m2s_opts* opts) {
-  std::lock_guard<std::mutex> lk(g_mu);
   clear_error();
   if (!bytes || !info) return fail(M2S_ERR_BAD_ARG, "bytes / info is NULL");
   std::vector<uint8_t> host_copy;
@@ -369,7 +369,6 @@ int m2s_sdf_probe(const uint8_t* bytes, size_t n_bytes, m2s_sdf_info* info, cons
 }
 
 int m2s_sdf_decode(const uint8_t* bytes, size_t n_bytes, float* queries_out, float* distances_out, const m2s_opts* opts) {
-  std::lock_guard<std::mutex> lk(g_mu);
   clear_error();
   if (!bytes) return fail(M2S_ERR_BAD_ARG, "bytes is NULL");
   CallCtx c;
@@ -381,7 +380,6 @@ int m2s_sdf_decode(const uint8_t* bytes, size_t n_bytes, float* queries_out, flo
 
 int m2s_sdf_save_grid(const char* path, const m2s_grid* grid, const float* distances, size_t n_distances,
                       const m2s_opts* opts) {
-  std::lock_guard<std::mutex> lk(g_mu);
   clear_error();
   if (!path || !grid) return fail(M2S_ERR_BAD_ARG, "path / grid is NULL");
   if (n_distances && !distances) return fail(M2S_ERR_BAD_ARG, "distances is NULL");
@@ -392,7 +390,6 @@ int m2s_sdf_save_grid(const char* path, const m2s_grid* grid, const float* dista
 
 int m2s_sdf_save_generic(const char* path, const float* queries, size_t n_queries, const float* distances,
                          size_t n_distances, const m2s_opts* opts) {
-  std::lock_guard<std::mutex> lk(g_mu);
   clear_error();
   if (!path) return fail(M2S_ERR_BAD_ARG, "path is NULL");
   if ((n_queries && !queries) || (n_distances && !distances)) return fail(M2S_ERR_BAD_ARG, "queries / distances is NULL");
@@ -402,7 +399,6 @@ int m2s_sdf_save_generic(const char* path, const float* queries, size_t n_querie
 }
 
 int m2s_sdf_probe_file(const char* path, m2s_sdf_info* info) {
-  std::lock_guard<std::mutex> lk(g_mu);
   clear_error();
   if (!path || !info) return fail(M2S_ERR_BAD_ARG, "path / info is NULL");
   MappedFile file;
@@ -414,7 +410,6 @@ int m2s_sdf_probe_file(const char* path, m2s_sdf_info* info) {
 }
 
 int m2s_sdf_read_file(const char* path, float* queries_out, float* distances_out, const m2s_opts* opts) {
-  std::lock_guard<std::mutex> lk(g_mu);
   clear_error();
   if (!path) return fail(M2S_ERR_BAD_ARG, "path is NULL");
   MappedFile file;
@@ -430,7 +425,6 @@ int m2s_sdf_read_file(const char* path, float* queries_out, float* distances_out
 
 int m2s_order_cells_by_distance(const float* distances, size_t n, uint32_t* ordered_indices, float* iso_limits,
                                 const m2s_opts* opts) {
-  std::lock_guard<std::mutex> lk(g_mu);
   clear_error();
   if (n && (!distances || !ordered_indices)) return fail(M2S_ERR_BAD_ARG, "distances / ordered_indices is NULL");
   if (n >= (1ull << 32)) return fail(M2S_ERR_BAD_ARG, "%zu cells do not fit the u32 indices of the reference (sdf.rs:67)", n);
@@ -465,7 +459,6 @@ int m2s_order_cells_by_distance(const float* distances, size_t n, uint32_t* orde
 
 int m2s_merge_instances(const m2s_instance* instances, size_t n_instances, float* vertices_out, uint32_t* indices_out,
                         float* bbox, const m2s_opts* opts) {
-  std::lock_guard<std::mutex> lk(g_mu);
   clear_error();
   if (n_instances && !instances) return fail(M2S_ERR_BAD_ARG, "instances is NULL");
   if (n_instances >= (1ull << 31)) return fail(M2S_ERR_BAD_ARG, "too many instances");

@@ -145,6 +145,13 @@ inline void choose_brick_shape(const float size[3], uint32_t bl[3]) {
     }
 }
 
+// Additional whole-grid output buffers (m2s_opts.peer_out): same layout and indexing as `out`, usually on other devices.
+constexpr uint32_t MAX_PEERS = 15;
+struct PeerOut {
+  float* p[MAX_PEERS];
+  uint32_t n;
+};
+
 // Device-side error flags (OR-ed into one int by kernels).
 enum : int { ERRF_INDEX_OOB = 1, ERRF_NAN = 2 };
 
@@ -224,13 +231,19 @@ int launch_grid_seeds(Arena& ws, hipStream_t st, const float4* cen, uint32_t n_t
 int prepare_grid_walk(Arena& ws, hipStream_t st, const DeviceMesh& mesh, const GridParams& g, int algorithm, bool pipelined,
                       GridWalkPlan* plan, const SeedLattice* raw_seeds = nullptr);
 // `g` may be an x-piece of the slab the plan was prepared for, starting bx_off bricks into it (a multiple of 2 bricks).
+// `peers` (optional): buffers that receive the same values in the walk's epilogue (M2S_PEER_STORE).
 int launch_grid_walk(hipStream_t st, const DeviceMesh& mesh, const GridParams& g, int mode, const uint32_t* d_inside_plane,
-                     int algorithm, const GridWalkPlan& plan, uint32_t bx_off, float* d_out, int* d_err);
+                     int algorithm, const GridWalkPlan& plan, uint32_t bx_off, float* d_out, int* d_err,
+                     const PeerOut* peers = nullptr);
+// M2S_PEER_PUSH: copies the cells [first, first + count) of the whole-grid buffer `src` to the same range of every peer
+// (16 B per lane where the range allows).
+int launch_push_cells(hipStream_t st, const float* src, const PeerOut& peers, uint64_t first, uint64_t count);
 // Records `ev_before_final` (if non-null) between the seed passes and the final k_packet launch.
 int launch_grid_distance(Arena& ws, hipStream_t st, const DeviceMesh& mesh, const GridParams& g, int mode,
                          const uint32_t* d_inside_plane, int algorithm, float* d_out, int* d_err,
                          hipEvent_t ev_before_final, hipEvent_t wait_before_final = nullptr, bool pipelined = false,
-                         const SeedLattice* raw_seeds = nullptr, hipEvent_t wait_raw_seeds = nullptr);
+                         const SeedLattice* raw_seeds = nullptr, hipEvent_t wait_raw_seeds = nullptr,
+                         const PeerOut* peers = nullptr);
 size_t query_workspace_bytes(size_t n_q);
 int launch_query_distance(Arena& ws, hipStream_t st, const DeviceMesh& mesh, const float* d_queries, size_t n_q,
                           int mode, int sign_src, int algorithm, float* d_out, int* d_err);

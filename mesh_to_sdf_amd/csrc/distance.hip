@@ -301,7 +301,7 @@ __global__ __launch_bounds__(256) void k_packet(DeviceMesh mesh, GridParams g, c
                                                 int* __restrict__ err, uint32_t n_packets, uint32_t chunk,
                                                 const uint32_t* __restrict__ seed_in, uint32_t seed_shift,
                                                 uint32_t seed_ny, uint32_t seed_nz,
-                                                const GridParams* __restrict__ seed_lattice, CutList cut) {
+                                                const GridParams* __restrict__ seed_lattice, CutList cut, PeerOut peers) {
   const int lane = threadIdx.x & 63;
   const uint32_t block = xcd_remap(blockIdx.x, chunk);
   const uint32_t packet = block * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -436,11 +436,35 @@ __global__ __launch_bounds__(256) void k_packet(DeviceMesh mesh, GridParams g, c
     }
   }
   if (MODE == MODE_NORMAL_FOLD && best.nan) atomicOr(err, ERRF_NAN);
-  if (store) out[out_index] = finish<MODE>(best, negate);
+  const float result = finish<MODE>(best, negate);
+  if (store) out[out_index] = result;
+  // M2S_PEER_STORE: the same value into every peer's whole-grid buffer (grid path; indices are whole-grid there)
+  if (GRID && peers.n != 0u && store) {
+    const size_t gi = out_index + (size_t)g.out_off;
+    for (uint32_t i = 0; i < peers.n; ++i) peers.p[i][gi] = result;
+  }
 }
 
-
-
+// M2S_PEER_PUSH: one slab piece of the finished whole-grid buffer to every peer, 16 B per lane.
+__global__ __launch_bounds__(256) void k_push_cells(const float* __restrict__ src, PeerOut peers, uint64_t first, uint64_t count) {
+  // head: up to the next 16-byte boundary; body: float4; tail: the rest
+  const uint64_t head = min(count, (uint64_t)((4u - (uint32_t)(first & 3u)) & 3u));
+  const uint64_t n4 = (count - head) >> 2, tail0 = head + (n4 << 2);
+  const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (uint64_t)gridDim.x * blockDim.x;
+  const float4* s4 = reinterpret_cast<const float4*>(src + first + head);
+  for (uint64_t i = tid; i < n4; i += stride) {
+    const float4 v = s4[i];
+    for (uint32_t k = 0; k < peers.n; ++k) reinterpret_cast<float4*>(peers.p[k] + first + head)[i] = v;
+  }
+  if (tid < head) {
+    const float v = src[first + tid];
+    for (uint32_t k = 0; k < peers.n; ++k) peers.p[k][first + tid] = v;
+  }
+  if (tid < count - tail0) {
+    const float v = src[first + tail0 + tid];
+    for (uint32_t k = 0; k < peers.n; ++k) peers.p[k][first + tail0 + tid] = v;
+  }
+}
 
 // ---- k_lane ---------------------------------------------------------------------------------
 // One VOXEL per lane, every lane walking the tree on its own (per-lane offsets, records by vector gathers).
@@ -452,7 +476,8 @@ __global__ __launch_bounds__(256) void k_packet(DeviceMesh mesh, GridParams g, c
 template <int MODE, int SIGN>
 __global__ __launch_bounds__(256) void k_lane(DeviceMesh mesh, GridParams g, const uint32_t* __restrict__ plane,
                                               float* __restrict__ out, int* __restrict__ err, uint32_t n_packets,
-                                              const uint32_t* __restrict__ seed_in, uint32_t seed_ny, uint32_t seed_nz, uint32_t bx_off) {
+                                              const uint32_t* __restrict__ seed_in, uint32_t seed_ny, uint32_t seed_nz, uint32_t bx_off,
+                                              PeerOut peers) {
   const int lane = threadIdx.x & 63;
   const uint32_t packet = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (packet >= n_packets) return;
@@ -496,7 +521,11 @@ __global__ __launch_bounds__(256) void k_lane(DeviceMesh mesh, GridParams g, con
     negate = (plane[w] >> (vox.z & 31u)) & 1u;                         // grid.rs:630-636
   }
   if (MODE == MODE_NORMAL_FOLD && best.nan) atomicOr(err, ERRF_NAN);
-  if (vox.in_range) out[out_index] = finish<MODE>(best, negate);
+  const float result = finish<MODE>(best, negate);
+  if (vox.in_range) {
+    out[out_index] = result;
+    for (uint32_t i = 0; i < peers.n; ++i) peers.p[i][out_index + (size_t)g.out_off] = result;
+  }
 }
 
 // ---- jump-flooding seed pass ------------------------------------------------------------------
@@ -657,7 +686,7 @@ __global__ __launch_bounds__(256) void k_cut(DeviceMesh mesh, GridParams g, cons
 template <bool GRID, int MODE, int SIGN>
 __global__ __launch_bounds__(256) void k_brute(DeviceMesh mesh, GridParams g, const float* __restrict__ queries,
                                                uint32_t n_q, const uint32_t* __restrict__ plane,
-                                               float* __restrict__ out, int* __restrict__ err, uint32_t n_packets) {
+                                               float* __restrict__ out, int* __restrict__ err, uint32_t n_packets, PeerOut peers) {
   __shared__ TriRec tile[TILE];
   const int lane = threadIdx.x & 63;
   const uint32_t packet = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -723,7 +752,10 @@ __global__ __launch_bounds__(256) void k_brute(DeviceMesh mesh, GridParams g, co
     }
   }
   if (MODE == MODE_NORMAL_FOLD && best.nan && store) atomicOr(err, ERRF_NAN);
-  if (store) out[out_index] = finish<MODE>(best, negate);
+  const float result = finish<MODE>(best, negate);
+  if (store) out[out_index] = result;
+  if (GRID && store)
+    for (uint32_t i = 0; i < peers.n; ++i) peers.p[i][out_index + (size_t)g.out_off] = result;
 }
 
 // ---- query ordering (generic path): Morton sort so that a packet is spatially compact ---------
@@ -819,7 +851,10 @@ template <bool GRID, int MODE, int SIGN>
 void launch_packet(hipStream_t st, const DeviceMesh& mesh, const GridParams& g, const float4* qs, const uint32_t* perm,
                    uint32_t n_q, const uint32_t* plane, float* out, int* err, uint32_t n_packets,
                    const uint32_t* seed_in = nullptr, uint32_t seed_shift = 0, uint32_t seed_ny = 0,
-                   uint32_t seed_nz = 0, const GridParams* seed_lattice = nullptr, CutList cut = {nullptr, 0, 0, 0, 0}) {
+                   uint32_t seed_nz = 0, const GridParams* seed_lattice = nullptr, CutList cut = {nullptr, 0, 0, 0, 0},
+                   const PeerOut* peers_in = nullptr) {
+  PeerOut peers{};
+  if (peers_in) peers = *peers_in;
   static const uint32_t wpb = getenv("M2S_WPB") ? std::min(4u, std::max(1u, (uint32_t)atoi(getenv("M2S_WPB")))) : 1u;   // waves (packets) per workgroup: single-wave groups free their slot as soon as the walk ends (4 -> 1: -3.8 %)
   const uint32_t blocks = (n_packets + wpb - 1) / wpb;
   // 2 (default): XCD x takes runs x, x+8, ... of 2^run_log packets; 1: one contiguous eighth per XCD; 0: plain order
@@ -834,24 +869,26 @@ void launch_packet(hipStream_t st, const DeviceMesh& mesh, const GridParams& g, 
     const uint32_t code = 0x80000000u | run_log;
     if (mesh.stats != nullptr)
       hipLaunchKernelGGL((k_packet<GRID, MODE, SIGN, true>), dim3(grid_blocks), dim3(64 * wpb), 0, st, mesh, g,
-                         qs, perm, n_q, plane, out, err, n_packets, code, seed_in, seed_shift, seed_ny, seed_nz, seed_lattice, cut);
+                         qs, perm, n_q, plane, out, err, n_packets, code, seed_in, seed_shift, seed_ny, seed_nz, seed_lattice, cut, peers);
     else
       hipLaunchKernelGGL((k_packet<GRID, MODE, SIGN, false>), dim3(grid_blocks), dim3(64 * wpb), 0, st, mesh, g,
-                         qs, perm, n_q, plane, out, err, n_packets, code, seed_in, seed_shift, seed_ny, seed_nz, seed_lattice, cut);
+                         qs, perm, n_q, plane, out, err, n_packets, code, seed_in, seed_shift, seed_ny, seed_nz, seed_lattice, cut, peers);
     return;
   }
   if (mesh.stats != nullptr)   // M2S_STATS: the counting variant (a few SALU ops more per node)
     hipLaunchKernelGGL((k_packet<GRID, MODE, SIGN, true>), dim3(remap ? chunk * 8 : blocks), dim3(64 * wpb), 0, st, mesh, g,
-                       qs, perm, n_q, plane, out, err, n_packets, chunk, seed_in, seed_shift, seed_ny, seed_nz, seed_lattice, cut);
+                       qs, perm, n_q, plane, out, err, n_packets, chunk, seed_in, seed_shift, seed_ny, seed_nz, seed_lattice, cut, peers);
   else
     hipLaunchKernelGGL((k_packet<GRID, MODE, SIGN, false>), dim3(remap ? chunk * 8 : blocks), dim3(64 * wpb), 0, st, mesh, g,
-                       qs, perm, n_q, plane, out, err, n_packets, chunk, seed_in, seed_shift, seed_ny, seed_nz, seed_lattice, cut);
+                       qs, perm, n_q, plane, out, err, n_packets, chunk, seed_in, seed_shift, seed_ny, seed_nz, seed_lattice, cut, peers);
 }
 template <bool GRID, int MODE, int SIGN>
 void launch_brute(hipStream_t st, const DeviceMesh& mesh, const GridParams& g, const float* q, uint32_t n_q,
-                  const uint32_t* plane, float* out, int* err, uint32_t n_packets) {
+                  const uint32_t* plane, float* out, int* err, uint32_t n_packets, const PeerOut* peers_in = nullptr) {
+  PeerOut peers{};
+  if (peers_in) peers = *peers_in;
   hipLaunchKernelGGL((k_brute<GRID, MODE, SIGN>), dim3((n_packets + 3) / 4), dim3(256), 0, st, mesh, g, q, n_q, plane,
-                     out, err, n_packets);
+                     out, err, n_packets, peers);
 }
 
 uint32_t host_brick_count(const GridParams& g) {   // padded to whole super-bricks
@@ -991,9 +1028,23 @@ int prepare_grid_walk(Arena& ws, hipStream_t st, const DeviceMesh& mesh, const G
   return 0;
 }
 
+int launch_push_cells(hipStream_t st, const float* src, const PeerOut& peers, uint64_t first, uint64_t count) {
+  if (peers.n == 0 || count == 0) return 0;
+  // a bandwidth-bound copy next to the walk of the following piece: enough workgroups to keep every xGMI link busy,
+  // few enough to leave the CUs to the walk (M2S_PUSH_BLOCKS)
+  static const unsigned max_blocks = getenv("M2S_PUSH_BLOCKS") ? (unsigned)std::max(1, atoi(getenv("M2S_PUSH_BLOCKS"))) : 256u;
+  const uint64_t want = (count / 4 + 255) / 256 + 1;
+  const unsigned blocks = (unsigned)std::min<uint64_t>(max_blocks, want);
+  hipLaunchKernelGGL(k_push_cells, dim3(blocks), dim3(256), 0, st, src, peers, first, count);
+  M2S_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
 int launch_grid_walk(hipStream_t st, const DeviceMesh& mesh, const GridParams& g, int mode, const uint32_t* d_inside_plane,
-                     int algorithm, const GridWalkPlan& plan, uint32_t bx_off, float* d_out, int* d_err) {
+                     int algorithm, const GridWalkPlan& plan, uint32_t bx_off, float* d_out, int* d_err, const PeerOut* peers) {
   if (g.xe <= g.xb || g.n[1] == 0 || g.n[2] == 0) return 0;
+  PeerOut pz{};
+  if (peers) pz = *peers;
   const uint32_t packets = host_brick_count(g);
   const bool brute = algorithm == 1;
   const uint32_t* seed1 = plan.seeds;
@@ -1002,23 +1053,23 @@ int launch_grid_walk(hipStream_t st, const DeviceMesh& mesh, const GridParams& g
   if (plan.lane_walk) {
     const unsigned blocks = (packets + 3) / 4;
     if (mode == MODE_UNSIGNED && d_inside_plane)
-      hipLaunchKernelGGL((k_lane<MODE_UNSIGNED, SIGN_GRID_PLANE>), dim3(blocks), dim3(256), 0, st, mesh, g, d_inside_plane, d_out, d_err, packets, seed1, s1ny, s1nz, bx_off);
+      hipLaunchKernelGGL((k_lane<MODE_UNSIGNED, SIGN_GRID_PLANE>), dim3(blocks), dim3(256), 0, st, mesh, g, d_inside_plane, d_out, d_err, packets, seed1, s1ny, s1nz, bx_off, pz);
     else if (mode == MODE_UNSIGNED)
-      hipLaunchKernelGGL((k_lane<MODE_UNSIGNED, SIGN_NONE>), dim3(blocks), dim3(256), 0, st, mesh, g, nullptr, d_out, d_err, packets, seed1, s1ny, s1nz, bx_off);
+      hipLaunchKernelGGL((k_lane<MODE_UNSIGNED, SIGN_NONE>), dim3(blocks), dim3(256), 0, st, mesh, g, nullptr, d_out, d_err, packets, seed1, s1ny, s1nz, bx_off, pz);
     else
-      hipLaunchKernelGGL((k_lane<MODE_NORMAL_FOLD, SIGN_NONE>), dim3(blocks), dim3(256), 0, st, mesh, g, nullptr, d_out, d_err, packets, seed1, s1ny, s1nz, bx_off);
+      hipLaunchKernelGGL((k_lane<MODE_NORMAL_FOLD, SIGN_NONE>), dim3(blocks), dim3(256), 0, st, mesh, g, nullptr, d_out, d_err, packets, seed1, s1ny, s1nz, bx_off, pz);
     M2S_HIP_CHECK(hipGetLastError());
     return 0;
   }
   if (mode == MODE_UNSIGNED && d_inside_plane) {
-    if (brute) launch_brute<true, MODE_UNSIGNED, SIGN_GRID_PLANE>(st, mesh, g, nullptr, 0, d_inside_plane, d_out, d_err, packets);
-    else launch_packet<true, MODE_UNSIGNED, SIGN_GRID_PLANE>(st, mesh, g, nullptr, nullptr, 0, d_inside_plane, d_out, d_err, packets, seed1, sh1, s1ny, s1nz, nullptr, cut);
+    if (brute) launch_brute<true, MODE_UNSIGNED, SIGN_GRID_PLANE>(st, mesh, g, nullptr, 0, d_inside_plane, d_out, d_err, packets, peers);
+    else launch_packet<true, MODE_UNSIGNED, SIGN_GRID_PLANE>(st, mesh, g, nullptr, nullptr, 0, d_inside_plane, d_out, d_err, packets, seed1, sh1, s1ny, s1nz, nullptr, cut, peers);
   } else if (mode == MODE_UNSIGNED) {
-    if (brute) launch_brute<true, MODE_UNSIGNED, SIGN_NONE>(st, mesh, g, nullptr, 0, nullptr, d_out, d_err, packets);
-    else launch_packet<true, MODE_UNSIGNED, SIGN_NONE>(st, mesh, g, nullptr, nullptr, 0, nullptr, d_out, d_err, packets, seed1, sh1, s1ny, s1nz, nullptr, cut);
+    if (brute) launch_brute<true, MODE_UNSIGNED, SIGN_NONE>(st, mesh, g, nullptr, 0, nullptr, d_out, d_err, packets, peers);
+    else launch_packet<true, MODE_UNSIGNED, SIGN_NONE>(st, mesh, g, nullptr, nullptr, 0, nullptr, d_out, d_err, packets, seed1, sh1, s1ny, s1nz, nullptr, cut, peers);
   } else {
-    if (brute) launch_brute<true, MODE_NORMAL_FOLD, SIGN_NONE>(st, mesh, g, nullptr, 0, nullptr, d_out, d_err, packets);
-    else launch_packet<true, MODE_NORMAL_FOLD, SIGN_NONE>(st, mesh, g, nullptr, nullptr, 0, nullptr, d_out, d_err, packets, seed1, sh1, s1ny, s1nz, nullptr, cut);
+    if (brute) launch_brute<true, MODE_NORMAL_FOLD, SIGN_NONE>(st, mesh, g, nullptr, 0, nullptr, d_out, d_err, packets, peers);
+    else launch_packet<true, MODE_NORMAL_FOLD, SIGN_NONE>(st, mesh, g, nullptr, nullptr, 0, nullptr, d_out, d_err, packets, seed1, sh1, s1ny, s1nz, nullptr, cut, peers);
   }
   M2S_HIP_CHECK(hipGetLastError());
   return 0;
@@ -1027,7 +1078,7 @@ int launch_grid_walk(hipStream_t st, const DeviceMesh& mesh, const GridParams& g
 int launch_grid_distance(Arena& ws, hipStream_t st, const DeviceMesh& mesh, const GridParams& g, int mode,
                          const uint32_t* d_inside_plane, int algorithm, float* d_out, int* d_err,
                          hipEvent_t ev_before_final, hipEvent_t wait_before_final, bool pipelined,
-                         const SeedLattice* raw_seeds, hipEvent_t wait_raw_seeds) {
+                         const SeedLattice* raw_seeds, hipEvent_t wait_raw_seeds, const PeerOut* peers) {
   GridWalkPlan plan;
   if (raw_seeds && wait_raw_seeds) M2S_HIP_CHECK(hipStreamWaitEvent(st, wait_raw_seeds, 0));   // computed on another stream
   int rc = prepare_grid_walk(ws, st, mesh, g, algorithm, pipelined, &plan, raw_seeds);
@@ -1035,7 +1086,7 @@ int launch_grid_distance(Arena& ws, hipStream_t st, const DeviceMesh& mesh, cons
   // the sign planes may have been built beside the seed passes, on another stream (capi.hip): the walk needs them
   if (wait_before_final) M2S_HIP_CHECK(hipStreamWaitEvent(st, wait_before_final, 0));
   if (ev_before_final) M2S_HIP_CHECK(hipEventRecord(ev_before_final, st));
-  return launch_grid_walk(st, mesh, g, mode, d_inside_plane, algorithm, plan, 0, d_out, d_err);
+  return launch_grid_walk(st, mesh, g, mode, d_inside_plane, algorithm, plan, 0, d_out, d_err, peers);
 }
 
 size_t query_workspace_bytes(size_t n_q) {

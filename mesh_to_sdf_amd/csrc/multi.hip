@@ -1,0 +1,333 @@
+// multi.hip — generate_grid_sdf over several GPUs of one node from one process (include/m2s.h:
+// m2s_generate_grid_sdf_multi), and the cross-process helpers (m2s_shared_alloc, m2s_ipc_*).
+//
+// every voxel depends only on the replicated mesh, so the grid shards into contiguous x-slabs with
+// no data-path exchange; what remains is delivering the slabs.  Host results: every device streams its slab into the
+// caller's array over its own PCIe link.  Device-resident results: every device writes its slab into all peers'
+// buffers over xGMI itself (m2s_opts.peer_out; the links are point-to-point, so seven peers are seven links in
+// parallel), or — where peer access is not available — one in-place ncclAllGather from librccl.
+//
+// One host thread per shard: each calls the ordinary single-device entry point with its (device, lane) context,
+// x-slab and peer list, so the multi-device path adds no second implementation of anything.
+#include <dlfcn.h>
+
+#include <atomic>
+#include <chrono>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include <rccl/rccl.h>   // types and prototypes only: the library itself is loaded on first use (dlopen)
+
+#include "../../include/m2s.h"
+#include "capi_internal.h"
+#include "common.h"
+
+namespace m2s {
+namespace {
+
+// ---- librccl, loaded on demand -------------------------------------------------------------------
+// The product must load (and serve single-GPU callers) on machines without RCCL, and linking it would pull a
+// several-hundred-MB library into every process that only wants one GPU.
+struct Rccl {
+  void* handle = nullptr;
+  decltype(&ncclCommInitAll) CommInitAll = nullptr;
+  decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclAllGather) AllGather = nullptr;
+  decltype(&ncclBroadcast) Broadcast = nullptr;
+  decltype(&ncclGroupStart) GroupStart = nullptr;
+  decltype(&ncclGroupEnd) GroupEnd = nullptr;
+  decltype(&ncclGetErrorString) GetErrorString = nullptr;
+  std::string why;
+  bool ok = false;
+};
+
+Rccl& rccl() {
+  static Rccl r;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+      r.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+      if (r.handle) break;
+    }
+    if (!r.handle) { r.why = std::string("dlopen(librccl.so.1) failed: ") + (dlerror() ? dlerror() : "?"); return; }
+    auto sym = [&](const char* n) { void* p = dlsym(r.handle, n); if (!p) r.why = std::string("librccl lacks ") + n; return p; };
+    r.CommInitAll = (decltype(r.CommInitAll))sym("ncclCommInitAll");
+    r.CommDestroy = (decltype(r.CommDestroy))sym("ncclCommDestroy");
+    r.AllGather = (decltype(r.AllGather))sym("ncclAllGather");
+    r.Broadcast = (decltype(r.Broadcast))sym("ncclBroadcast");
+    r.GroupStart = (decltype(r.GroupStart))sym("ncclGroupStart");
+    r.GroupEnd = (decltype(r.GroupEnd))sym("ncclGroupEnd");
+    r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
+    r.ok = r.CommInitAll && r.CommDestroy && r.AllGather && r.Broadcast && r.GroupStart && r.GroupEnd && r.GetErrorString;
+  });
+  return r;
+}
+
+// Communicators of the last device list (ncclCommInitAll costs tens of ms; a caller repeats the same list).
+struct CommCache {
+  std::mutex mu;
+  std::vector<int> devices;
+  std::vector<ncclComm_t> comms;
+  std::vector<hipStream_t> streams;
+};
+CommCache g_comms;
+
+int ensure_comms(const std::vector<int>& devices) {
+  Rccl& r = rccl();
+  if (!r.ok) return fail(M2S_ERR_HIP, "RCCL exchange unavailable: %s", r.why.c_str());
+  if (g_comms.devices == devices) return 0;
+  for (size_t k = 0; k < g_comms.comms.size(); ++k) {
+    (void)hipSetDevice(g_comms.devices[k]);
+    (void)r.CommDestroy(g_comms.comms[k]);
+    (void)hipStreamDestroy(g_comms.streams[k]);
+  }
+  g_comms.comms.assign(devices.size(), nullptr);
+  g_comms.streams.assign(devices.size(), nullptr);
+  g_comms.devices.clear();
+  const ncclResult_t e = r.CommInitAll(g_comms.comms.data(), (int)devices.size(), devices.data());
+  if (e != ncclSuccess) {
+    g_comms.comms.clear();
+    g_comms.streams.clear();
+    return fail(M2S_ERR_HIP, "ncclCommInitAll over %zu devices failed: %s", devices.size(), r.GetErrorString(e));
+  }
+  for (size_t k = 0; k < devices.size(); ++k) {
+    M2S_HIP_CHECK(hipSetDevice(devices[k]));
+    M2S_HIP_CHECK(hipStreamCreateWithFlags(&g_comms.streams[k], hipStreamNonBlocking));
+  }
+  g_comms.devices = devices;
+  return 0;
+}
+
+// In-place gather of the x-slabs: buffer k holds slab k on entry, every buffer the whole grid on return.
+int rccl_gather(const std::vector<int>& devices, float* const* outs, const std::vector<uint64_t>& xb,
+                const std::vector<uint64_t>& xe, uint64_t row) {
+  std::lock_guard<std::mutex> lk(g_comms.mu);
+  int rc = ensure_comms(devices);
+  if (rc) return rc;
+  Rccl& r = rccl();
+  const size_t n = devices.size();
+  bool even = true;
+  for (size_t k = 0; k < n; ++k) even &= (xe[k] - xb[k]) == (xe[0] - xb[0]);
+  ncclResult_t e = r.GroupStart();
+  if (even) {
+    for (size_t k = 0; k < n && e == ncclSuccess; ++k)   // sendbuff = recvbuff + rank * count: in place
+      e = r.AllGather(outs[k] + xb[k] * row, outs[k], (size_t)((xe[k] - xb[k]) * row), ncclFloat, g_comms.comms[k], g_comms.streams[k]);
+  } else {
+    for (size_t root = 0; root < n && e == ncclSuccess; ++root)   // uneven slabs: one broadcast per slab
+      for (size_t k = 0; k < n && e == ncclSuccess; ++k)
+        if (xe[root] > xb[root])
+          e = r.Broadcast(outs[k] + xb[root] * row, outs[k] + xb[root] * row, (size_t)((xe[root] - xb[root]) * row), ncclFloat, (int)root,
+                          g_comms.comms[k], g_comms.streams[k]);
+  }
+  const ncclResult_t e2 = r.GroupEnd();
+  if (e == ncclSuccess) e = e2;
+  if (e != ncclSuccess) return fail(M2S_ERR_HIP, "RCCL all-gather failed: %s", r.GetErrorString(e));
+  for (size_t k = 0; k < n; ++k) {
+    M2S_HIP_CHECK(hipSetDevice(devices[k]));
+    M2S_HIP_CHECK(hipStreamSynchronize(g_comms.streams[k]));
+  }
+  return 0;
+}
+
+// Peer access between every pair of distinct devices of the list; false if some pair cannot.
+bool enable_peer_access(const std::vector<int>& devices) {
+  static std::mutex mu;
+  static std::vector<std::pair<int, int>> enabled;
+  std::lock_guard<std::mutex> lk(mu);
+  for (int a : devices)
+    for (int b : devices) {
+      if (a == b) continue;
+      bool have = false;
+      for (auto& p : enabled) have |= p.first == a && p.second == b;
+      if (have) continue;
+      int can = 0;
+      if (hipDeviceCanAccessPeer(&can, a, b) != hipSuccess || !can) { (void)hipGetLastError(); return false; }
+      if (hipSetDevice(a) != hipSuccess) return false;
+      const hipError_t e = hipDeviceEnablePeerAccess(b, 0);
+      if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) { (void)hipGetLastError(); return false; }
+      (void)hipGetLastError();
+      enabled.emplace_back(a, b);
+    }
+  return true;
+}
+
+}  // namespace
+}  // namespace m2s
+
+using namespace m2s;
+
+extern "C" {
+
+void m2s_slab_bounds(uint64_t nx, int n, int k, uint64_t* x_begin, uint64_t* x_end) {
+  if (n <= 0) { *x_begin = 0; *x_end = nx; return; }
+  const uint64_t base = nx / (uint64_t)n, rem = nx % (uint64_t)n, kk = (uint64_t)k;
+  const uint64_t x0 = kk * base + (kk < rem ? kk : rem);
+  *x_begin = x0;
+  *x_end = x0 + base + (kk < rem ? 1 : 0);
+}
+
+int m2s_generate_grid_sdf_multi(const float* vertices, size_t n_vertices, const void* indices, size_t n_indices,
+                                int index_bytes, int topology, const m2s_grid* grid, int sign_method, float* const* outs,
+                                const m2s_multi_opts* opts) {
+  clear_error();
+  const auto t0 = std::chrono::steady_clock::now();
+  if (!grid) return fail(M2S_ERR_BAD_ARG, "grid is NULL");
+  if (!outs) return fail(M2S_ERR_BAD_ARG, "outs is NULL");
+  if (opts && opts->struct_size != 0 && opts->struct_size < sizeof(m2s_multi_opts)) return fail(M2S_ERR_BAD_ARG, "m2s_multi_opts.struct_size too small");
+  const int visible = m2s_device_count();
+  if (visible <= 0) return fail(M2S_ERR_HIP, "no HIP device available: the MI355X kernels cannot run (there is no CPU fallback)");
+  int n = opts ? opts->n_devices : 0;
+  if (n == 0) n = visible;
+  if (n < 0 || n > M2S_MAX_PEERS + 1) return fail(M2S_ERR_BAD_ARG, "n_devices %d outside [1, %d]", n, M2S_MAX_PEERS + 1);
+  std::vector<int> devices((size_t)n), lanes((size_t)n);
+  for (int k = 0; k < n; ++k) {
+    devices[k] = (opts && opts->devices) ? opts->devices[k] : k;
+    if (devices[k] < 0 || devices[k] >= visible) return fail(M2S_ERR_BAD_ARG, "devices[%d] = %d, but %d device(s) are visible", k, devices[k], visible);
+    int lane = 0;
+    for (int j = 0; j < k; ++j) lane += devices[j] == devices[k];   // shards that share a device get contexts of their own
+    if (lane >= M2S_MAX_LANES) return fail(M2S_ERR_BAD_ARG, "more than %d shards on device %d", M2S_MAX_LANES, devices[k]);
+    lanes[k] = lane;
+  }
+  const int mem_kind = opts ? opts->mem_kind : M2S_MEM_HOST;
+  if (mem_kind != M2S_MEM_HOST && mem_kind != M2S_MEM_DEVICE) return fail(M2S_ERR_BAD_ARG, "bad mem_kind");
+  int exchange = opts ? opts->exchange : M2S_XCHG_AUTO;
+  if (exchange < M2S_XCHG_AUTO || exchange > M2S_XCHG_NONE) return fail(M2S_ERR_BAD_ARG, "bad exchange");
+  const int peer_mode = opts ? opts->peer_mode : M2S_PEER_PUSH;
+  if (peer_mode != M2S_PEER_PUSH && peer_mode != M2S_PEER_STORE) return fail(M2S_ERR_BAD_ARG, "bad peer_mode");
+  const uint64_t nx = grid->cell_count[0], row = grid->cell_count[1] * grid->cell_count[2];
+  const bool empty = nx == 0 || row == 0;
+  for (int k = 0; k < (mem_kind == M2S_MEM_HOST ? 1 : n); ++k)
+    if (!outs[k] && !empty) return fail(M2S_ERR_BAD_ARG, "outs[%d] is NULL", k);
+
+  std::vector<int> distinct;
+  for (int d : devices) { bool seen = false; for (int e : distinct) seen |= e == d; if (!seen) distinct.push_back(d); }
+  // (an explicit RCCL request is honoured even for one shard: a 1-rank in-place all-gather, which is how the RCCL
+  // path is exercised on a 1-GPU box)
+  if (mem_kind == M2S_MEM_HOST || (n == 1 && exchange != M2S_XCHG_RCCL)) exchange = M2S_XCHG_NONE;
+  else if (exchange == M2S_XCHG_AUTO || exchange == M2S_XCHG_PEER) {
+    const bool ok = enable_peer_access(distinct);
+    if (!ok && exchange == M2S_XCHG_PEER) return fail(M2S_ERR_HIP, "peer access between the listed devices is not available");
+    exchange = ok ? M2S_XCHG_PEER : M2S_XCHG_RCCL;
+  }
+  if (exchange == M2S_XCHG_RCCL && distinct.size() != devices.size())
+    return fail(M2S_ERR_BAD_ARG, "the RCCL exchange needs distinct devices (one communicator rank per device)");
+  if (opts && opts->exchange_used) *opts->exchange_used = exchange;
+
+  // the mesh lives on devices[0] in device mode: the other devices read it through a staging copy of their own
+  const size_t vbytes = n_vertices * 12, ibytes = indices ? n_indices * (size_t)index_bytes : 0;
+  std::vector<uint64_t> xb((size_t)n), xe((size_t)n);
+  for (int k = 0; k < n; ++k) m2s_slab_bounds(nx, n, k, &xb[k], &xe[k]);
+
+  std::vector<int> rcs((size_t)n, 0);
+  std::vector<std::string> errs((size_t)n);
+  auto shard = [&](int k) {
+    m2s_opts o{};
+    o.struct_size = sizeof(m2s_opts);
+    o.device = devices[k];
+    o.lane = lanes[k];
+    o.mem_kind = mem_kind;
+    o.algorithm = opts ? opts->algorithm : 0;
+    o.x_begin = xb[k];
+    o.x_end = xe[k];
+    o.synchronous = 1;
+    o.timings = (opts && opts->timings) ? &opts->timings[k] : nullptr;
+    float* peers[M2S_MAX_PEERS];
+    if (exchange == M2S_XCHG_PEER) {
+      uint32_t np = 0;
+      for (int j = 0; j < n; ++j)
+        if (j != k && outs[j] != outs[k]) peers[np++] = outs[j];
+      o.n_peer_out = np;
+      o.peer_out = peers;
+      o.peer_mode = peer_mode;
+    }
+    const float* v = vertices;
+    const void* ix = indices;
+    void* staged = nullptr;
+    int rc = 0;
+    if (xe[k] == xb[k]) { rcs[k] = 0; return; }   // more shards than layers
+    if (mem_kind == M2S_MEM_DEVICE && devices[k] != devices[0] && (vbytes || ibytes)) {
+      // replicate the mesh: one peer copy into a block of this device (1.8 MB for 100k triangles)
+      if (hipSetDevice(devices[k]) != hipSuccess || hipMalloc(&staged, vbytes + ibytes + 512) != hipSuccess) rc = fail(M2S_ERR_HIP, "mesh replica: hipMalloc failed on device %d", devices[k]);
+      char* sv = (char*)staged;
+      char* si = sv + (vbytes + 255) / 256 * 256;
+      if (!rc && vbytes && hipMemcpyPeer(sv, devices[k], vertices, devices[0], vbytes) != hipSuccess) rc = fail(M2S_ERR_HIP, "mesh replica: hipMemcpyPeer failed");
+      if (!rc && ibytes && hipMemcpyPeer(si, devices[k], indices, devices[0], ibytes) != hipSuccess) rc = fail(M2S_ERR_HIP, "mesh replica: hipMemcpyPeer failed");
+      v = (const float*)sv;
+      if (indices) ix = si;
+    }
+    if (!rc) rc = m2s_generate_grid_sdf(v, n_vertices, ix, n_indices, index_bytes, topology, grid, sign_method,
+                                        mem_kind == M2S_MEM_HOST ? outs[0] : outs[k], &o);
+    if (rc) errs[k] = m2s_last_error();
+    if (staged) (void)hipFree(staged);
+    rcs[k] = rc;
+  };
+  if (n == 1) shard(0);
+  else {
+    std::vector<std::thread> th;
+    for (int k = 0; k < n; ++k) th.emplace_back(shard, k);
+    for (auto& t : th) t.join();
+  }
+  for (int k = 0; k < n; ++k)
+    if (rcs[k]) return fail(rcs[k], "shard %d (device %d): %s", k, devices[k], errs[k].c_str());
+  // every shard returned synchronously: all slabs (and, with the peer exchange, all pushes) are complete
+  if (exchange == M2S_XCHG_RCCL && !empty) {
+    const int rc = rccl_gather(devices, outs, xb, xe, row);
+    if (rc) return rc;
+  }
+  if (opts && opts->wall_ms) *opts->wall_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  return M2S_OK;
+}
+
+// ---- one process per GPU: buffers that other processes can map ---------------------------------------------
+int m2s_shared_alloc(size_t bytes, int device, void** device_ptr) {
+  clear_error();
+  if (!device_ptr) return fail(M2S_ERR_BAD_ARG, "device_ptr is NULL");
+  *device_ptr = nullptr;
+  M2S_HIP_CHECK(hipSetDevice(device));
+  M2S_HIP_CHECK(hipMalloc(device_ptr, bytes ? bytes : 256));
+  return M2S_OK;
+}
+
+int m2s_shared_free(void* device_ptr, int device) {
+  clear_error();
+  if (!device_ptr) return M2S_OK;
+  M2S_HIP_CHECK(hipSetDevice(device));
+  M2S_HIP_CHECK(hipDeviceSynchronize());
+  M2S_HIP_CHECK(hipFree(device_ptr));
+  return M2S_OK;
+}
+
+static_assert(sizeof(hipIpcMemHandle_t) == M2S_IPC_HANDLE_BYTES, "hipIpcMemHandle_t is expected to be 64 bytes");
+
+int m2s_ipc_export(const void* device_ptr, uint8_t handle[M2S_IPC_HANDLE_BYTES]) {
+  clear_error();
+  if (!device_ptr || !handle) return fail(M2S_ERR_BAD_ARG, "NULL argument");
+  hipIpcMemHandle_t h;
+  M2S_HIP_CHECK(hipIpcGetMemHandle(&h, const_cast<void*>(device_ptr)));
+  memcpy(handle, &h, sizeof(h));
+  return M2S_OK;
+}
+
+int m2s_ipc_open(const uint8_t handle[M2S_IPC_HANDLE_BYTES], int device, void** device_ptr) {
+  clear_error();
+  if (!handle || !device_ptr) return fail(M2S_ERR_BAD_ARG, "NULL argument");
+  *device_ptr = nullptr;
+  hipIpcMemHandle_t h;
+  memcpy(&h, handle, sizeof(h));
+  M2S_HIP_CHECK(hipSetDevice(device));
+  M2S_HIP_CHECK(hipIpcOpenMemHandle(device_ptr, h, hipIpcMemLazyEnablePeerAccess));
+  return M2S_OK;
+}
+
+int m2s_ipc_close(void* device_ptr, int device) {
+  clear_error();
+  if (!device_ptr) return M2S_OK;
+  M2S_HIP_CHECK(hipSetDevice(device));
+  M2S_HIP_CHECK(hipIpcCloseMemHandle(device_ptr));
+  return M2S_OK;
+}
+
+}  // extern "C"

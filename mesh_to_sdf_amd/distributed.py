@@ -21,7 +21,8 @@ stream that computed it.
 """
 from typing import Callable, List, Optional, Tuple
 
-from .api import AccelerationMethod, Grid, Mesh, SignMethod, Topology, generate_grid_sdf, generate_sdf
+from .api import (AccelerationMethod, Grid, Mesh, PeerMode, SharedGrid, SignMethod, Topology, generate_grid_sdf,
+                  generate_sdf)
 
 
 import os
@@ -138,11 +139,48 @@ def run_pieces(mesh: Mesh, grid: Grid, sign_method: SignMethod, out, pieces: Lis
     return results
 
 
+class PeerGrid:
+    """This rank's whole-grid result buffer plus the mapped buffers of every other rank (m2s_shared_alloc +
+    m2s_ipc_export / m2s_ipc_open; the 64-byte handles travel through `all_gather_object`).  With it the ranks deliver
+    their x-slabs by writing them into each other's buffers over xGMI themselves (m2s_opts.peer_out) — no all-gather.
+    Created once and reused for every step: mapping a peer's memory costs milliseconds."""
+
+    def __init__(self, n_cells: int, device: int, group=None):
+        import torch.distributed as dist
+
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.local = SharedGrid(n_cells, device)
+        handles = [None] * self.world
+        dist.all_gather_object(handles, self.local.handle, group=group)
+        self.peers = [SharedGrid.open(h, n_cells, device) for r, h in enumerate(handles) if r != self.rank]
+        self.tensor = self.local.tensor
+
+    def close(self):
+        import torch.distributed as dist
+
+        for p in self.peers:
+            p.close()
+        self.peers = []
+        if dist.is_initialized():
+            dist.barrier(self.group)   # nobody unmaps-then-frees under a peer that is still writing
+        self.tensor = None
+        self.local.close()
+
+
 def generate_grid_sdf_sharded(vertices, indices: Topology, grid: Grid, sign_method: SignMethod = SignMethod.Raycast, *,
                               group=None, out=None, compute_slab: Optional[Callable] = None, chunks: int = 1,
-                              mesh: Optional[Mesh] = None, gather: bool = True, return_mesh: bool = False):
+                              mesh: Optional[Mesh] = None, gather: bool = True, return_mesh: bool = False,
+                              peer_grid: Optional[PeerGrid] = None, peer_mode: PeerMode = PeerMode.Push, timings=None):
     """generate_grid_sdf over all ranks of `group` (default: the world).  `vertices`/`indices` are this
     rank's copies (CUDA tensors for the HIP path); returns the full grid on every rank.
+
+    Two ways to deliver the slabs:
+      peer_grid given   one m2s_generate_grid_sdf call per rank on its contiguous x-slab, writing into `peer_grid.tensor`
+                        and into every other rank's buffer (peer pushes over xGMI), then a barrier: no collective moves data;
+      otherwise         `chunks` contiguous x-ranges, each gathered in place by an asynchronous RCCL all-gather that
+                        overlaps the next chunk's compute.
 
     compute_slab(out, x0, x1) may replace the slab computation (the CPU tests inject the oracle there
     so the partition / overlap / gather logic runs under gloo without a GPU)."""
@@ -154,6 +192,14 @@ def generate_grid_sdf_sharded(vertices, indices: Topology, grid: Grid, sign_meth
     world = dist.get_world_size(group) if inited else 1
     rank = dist.get_rank(group) if inited else 0
     row = ny * nz
+    if peer_grid is not None:
+        a, b = slab_bounds(nx, world, rank)
+        out = peer_grid.tensor
+        generate_grid_sdf(vertices, indices, grid, sign_method, x_slab=(a, b), out=out, peer_out=peer_grid.peers,
+                          peer_mode=peer_mode, timings=timings)   # synchronous: this rank's slab and its pushes are complete
+        if world > 1:
+            dist.barrier(group)                                   # ... and so are everybody else's into `out`
+        return out
     if out is None:
         dev = vertices.device if hasattr(vertices, "device") else "cpu"
         out = torch.empty(nx * row, dtype=torch.float32, device=dev)

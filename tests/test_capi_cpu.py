@@ -28,7 +28,7 @@ def test_exports_match_header(lib):
     assert declared == set(_lib.EXPORTS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.m2s_version() == 1
+    assert lib.m2s_version() == 2
 
 
 def test_struct_layout_matches_header(tmp_path):
@@ -38,14 +38,18 @@ def test_struct_layout_matches_header(tmp_path):
     src = tmp_path / "probe.c"
     src.write_text(
         '#include <stdio.h>\n#include <stddef.h>\n#include "m2s.h"\n'
-        'int main(void){printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(m2s_grid), sizeof(m2s_timings), sizeof(m2s_opts),'
-        ' offsetof(m2s_opts, x_begin), offsetof(m2s_opts, timings), offsetof(m2s_timings, n_units));return 0;}\n'
+        'int main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %d\\n", sizeof(m2s_grid), sizeof(m2s_timings), sizeof(m2s_opts),'
+        ' offsetof(m2s_opts, x_begin), offsetof(m2s_opts, timings), offsetof(m2s_timings, n_units),'
+        ' offsetof(m2s_opts, lane), offsetof(m2s_opts, peer_out), sizeof(m2s_multi_opts), offsetof(m2s_multi_opts, timings),'
+        ' M2S_OPTS_V1_SIZE);return 0;}\n'
     )
     exe = tmp_path / "probe"
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
     got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
     want = [C.sizeof(_lib.M2SGrid), C.sizeof(_lib.M2STimings), C.sizeof(_lib.M2SOpts), _lib.M2SOpts.x_begin.offset,
-            _lib.M2SOpts.timings.offset, _lib.M2STimings.n_units.offset]
+            _lib.M2SOpts.timings.offset, _lib.M2STimings.n_units.offset, _lib.M2SOpts.lane.offset, _lib.M2SOpts.peer_out.offset,
+            C.sizeof(_lib.M2SMultiOpts), _lib.M2SMultiOpts.timings.offset, _lib.OPTS_V1_SIZE]
+    assert _lib.M2SOpts.lane.offset == _lib.OPTS_V1_SIZE   # version-0.1 callers stop exactly where the new fields begin
     assert got == want
 
 

@@ -1,0 +1,188 @@
+"""Multi-GPU generate_grid_sdf behind the C ABI (include/m2s.h: m2s_generate_grid_sdf_multi, m2s_opts.peer_out,
+m2s_ipc_*), exercised on ONE GPU: `devices` may name a device twice (two shards, two contexts, two host threads),
+peers are then other buffers on the same device; the cross-process exchange runs as two processes sharing the GPU;
+RCCL runs as a 1-rank communicator.  A device-count-gated test covers real peers where the box has them.
+Everything is compared bit for bit with the single-device call (itself bit-identical to the oracle, test_gpu_parity.py).
+"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from mesh_to_sdf_amd import (Exchange, Grid, PeerMode, SignMethod, Topology, generate_grid_sdf, generate_grid_sdf_multi, meshes,
+                             slab_bounds)
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _case(n=(70, 40, 36), mesh="blob-6k"):
+    v, idx = meshes.named(mesh)
+    lo, hi = meshes.extended_bbox(v, 0.1)
+    return v, idx, Grid.from_bounding_box(lo, hi, list(n))
+
+
+def _device_inputs(v, idx):
+    import torch
+
+    return torch.as_tensor(v, device="cuda:0"), torch.as_tensor(idx.astype(np.int64), device="cuda:0")
+
+
+@pytest.mark.parametrize("sign", [SignMethod.Raycast, SignMethod.Normal])
+@pytest.mark.parametrize("devices", [[0], [0, 0], [0, 0, 0]])
+def test_multi_host_result_equals_single_call(sign, devices):
+    v, idx, g = _case()
+    want = generate_grid_sdf(v, Topology.TriangleList(idx), g, sign)
+    info = {}
+    got = generate_grid_sdf_multi(v, Topology.TriangleList(idx), g, sign, devices=devices, info=info)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    assert info["exchange"] == "Nothing"                       # host result: no collective at all
+    nx = g.get_cell_count()[0]
+    assert sum(int(t.n_units) for t in info["timings"]) == g.get_total_cell_count()
+    assert [int(t.n_units) for t in info["timings"]] == [(b - a) * 40 * 36 for a, b in (slab_bounds(nx, len(devices), k) for k in range(len(devices)))]
+
+
+@pytest.mark.parametrize("mode", [PeerMode.Push, PeerMode.Store])
+@pytest.mark.parametrize("sign", [SignMethod.Raycast, SignMethod.Normal])
+def test_multi_device_resident_peer_exchange_two_shards_one_gpu(mode, sign):
+    import torch
+
+    v, idx, g = _case((83, 40, 36))   # uneven slabs, x not a multiple of the brick
+    dv, di = _device_inputs(v, idx)
+    want = generate_grid_sdf(dv, Topology.TriangleList(di), g, sign)
+    outs = [torch.full_like(want, float("nan")) for _ in range(3)]
+    info = {}
+    got = generate_grid_sdf_multi(dv, Topology.TriangleList(di), g, sign, devices=[0, 0, 0], outs=outs, exchange=Exchange.Peer,
+                                  peer_mode=mode, info=info)
+    assert info["exchange"] == "Peer"
+    for k, o in enumerate(got):     # EVERY buffer holds the whole grid
+        assert torch.equal(o.view(torch.int32), want.view(torch.int32)), f"buffer {k}"
+
+
+def test_multi_peer_push_large_slab_in_pieces():
+    """A slab big enough for the piece pipeline (walk of piece i+1 beside the push of piece i)."""
+    import torch
+
+    v, idx = meshes.named("blob-100k")
+    lo, hi = meshes.extended_bbox(v, 0.1)
+    g = Grid.from_bounding_box(lo, hi, [256, 256, 256])
+    dv, di = _device_inputs(v, idx)
+    want = generate_grid_sdf(dv, Topology.TriangleList(di), g, SignMethod.Raycast)
+    info = {}
+    outs = generate_grid_sdf_multi(dv, Topology.TriangleList(di), g, SignMethod.Raycast, devices=[0, 0], exchange=Exchange.Peer, info=info)
+    assert [int(t.distance_launches) for t in info["timings"]] == [4, 4]
+    for o in outs:
+        assert torch.equal(o.view(torch.int32), want.view(torch.int32))
+
+
+def test_multi_rccl_one_rank():
+    """The ncclAllGather fallback through librccl (dlopen), as a 1-rank communicator on this box's GPU."""
+    import torch
+
+    v, idx, g = _case()
+    dv, di = _device_inputs(v, idx)
+    want = generate_grid_sdf(dv, Topology.TriangleList(di), g, SignMethod.Raycast)
+    info = {}
+    outs = generate_grid_sdf_multi(dv, Topology.TriangleList(di), g, SignMethod.Raycast, devices=[0], exchange=Exchange.Rccl, info=info)
+    assert info["exchange"] == "Rccl"
+    assert torch.equal(outs[0].view(torch.int32), want.view(torch.int32))
+
+
+def test_multi_exchange_none_leaves_other_slabs_alone():
+    import torch
+
+    v, idx, g = _case()
+    dv, di = _device_inputs(v, idx)
+    want = generate_grid_sdf(dv, Topology.TriangleList(di), g, SignMethod.Raycast).view(70, -1)
+    outs = [torch.full((70 * 40 * 36,), -7.0, device="cuda:0") for _ in range(2)]
+    generate_grid_sdf_multi(dv, Topology.TriangleList(di), g, SignMethod.Raycast, devices=[0, 0], outs=outs, exchange=Exchange.Nothing)
+    for k in range(2):
+        a, b = slab_bounds(70, 2, k)
+        o = outs[k].view(70, -1)
+        assert torch.equal(o[a:b], want[a:b])
+        mask = torch.ones(70, dtype=torch.bool, device="cuda:0")
+        mask[a:b] = False
+        assert bool((o[mask] == -7.0).all())
+
+
+def test_multi_real_peers_when_the_box_has_them():
+    import torch
+
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs (the driver's GPU box has one)")
+    n = min(torch.cuda.device_count(), 8)
+    v, idx, g = _case((96, 64, 64), "blob-100k")
+    dv, di = _device_inputs(v, idx)
+    want = generate_grid_sdf(dv, Topology.TriangleList(di), g, SignMethod.Raycast)
+    for exchange, mode in ((Exchange.Peer, PeerMode.Push), (Exchange.Peer, PeerMode.Store), (Exchange.Rccl, PeerMode.Push)):
+        outs = generate_grid_sdf_multi(dv, Topology.TriangleList(di), g, SignMethod.Raycast, devices=list(range(n)), exchange=exchange, peer_mode=mode)
+        for o in outs:
+            assert torch.equal(o.cpu().view(torch.int32), want.cpu().view(torch.int32)), (exchange, mode)
+    host = generate_grid_sdf_multi(v, Topology.TriangleList(idx), g, SignMethod.Raycast, devices=list(range(n)))
+    assert np.array_equal(host.view(np.uint32), want.cpu().numpy().view(np.uint32))
+
+
+def test_multi_errors():
+    from mesh_to_sdf_amd import M2SPanic
+
+    v, idx, g = _case()
+    with pytest.raises(M2SPanic):
+        generate_grid_sdf_multi(v, Topology.TriangleList(idx), g, SignMethod.Raycast, devices=[0, 99])
+    bad = idx.copy()
+    bad[5] = 10 ** 6                                              # out-of-range index: the reference panics; every shard reports it
+    with pytest.raises(M2SPanic):
+        generate_grid_sdf_multi(v, Topology.TriangleList(bad), g, SignMethod.Raycast, devices=[0, 0])
+    empty = Grid.from_bounding_box([0, 0, 0], [1, 1, 1], [0, 4, 4])
+    assert generate_grid_sdf_multi(v, Topology.TriangleList(idx), empty, SignMethod.Raycast, devices=[0, 0]).size == 0
+
+
+def test_concurrent_calls_on_two_lanes_from_two_threads():
+    """Threading contract of include/m2s.h: contexts are per (device, lane); two host threads on different lanes run
+    concurrently and do not disturb each other."""
+    import threading
+
+    v, idx, g = _case()
+    want = {s: generate_grid_sdf(v, Topology.TriangleList(idx), g, s) for s in (SignMethod.Raycast, SignMethod.Normal)}
+    errs = []
+
+    def work(lane, sign):
+        try:
+            for _ in range(6):
+                got = generate_grid_sdf(v, Topology.TriangleList(idx), g, sign, lane=lane)
+                assert np.array_equal(got.view(np.uint32), want[sign].view(np.uint32))
+        except Exception as e:   # noqa: BLE001
+            errs.append(e)
+
+    th = [threading.Thread(target=work, args=(k, s)) for k, s in enumerate((SignMethod.Raycast, SignMethod.Normal, SignMethod.Raycast))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs
+
+
+def _run_worker(mode, world, extra_env=None, timeout=300):
+    env = dict(os.environ)
+    env.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(29500 + (os.getpid() % 400)), "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    env.update(extra_env or {})
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", env["MASTER_PORT"], os.path.join(ROOT, "tests", "dist_worker.py"), mode]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stdout[-3000:] + "\n" + r.stderr[-3000:]
+    return r.stdout
+
+
+def test_two_processes_one_gpu_ipc_peer_exchange():
+    """One process per GPU, peers mapped through m2s_ipc_*: two ranks share this box's GPU, each writes its slab into
+    the other's whole-grid buffer (push and epilogue-store modes), host barrier, both compare with the single call."""
+    out = _run_worker("ipc_peer", 2, {"M2S_DIST_BACKEND": "gloo"})
+    assert out.count("ipc_peer ok") == 2, out
+
+
+def test_nccl_backend_one_rank():
+    """The torch.distributed "nccl" backend (= RCCL) on this box's GPU: 1-rank group, chunked in-place all-gathers
+    issued from the piece streams (M2S_FORCE_COLLECTIVES), result equal to the single call."""
+    out = _run_worker("nccl_one_rank", 1, {"M2S_FORCE_COLLECTIVES": "1"})
+    assert "nccl_one_rank ok" in out, out
