@@ -4,8 +4,9 @@
 
 One "step" = one complete generate_grid_sdf call through the C ABI with the mesh and the output
 resident in HBM (device pointers): topology flatten + LBVH build + sign planes + nearest-triangle
-kernel for this rank's x-slab, then the RCCL all-gather that leaves the full grid on every GPU
-(N = 1: one m2s_generate_grid_sdf call; N > 1: mesh_to_sdf_amd/distributed.py).
+kernel for this rank's contiguous x-slab, and its delivery so that the full grid is on every GPU
+(N = 1: one m2s_generate_grid_sdf call; N > 1: mesh_to_sdf_amd/distributed.py — peer writes over xGMI
+through m2s_opts.peer_out, or chunked RCCL all-gathers with M2S_EXCHANGE=rccl).
 The work is FIXED as N grows (strong scaling): rank r computes cells x in [r*512/N, (r+1)*512/N).
 
     python bench.py --gpus 1 --steps 10 --warmup 2
@@ -110,9 +111,14 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus}")
+    # Three ways to run (all through the C ABI of include/m2s.h):
+    #   N = 1                                   one m2s_generate_grid_sdf call per step (the reference's call)
+    #   N > 1 under torch.distributed.run       one process per GPU; every rank computes its contiguous x-slab with one call and
+    #                                           delivers it by peer writes over xGMI (m2s_opts.peer_out on IPC-mapped buffers,
+    #                                           M2S_EXCHANGE=peer, default) or by chunked in-place RCCL all-gathers (=rccl)
+    #   N > 1 started as plain `python bench.py` one process: m2s_generate_grid_sdf_multi, one host thread per device
+    in_process = world == 1 and args.gpus > 1
+    n_gpus = args.gpus if in_process else world
     local_dev = local_rank % max(torch.cuda.device_count(), 1)   # one rank per GPU; the modulo only matters in 1-GPU tests
     torch.cuda.set_device(local_dev)
     dev = torch.device("cuda", local_dev)
@@ -124,8 +130,9 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    from mesh_to_sdf_amd import Grid, M2STimings, SignMethod, Topology, generate_grid_sdf, meshes
-    from mesh_to_sdf_amd.distributed import generate_grid_sdf_sharded, slab_bounds
+    from mesh_to_sdf_amd import (Exchange, Grid, M2STimings, PeerMode, SignMethod, Topology, generate_grid_sdf,
+                                 generate_grid_sdf_multi, meshes)
+    from mesh_to_sdf_amd.distributed import PeerGrid, generate_grid_sdf_sharded, slab_bounds
 
     v, idx = meshes.named(args.mesh)
     lo, hi = meshes.extended_bbox(v, 0.1)
@@ -135,55 +142,103 @@ def main():
     dv = torch.as_tensor(v, device=dev)
     di = torch.as_tensor(idx.astype(np.int64), device=dev).to(torch.int32)
     topo = Topology.TriangleList(di)
-    out = torch.empty(n ** 3, dtype=torch.float32, device=dev)
     x0, x1 = slab_bounds(n, world, rank)
-
-    chunks = args.chunks if args.chunks > 0 else (4 if (world > 1 or force_pg) else 1)
-
     sharded = world > 1 or force_pg
+    peer_mode = PeerMode[os.environ.get("M2S_PEER_MODE", "Push")]
+    exchange = os.environ.get("M2S_EXCHANGE", "peer") if sharded else ("in-process" if in_process else "none")
 
-    def step():
-        # one complete call: LBVH build, sign planes, seed passes, nearest-triangle launches.
-        # N = 1: exactly the reference's call, one m2s_generate_grid_sdf through the C ABI (device pointers).
-        # N > 1: this rank's x-pieces through the persistent mesh + the all-gathers (asynchronous per chunk,
-        # overlapping the next chunk's compute).
-        if not sharded:
+    def all_agree(ok):
+        if not (dist.is_available() and dist.is_initialized()) or world == 1:
+            return ok
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(t.item())
+
+    pg, why = None, None
+    if sharded and exchange == "peer":
+        try:
+            pg = PeerGrid(n ** 3, local_dev)
+        except Exception as e:   # noqa: BLE001  (IPC mapping not permitted on this host, ...)
+            why = f"{type(e).__name__}: {e}"
+        if not all_agree(pg is not None):
+            if pg is not None:
+                pg.close()
+            pg, exchange = None, "rccl"
+    out = pg.tensor if pg is not None else torch.empty(n ** 3, dtype=torch.float32, device=dev)
+    outs = devices = None
+    if in_process:
+        devices = list(range(args.gpus))
+        if os.environ.get("M2S_BENCH_DEVICES"):                   # e.g. "0,0,0,0": the in-process path on a 1-GPU box
+            devices = [int(d) for d in os.environ["M2S_BENCH_DEVICES"].split(",")]
+        outs = [out] + [torch.empty(n ** 3, dtype=torch.float32, device=f"cuda:{d}") for d in devices[1:]]
+
+    def measure(exchange):
+        chunks = args.chunks if args.chunks > 0 else (4 if exchange == "rccl" else 1)
+
+        def step():
+            # one complete call: LBVH build, sign planes, seed passes, cut lists, nearest-triangle launches (+ delivery of the slab)
+            if in_process:
+                info = {}
+                generate_grid_sdf_multi(dv, topo, grid, sign, devices=devices, outs=outs, exchange=Exchange.Auto, peer_mode=peer_mode, info=info)
+                return info["timings"][0]
             t = M2STimings()
-            generate_grid_sdf(dv, topo, grid, sign, out=out, timings=t)
+            if not sharded:
+                generate_grid_sdf(dv, topo, grid, sign, out=out, timings=t)
+            elif exchange == "peer":
+                generate_grid_sdf_sharded(dv, topo, grid, sign, peer_grid=pg, peer_mode=peer_mode, timings=t)
+            else:
+                # this rank's x-pieces through the persistent mesh + the all-gathers (asynchronous per chunk, overlapping the
+                # next chunk's compute)
+                _, mesh = generate_grid_sdf_sharded(dv, topo, grid, sign, out=out, chunks=chunks, return_mesh=True)
+                t = mesh.drain_timings()   # waits for the launches of this step, reads their HIP-event durations
+                mesh.close()
             return t
-        _, mesh = generate_grid_sdf_sharded(dv, topo, grid, sign, out=out, chunks=chunks, return_mesh=True)
-        return mesh
 
-    def finish(mesh):
-        if not sharded:
-            return mesh   # the call was synchronous and filled its timings
-        t = mesh.drain_timings()   # waits for the launches of this step, reads their HIP-event durations
-        mesh.close()
-        return t
+        for _ in range(args.warmup):
+            step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        tims = []
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            tims.append(step())
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(te, op=dist.ReduceOp.MAX)
+            elapsed = float(te.item())
+        return elapsed, tims, chunks
 
-    for _ in range(args.warmup):
-        finish(step())
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    tims = []
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        tims.append(finish(step()))
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(te, op=dist.ReduceOp.MAX)
-        elapsed = float(te.item())
+    elapsed, tims, chunks = measure(exchange)
+
+    # N > 1: the delivered grid must be the grid (checked after the timed region, every rank against its own single-GPU run)
+    verified = None
+    if sharded or in_process:
+        ref = torch.empty(n ** 3, dtype=torch.float32, device=dev)
+        generate_grid_sdf(dv, topo, grid, sign, out=ref)
+        ok = all(bool(torch.equal(o.to(dev).view(torch.int32), ref.view(torch.int32))) for o in (outs if in_process else [out]))
+        verified = all_agree(ok)
+        if not verified and exchange == "peer":      # never report a number for a wrong grid: measure the RCCL path instead
+            why = "peer exchange delivered a grid that differs from the single-GPU result"
+            exchange = "rccl"
+            out = torch.empty(n ** 3, dtype=torch.float32, device=dev)
+            elapsed, tims, chunks = measure(exchange)
+            verified = all_agree(bool(torch.equal(out.view(torch.int32), ref.view(torch.int32))))
+        del ref
 
     # phase breakdown of one extra, untimed, synchronous one-shot call on this rank's whole slab
     ph = M2STimings()
-    generate_grid_sdf(dv, topo, grid, sign, x_slab=(x0, x1), out=out, timings=ph)
+    scratch_out = out if pg is None else torch.empty(n ** 3, dtype=torch.float32, device=dev)
+    xs = slab_bounds(n, n_gpus, 0) if in_process else (x0, x1)
+    generate_grid_sdf(dv, topo, grid, sign, x_slab=xs, out=scratch_out, timings=ph)
+    del scratch_out
+    world_label = n_gpus
 
     if rank == 0:
         ms_per_step = elapsed * 1e3 / args.steps
@@ -204,7 +259,7 @@ def main():
         pmc_src = None
         pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
         # the PMC figure is per launch over the WHOLE 512^3 grid: it only applies to the 1-GPU, 1-launch step
-        if os.path.exists(pmc) and world == 1 and launches == args.steps and n == 512 and args.mesh == "blob-100k":
+        if os.path.exists(pmc) and world_label == 1 and launches == args.steps and n == 512 and args.mesh == "blob-100k":
             try:
                 pj = json.load(open(pmc))
                 traffic = pj.get("k_packet_hbm_bytes_per_launch")
@@ -212,11 +267,15 @@ def main():
                 valu_frac = pj.get("valu_issue_frac")
             except Exception:
                 traffic = None
+        delivery = {"none": "single GPU, nothing to deliver",
+                    "peer": f"each rank writes its slab into every peer's buffer over xGMI, m2s_opts.peer_out / {peer_mode.name}, IPC-mapped, then a barrier; no collective",
+                    "rccl": f"{chunks} chunked in-place RCCL all-gathers overlapping the next chunk's compute",
+                    "in-process": f"peer writes over xGMI ({peer_mode.name}) or RCCL where peers cannot map each other"}[exchange]
         res = {
             "metric": "Mvoxels/s for generate_grid_sdf (512^3, 100k tris, Raycast)",
             "value": round(value, 2),
             "unit": "Mvoxels/s",
-            "n_gpus": world,
+            "n_gpus": world_label,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4),
@@ -227,15 +286,20 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"generate_grid_sdf {n}^3 grid, {args.mesh} ({n_tris} tris, {v.shape[0]} verts), SignMethod::{args.sign}, "
-                            f"x-slab sharded over {world} GPU(s) + RCCL all-gather, inputs/outputs resident in HBM",
+                            f"contiguous x-slabs over {world_label} GPU(s), whole grid resident on every GPU at the end of a step "
+                            f"(delivery: {delivery}), inputs/outputs resident in HBM",
                 "grid": [n, n, n],
                 "mesh": args.mesh,
                 "sign_method": args.sign,
-                "parallelism": f"xslab{world}",
+                "parallelism": f"xslab{world_label}",
+                "processes": ("1 (m2s_generate_grid_sdf_multi: one host thread per device)" if in_process else f"{world} (one per GPU)"),
+                "exchange": exchange,
+                "exchange_fallback_reason": why,
+                "gather_verified": verified,
                 "gather_chunks": chunks,
-                # N > 1: a rank's x-pieces run on two alternating streams, so consecutive launches of the dominant kernel
+                # rccl exchange: a rank's x-pieces run on two alternating streams, so consecutive launches of the dominant kernel
                 # overlap and their individual durations (roofline.avg_launch_ms) are longer than when run alone
-                "piece_streams": (int(os.environ.get("M2S_PIECE_STREAMS", "2")) if sharded and chunks > 1 else 1),
+                "piece_streams": (int(os.environ.get("M2S_PIECE_STREAMS", "2")) if exchange == "rccl" and chunks > 1 else 1),
             },
             "phases_ms": {"accel_build": round(build_ms, 4), "sign_planes": round(sign_ms, 4), "seed_passes": round(seed_ms, 4),
                           "distance_per_launch": round(dist_ms, 4), "launches_per_step": launches // max(args.steps, 1),
@@ -256,7 +320,7 @@ def main():
                 "valu_issue_frac_pmc": valu_frac,
             },
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world_label == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"], rn, ref = cpu_baseline(v, idx, lo, hi, int(sign), args.cpu_seconds, n)
             # What a user switching from the reference sees (SURVEY.md header fact 2, §8c): this library's exact minimum
             # against the reference's propagation semantics (the CPU run above, kept) on the same grid.
@@ -277,6 +341,8 @@ def main():
             res["host_pointer_call_ms"] = round(min(times[1:]), 2)
             res["host_pointer_first_call_ms"] = round(times[0], 2)
         print(json.dumps(res), flush=True)
+    if pg is not None:
+        pg.close()
     if dist.is_initialized():
         dist.destroy_process_group()
 

@@ -654,7 +654,7 @@ size_t bvh_workspace_bytes(size_t n_tris) {
 
 int build_device_mesh(Arena& ws, hipStream_t st, const float* d_verts, size_t n_verts, const void* d_indices,
                       size_t n_indices, int index_bytes, int topology, size_t n_tris, int* d_err, DeviceMesh* out,
-                      const std::function<int(const float4*)>* after_setup) {
+                      const std::function<int(const float4*, const TriRec*, int)>* after_setup) {
   (void)n_indices;
   out->cen_raw = nullptr;
   out->slot_of = nullptr;
@@ -711,7 +711,7 @@ int build_device_mesh(Arena& ws, hipStream_t st, const float* d_verts, size_t n_
   out->cen_raw = cen_raw;
   out->slot_of = slot_of;
   if (after_setup) {   // the caller's seed passes only need the centroids: they run beside the sort and the hierarchy
-    const int rc = (*after_setup)(cen_raw);
+    const int rc = (*after_setup)(cen_raw, raw, 0);   // phase 0: mark this point of the stream (an event), launch nothing yet
     if (rc) return rc;
   }
   hipLaunchKernelGGL(k_morton, dim3(cdiv(n_tris, B)), dim3(B), 0, st, boxes, (uint32_t)n_tris, scene, keys, vals);
@@ -729,6 +729,14 @@ int build_device_mesh(Arena& ws, hipStream_t st, const float* d_verts, size_t n_
   }
   M2S_HIP_CHECK(rocprim::radix_sort_pairs(tmp, sort_tmp, keys, keys2, vals, order, n_tris, 0, 64, st));
   if (n > 1) hipLaunchKernelGGL(k_karras, dim3(cdiv(n_tris - 1, B)), dim3(B), 0, st, keys2, n, range, child, parent);
+  if (after_setup) {
+    // phase 1: `st` now holds ~100 us of work (keys, sort, hierarchy) — the time the host needs to enqueue the side
+    // work (the seed passes, behind the phase-0 mark).  Launching it at phase 0 left `st` idle for those ~100 us (a
+    // launch costs the host ~8 us, and the thin slab of a multi-GPU rank has nothing to hide that behind); launching it
+    // after the whole build serialised the passes of a 512^3 lattice (0.5 ms) behind the build instead of beside it.
+    const int rc = (*after_setup)(cen_raw, raw, 1);
+    if (rc) return rc;
+  }
   static const bool treelets = !(getenv("M2S_TREELETS") && atoi(getenv("M2S_TREELETS")) == 0);
   if (n > 2 && treelets && !getenv("M2S_KEYS_FILE")) {
     // treelet pass: the nodes of at most TREELET_MAX triangles are rebuilt by sweep splits, then the hierarchy is derived again

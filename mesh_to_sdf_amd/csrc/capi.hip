@@ -153,6 +153,7 @@ int resolve_ctx(const m2s_opts* opts, CallCtx* c, DeviceState** st) {
   c->lock = std::unique_lock<std::mutex>((*st)->mu);
   int rc = init_state(**st);
   if (rc) return rc;
+  (*st)->early_planes = false;
   if (opts && (opts->stream || opts->stream_mode == 1)) c->stream = (hipStream_t)opts->stream;
   else if ((rc = own_stream(**st, &c->stream)) != 0) return rc;
   return select_scratch(**st, c->stream);
@@ -202,16 +203,23 @@ int stage_mesh(Arena& ws, const CallCtx& c, const float* vertices, size_t n_vert
 
 // Stream the sign planes of this call are built on: the device's side stream (ordered after everything enqueued on the
 // caller's stream so far), or the caller's stream itself with M2S_SIGN_OVERLAP=0.
-static int sign_stream_begin(DeviceState& st, hipStream_t main, bool synchronous_call, hipStream_t* out) {
+static bool side_stream_wanted(bool synchronous_call) {
   static const bool overlap = !(getenv("M2S_SIGN_OVERLAP") && atoi(getenv("M2S_SIGN_OVERLAP")) == 0);
-  st.planes_done = nullptr;
-  *out = main;
   // asynchronous calls are the pieces of a caller who overlaps them on streams of its own: leave the hardware queues to those
-  if (!overlap || !synchronous_call) return 0;
+  return overlap && synchronous_call;
+}
+static int ensure_side_stream(DeviceState& st) {
   if (!st.side_stream) {
     M2S_HIP_CHECK(hipStreamCreateWithFlags(&st.side_stream, hipStreamNonBlocking));
     M2S_HIP_CHECK(hipEventCreateWithFlags(&st.fork_ev, hipEventDisableTiming));
   }
+  return 0;
+}
+static int sign_stream_begin(DeviceState& st, hipStream_t main, bool synchronous_call, hipStream_t* out) {
+  st.planes_done = nullptr;
+  *out = main;
+  if (!side_stream_wanted(synchronous_call)) return 0;
+  if (int rc = ensure_side_stream(st)) return rc;
   M2S_HIP_CHECK(hipEventRecord(st.fork_ev, main));
   M2S_HIP_CHECK(hipStreamWaitEvent(st.side_stream, st.fork_ev, 0));
   *out = st.side_stream;
@@ -232,12 +240,12 @@ int finish_call(const CallCtx& c, DeviceState& st, int* d_err, m2s_timings* t, s
   if (t) {
     float a = 0, b = 0, d = 0, tot = 0;
     (void)hipEventElapsedTime(&a, st.ev[0], st.ev[1]);
-    (void)hipEventElapsedTime(&b, st.ev[1], st.ev[2]);
+    (void)hipEventElapsedTime(&b, st.early_planes ? st.ev[5] : st.ev[1], st.ev[2]);   // early planes: their own span on side_stream2
     float sd = 0;
     if (had_seed_event) {
       // planes beside the seed passes: the seed phase then runs from the end of the build (ev[1]) to the dominant launch,
       // which also waits for the planes; sign_ms and seed_ms overlap and do not add up to the total
-      (void)hipEventElapsedTime(&sd, st.planes_done ? st.ev[1] : st.ev[2], st.ev[4]);
+      (void)hipEventElapsedTime(&sd, (st.planes_done || st.early_planes) ? st.ev[1] : st.ev[2], st.ev[4]);
       (void)hipEventElapsedTime(&d, st.ev[4], st.ev[3]);
     } else {
       (void)hipEventElapsedTime(&d, st.ev[2], st.ev[3]);
@@ -788,26 +796,62 @@ int m2s_generate_grid_sdf(const float* vertices, size_t n_vertices, const void* 
   // stream sorts, derives the hierarchy and fits the bounds (0.3 ms).  The ids are translated to sorted slots afterwards.
   st->have_raw_seeds = false;
   static const bool seed_overlap = !(getenv("M2S_SEED_OVERLAP") && atoi(getenv("M2S_SEED_OVERLAP")) == 0);
-  const std::function<int(const float4*)> seeds_beside_build = [&](const float4* cen_raw) -> int {
-    hipStream_t ss;
-    int r = sign_stream_begin(*st, c.stream, c.sync, &ss);   // orders the side stream after the centroid kernels
+  const uint32_t* plane = nullptr;
+  st->early_planes = false;
+  static const bool early_sign = !(getenv("M2S_EARLY_SIGN") && atoi(getenv("M2S_EARLY_SIGN")) == 0);
+  const bool beside = seed_overlap && c.algorithm == 0 && !getenv("M2S_STATS") && grid_walk_wants_seeds(g, n_tris, c.algorithm);
+  const std::function<int(const float4*, const TriRec*, int)> seeds_beside_build = [&](const float4* cen_raw, const TriRec* raw, int phase) -> int {
+    if (!side_stream_wanted(c.sync)) return 0;               // no side stream for this call: seeds as part of the walk's preparation
+    if (phase == 0) {                                        // the centroid / record kernels are enqueued: mark that point
+      if (!st->seeds_done) {
+        M2S_HIP_CHECK(hipEventCreateWithFlags(&st->seeds_done, hipEventDisableTiming));
+        M2S_HIP_CHECK(hipEventCreateWithFlags(&st->seeds_fork, hipEventDisableTiming));
+      }
+      M2S_HIP_CHECK(hipEventRecord(st->seeds_fork, c.stream));
+    }
+    if (phase == 1 && sign_method == M2S_SIGN_RAYCAST && early_sign && n_tris) {
+      // The Raycast sign planes need nothing but the triangles themselves (marking is triangle-parallel and XOR is
+      // commutative, so the input order serves as well as the sorted one): a third stream builds them beside the rest of
+      // the build and the seed passes.  After the build they were the last thing the walk of a thin slab waited for
+      // (8-GPU rank: 0.09 ms of its 2.0 ms step).
+      if (!st->side_stream2) M2S_HIP_CHECK(hipStreamCreateWithFlags(&st->side_stream2, hipStreamNonBlocking));
+      M2S_HIP_CHECK(hipStreamWaitEvent(st->side_stream2, st->seeds_fork, 0));
+      M2S_HIP_CHECK(hipEventRecord(st->ev[5], st->side_stream2));
+      DeviceMesh rm{};
+      rm.tris = raw;
+      rm.n_tris = (uint32_t)n_tris;
+      int r2 = build_grid_sign_plane(ws, st->side_stream2, rm, g, &plane);
+      if (r2) return r2;
+      M2S_HIP_CHECK(hipEventRecord(st->ev[2], st->side_stream2));
+      st->early_planes = true;
+    }
+    if (!beside) return 0;
+    // A large lattice (512^3: 2 M brick centres, 0.5 ms of passes) must start at once to finish beside the build; a small
+    // one (the slab of a multi-GPU rank: 0.1 ms) starts when the sort is enqueued, so that the host's ~100 us of side-stream
+    // launches do not leave the caller's stream idle (common.h build_device_mesh).
+    const bool big = (uint64_t)host_packet_bricks(g) > 600000u;
+    if (phase == 0) {
+      if (!big) return 0;
+    } else if (big) {
+      return 0;                                              // launched at phase 0
+    }
+    int r = ensure_side_stream(*st);
     if (r) return r;
-    if (ss == c.stream) return 0;                            // no side stream for this call: seeds as part of the walk's preparation
-    if (!st->seeds_done) M2S_HIP_CHECK(hipEventCreateWithFlags(&st->seeds_done, hipEventDisableTiming));
-    r = launch_grid_seeds(ws, ss, cen_raw, (uint32_t)n_tris, g, &st->raw_seeds);
+    M2S_HIP_CHECK(hipStreamWaitEvent(st->side_stream, st->seeds_fork, 0));
+    r = launch_grid_seeds(ws, st->side_stream, cen_raw, (uint32_t)n_tris, g, &st->raw_seeds);
     if (r) return r;
-    M2S_HIP_CHECK(hipEventRecord(st->seeds_done, ss));
+    M2S_HIP_CHECK(hipEventRecord(st->seeds_done, st->side_stream));
     st->have_raw_seeds = true;
     return 0;
   };
-  const bool beside = seed_overlap && c.algorithm == 0 && !getenv("M2S_STATS") && grid_walk_wants_seeds(g, n_tris, c.algorithm);
   rc = build_device_mesh(ws, c.stream, sm.d_verts, n_vertices, sm.d_indices, n_indices, index_bytes, topology, n_tris, d_err, &mesh,
-                         beside ? &seeds_beside_build : nullptr);
+                         &seeds_beside_build);
   if (rc) return rc;
   M2S_HIP_CHECK(hipEventRecord(st->ev[1], c.stream));
-  const uint32_t* plane = nullptr;
   st->planes_done = nullptr;
-  if (sign_method == M2S_SIGN_RAYCAST) {
+  if (st->early_planes) {
+    st->planes_done = st->ev[2];                             // the walk waits for it
+  } else if (sign_method == M2S_SIGN_RAYCAST) {
     hipStream_t ss;
     rc = sign_stream_begin(*st, c.stream, c.sync, &ss);
     if (rc) return rc;

@@ -28,7 +28,9 @@ struct DeviceState {
   int n_scratch = 0, active = -1;
   uint64_t tick = 0;
   hipStream_t stream = nullptr;
-  hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // [5]: start of early sign planes (side_stream2)
+  hipStream_t side_stream2 = nullptr;   // one-shot Raycast grid calls: the sign planes, from the input-order records, beside build and seeds
+  bool early_planes = false;            // this call's planes were launched on side_stream2 (ev[5] .. ev[2])
   // Raycast sign planes depend on the mesh only: they are built on `side_stream` while the caller's stream runs the seed
   // passes and cut lists; the dominant launch waits for ev[2], which is then recorded on the side stream.
   hipStream_t side_stream = nullptr;
@@ -37,7 +39,7 @@ struct DeviceState {
   // one-shot grid calls also run the jump-flooding seed passes on the side stream, beside the sort / hierarchy of the build
   // (they only need the input-order centroids): the lattice, and the event recorded after the last pass
   SeedLattice raw_seeds;
-  hipEvent_t seeds_done = nullptr;
+  hipEvent_t seeds_done = nullptr, seeds_fork = nullptr;
   bool have_raw_seeds = false;
   int* h_err = nullptr;  // pinned
   char* spare_mesh = nullptr;  // last destroyed m2s_mesh block, recycled by the next m2s_mesh_create

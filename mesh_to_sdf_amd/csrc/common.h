@@ -199,11 +199,12 @@ struct Arena {
 // ---- host launchers implemented in the .hip files ------------------------------------------
 // bvh.hip: flatten topology, build triangle records + LBVH in pre-order layout.
 size_t bvh_workspace_bytes(size_t n_tris);
-// `after_setup` (optional) is called once the kernels that fill the input-order centroids are enqueued on `st`, with
-// that array: whatever it enqueues elsewhere (the seed passes) may wait for an event recorded on `st` at that point.
+// `after_setup` (optional) is called twice with the input-order centroid array and triangle records: with phase 0 once the kernels that fill
+// it are enqueued on `st` (record an event there), and with phase 1 once the keys, the sort and the hierarchy are enqueued
+// (enqueue the side work — the seed passes — on another stream behind that event; bvh.hip says why there).
 int build_device_mesh(Arena& ws, hipStream_t st, const float* d_verts, size_t n_verts, const void* d_indices,
                       size_t n_indices, int index_bytes, int topology, size_t n_tris, int* d_err, DeviceMesh* out,
-                      const std::function<int(const float4*)>* after_setup = nullptr);
+                      const std::function<int(const float4*, const TriRec*, int)>* after_setup = nullptr);
 
 // sign.hip: grid-line ray parity -> one "inside" bit per voxel (bit plane in grid layout).
 size_t sign_workspace_bytes(const GridParams& g, size_t n_tris);
@@ -227,6 +228,7 @@ struct SeedLattice {
   size_t points = 0;
 };
 bool grid_walk_wants_seeds(const GridParams& g, size_t n_tris, int algorithm);
+uint32_t host_packet_bricks(const GridParams& g);   // packet bricks of the slab (= points of its seed lattice), padded to super-bricks
 int launch_grid_seeds(Arena& ws, hipStream_t st, const float4* cen, uint32_t n_tris, const GridParams& g, SeedLattice* out);
 int prepare_grid_walk(Arena& ws, hipStream_t st, const DeviceMesh& mesh, const GridParams& g, int algorithm, bool pipelined,
                       GridWalkPlan* plan, const SeedLattice* raw_seeds = nullptr);
