@@ -274,9 +274,10 @@ int run_grid_distance(Arena& ws, const CallCtx& c, DeviceState& st, DeviceMesh m
                       const uint32_t* plane, float* d_out, int* d_err) {
   unsigned long long* d_stats = nullptr;
   if (getenv("M2S_STATS")) {
-    d_stats = ws.take<unsigned long long>(8);
-    unsigned long long init[8] = {0, 0, 0, 0, 0, 0, 0, (unsigned long long)atoi(getenv("M2S_STATS"))};
-    M2S_HIP_CHECK(hipMemcpyAsync(d_stats, init, 64, hipMemcpyHostToDevice, c.stream));
+    d_stats = ws.take<unsigned long long>(72);
+    unsigned long long init[72] = {0};
+    init[7] = (unsigned long long)atoi(getenv("M2S_STATS"));
+    M2S_HIP_CHECK(hipMemcpyAsync(d_stats, init, sizeof(init), hipMemcpyHostToDevice, c.stream));
     M2S_HIP_CHECK(hipStreamSynchronize(c.stream));
     mesh.stats = d_stats;
   }
@@ -289,11 +290,18 @@ int run_grid_distance(Arena& ws, const CallCtx& c, DeviceState& st, DeviceMesh m
   if (rc) return rc;
   M2S_HIP_CHECK(hipEventRecord(st.ev[3], c.stream));
   if (d_stats) {
-    unsigned long long h[8];
-    M2S_HIP_CHECK(hipMemcpyAsync(h, d_stats, 64, hipMemcpyDeviceToHost, c.stream));
+    unsigned long long h[72];
+    M2S_HIP_CHECK(hipMemcpyAsync(h, d_stats, sizeof(h), hipMemcpyDeviceToHost, c.stream));
     M2S_HIP_CHECK(hipStreamSynchronize(c.stream));
     const double w = h[3] ? (double)h[3] : 1.0;
-    fprintf(stderr, "[m2s stats] packets %llu: per packet node tests %.1f, leaf pre-tests %.1f, exact triangle tests %.1f\n", h[3], h[0] / w, h[1] / w, h[2] / w);
+    fprintf(stderr, "[m2s stats] packets %llu: per packet node tests %.1f, leaf pre-tests %.1f, exact triangle tests %.1f; node tests that pruned %.1f (by the slab term alone %.1f, by a sphere test %.1f)\n",
+            h[3], h[0] / w, h[1] / w, h[2] / w, h[4] / w, h[5] / w, h[6] / w);
+    // by distance of the packet's first voxel to its seed triangle, in cells: [0,1) [1,2) [2,4) ... [64,inf)
+    for (int bk = 0; bk < 8; ++bk) {
+      const unsigned long long* q = h + 8 + 8 * bk;
+      if (q[3]) fprintf(stderr, "[m2s stats]   band %d (d >= %d cells): %5.1f %% of packets, node tests %.1f, pre-tests %.1f, exact %.1f, cut ranges %.1f\n", bk, bk ? 1 << (bk - 1) : 0,
+                        100.0 * q[3] / w, (double)q[0] / q[3], (double)q[1] / q[3], (double)q[2] / q[3], (double)q[4] / q[3]);
+    }
   }
   return 0;
 }

@@ -327,6 +327,7 @@ __global__ __launch_bounds__(256) void k_packet(DeviceMesh mesh, GridParams g, c
 
   Best<MODE> best;
   uint32_t st_box = 0, st_ext = 0, st_leaf = 0;   // wave-uniform traversal counters (SGPRs)
+  uint32_t st_pruned = 0, st_slab = 0, st_sphere = 0, st_ranges = 0, st_band = 0;
   if (mesh.n_nodes) {
     const float scale = fmaxf(mesh_scale(mesh), fmaxf(fabsf(p.x), fmaxf(fabsf(p.y), fabsf(p.z))));
     const float slack = 4.0e-6f * scale + (MODE == MODE_NORMAL_FOLD ? 2.5e-6f : 0.0f);
@@ -372,6 +373,11 @@ __global__ __launch_bounds__(256) void k_packet(DeviceMesh mesh, GridParams g, c
     }
 
     float thr = prune_bound(best.d2, slack);
+    if (STATS && GRID) {
+      const float cells = __shfl(__builtin_amdgcn_sqrtf(best.d2), 0) / fabsf(g.size[0]);
+      st_band = cells < 1.0f ? 0u : min(7u, 1u + (uint32_t)__builtin_amdgcn_readfirstlane((int)floorf(log2f(cells))));
+      st_band = __builtin_amdgcn_readfirstlane(st_band);
+    }
     // M2S_STATS=2: a second, counting-only traversal that starts from the final bound ("perfect seed")
     const int passes = (STATS && mesh.stats != nullptr && mesh.stats[7] == 2ull) ? 2 : 1;
     for (int pass = 0; pass < passes; ++pass) {
@@ -387,6 +393,7 @@ __global__ __launch_bounds__(256) void k_packet(DeviceMesh mesh, GridParams g, c
       cl = cut.lists + (size_t)cb * CUT_WORDS;
       n_ranges = cl[0];
     }
+    if (STATS) st_ranges = n_ranges;
     for (uint32_t range = 0; range < n_ranges; ++range) {
     uint32_t off = cl ? cl[1 + 2 * range] : 0u;
     const uint32_t end = cl ? cl[2 + 2 * range] : mesh.n_nodes * NB;
@@ -395,6 +402,15 @@ __global__ __launch_bounds__(256) void k_packet(DeviceMesh mesh, GridParams g, c
       const NodeExt nr = *reinterpret_cast<const NodeExt*>(reinterpret_cast<const char*>(mesh.ext) + off);
       if (STATS) ++st_box;
       const float ed2 = ext_dist2(p, nr);
+      if (STATS && __ballot(!(ed2 > thr)) == 0ull) {
+        ++st_pruned;
+        const float vx = p.x - nr.cx, vy = p.y - nr.cy, vz = p.z - nr.cz;
+        const float t = nr.nz * vz + nr.ny * vy + nr.nx * vx, sl = fmaxf(fabsf(t - nr.mid) - nr.half, 0.0f);
+        if (__ballot(!(sl * sl > thr)) == 0ull) ++st_slab;
+        const float rs = __builtin_amdgcn_sqrtf(nr.R * nr.R + (fabsf(nr.mid) + nr.half) * (fabsf(nr.mid) + nr.half));
+        const float sp = fmaxf(__builtin_amdgcn_sqrtf(vx * vx + vy * vy + vz * vz) - rs, 0.0f);
+        if (__ballot(!(sp * sp > thr)) == 0ull) ++st_sphere;
+      }
       if (__ballot(!(ed2 > thr)) == 0ull) { off = nr.skip; continue; }   // a NaN bound keeps the node
       if (nr.tri >= 0) {
         const uint32_t cnt = (nr.skip - off + NB) / (2u * NB);    // triangles of this (possibly collapsed) leaf
@@ -423,6 +439,15 @@ __global__ __launch_bounds__(256) void k_packet(DeviceMesh mesh, GridParams g, c
     atomicAdd(&mesh.stats[1], (unsigned long long)st_ext);
     atomicAdd(&mesh.stats[2], (unsigned long long)st_leaf);
     atomicAdd(&mesh.stats[3], 1ull);
+    atomicAdd(&mesh.stats[4], (unsigned long long)st_pruned);
+    atomicAdd(&mesh.stats[5], (unsigned long long)st_slab);
+    atomicAdd(&mesh.stats[6], (unsigned long long)st_sphere);
+    unsigned long long* q = mesh.stats + 8 + 8 * st_band;
+    atomicAdd(&q[0], (unsigned long long)st_box);
+    atomicAdd(&q[1], (unsigned long long)st_ext);
+    atomicAdd(&q[2], (unsigned long long)st_leaf);
+    atomicAdd(&q[3], 1ull);
+    atomicAdd(&q[4], (unsigned long long)st_ranges);
   }
 
   bool negate = false;
@@ -602,99 +627,132 @@ __global__ __launch_bounds__(256) void k_jfa_pass(DeviceMesh mesh, GridParams g0
   out[i] = best;
 }
 
-// ---- k_cut: one wave per 4 x 4 x 4 bricks = 2 x 2 x 2 blocks; lane = brick (see CutList) -------------------
-// The eight blocks of a wave are neighbours, so they visit nearly the same top of the tree: the wave walks it ONCE, like
-// k_packet does (wave-uniform position, node records through scalar loads, a subtree left when no lane's ball reaches
-// it), one bound test per lane per node.  Lane 8 g + j owns brick j of block g: its centre q and the radius R inside which
-// a subtree can still matter to one of its voxels.  Block-level decisions are the block's byte of the wave ballot; a block
-// that has dropped or emitted a subtree sits out until the walk has left it (`resume`).
-// Earlier versions, 512^3 x blob-100k / the 64-layer slab of an 8-GPU rank: one lane per block, eight tests per step on
-// one dependency chain and per-lane 48-byte record fetches: 0.27 / 0.24 ms (a ~200-step chain at ~1.2 us per step however
-// small the slab); eight lanes per block with per-lane fetches: 0.40 / 0.15 ms (eight times the record traffic through
-// the vector L1).
+// ---- k_cut: one wave per 4 x 4 x 4 bricks, lane = brick, one cut list per brick (see CutList) ---------------
+// The 64 bricks of a wave are neighbours, so they visit nearly the same top of the tree: the wave walks it ONCE, like
+// k_packet does (wave-uniform position, node records through scalar loads, a subtree left when no lane keeps it), one
+// test per lane per node; a lane that has dropped or emitted a subtree sits out until the walk has left it (`resume`).
+//
+// What a brick may drop.  Brick: centre q, every voxel centre v = q + w with |w| <= r.  k_packet evaluates the brick's seed
+// triangle T first, so voxel v ends with a minimum <= dist(v, T) <= |v - s|, s = the point of T closest to q, a = q - s,
+// D = |a|, e = a / D.  Subtree X lies inside its convex disc-slab C_X; c = the point of C_X closest to q, L = |q - c|,
+// n = (q - c) / L, and convexity gives dist(v, C_X) >= n . (v - c) = L + n . w.  X holds nothing within (or tied with) any
+// voxel's minimum if   L + n . w > |a + w|   for all |w| <= r.  Two sufficient conditions, either drops X:
+//   sphere     L - r > D + r                                                       (1-Lipschitz; the only test so far)
+//   gradient   L - D > |n - e| r + r^2 / (2 D)          from |a + w| <= D + e . w + |w|^2 / (2 D)
+// The sphere test wastes 2 r = 5 cells: far from the surface (D = 64 cells) it keeps every triangle of a cap of ~25
+// cells radius, so the lists had to stay coarse and the packets walked the rest voxel by voxel — 64 lanes repeating
+// nearly the same decision (84 % of the packets of 512^3 x blob-100k are farther than 16 cells from the surface and
+// they are the expensive ones: 129 node tests at D >= 64 cells against 45 next to the surface).  The gradient test sees
+// that all voxels of the brick look at X from (almost) the same direction as at their seed: its slack is
+// |n - e| r ~ (lateral offset / D) r, a few tenths of a cell, so the lists can go down to subtrees of a few triangles.
+// All margins are far above f32 rounding (relative 1e-4 on lengths, sqrt(2e-5) on |n - e|), always towards keeping.
+//
+// Earlier versions (512^3 x blob-100k / the 64-layer slab of an 8-GPU rank; lists per block of 2 x 2 x 2 bricks, sphere
+// test): one lane per block, per-lane record fetches: 0.27 / 0.24 ms; eight lanes per block: 0.40 / 0.15 ms; one wave per
+// eight blocks with scalar record loads: 0.22 / 0.07 ms.
 __global__ __launch_bounds__(64) void k_cut(DeviceMesh mesh, GridParams g, const uint32_t* __restrict__ seeds,
-                                            uint32_t seed_ny, uint32_t seed_nz, uint32_t log, uint32_t ncx, uint32_t ncy,
-                                            uint32_t ncz, uint32_t* __restrict__ lists, float emit_near, float emit_far) {
-  const uint32_t nsy = (ncy + 1u) >> 1, nsz = (ncz + 1u) >> 1;
-  const uint32_t sb = blockIdx.x;                            // super-block: 2 x 2 x 2 blocks
+                                            uint32_t seed_ny, uint32_t seed_nz, uint32_t nbx, uint32_t nby, uint32_t nbz,
+                                            uint32_t* __restrict__ lists, float emit_near, float emit_far, uint32_t budget) {
+  const uint32_t nsy = (nby + 3u) >> 2, nsz = (nbz + 3u) >> 2;
+  const uint32_t sb = blockIdx.x;                            // 4 x 4 x 4 bricks
   const uint32_t sz = sb % nsz, sy = (sb / nsz) % nsy, sx = sb / (nsz * nsy);
-  const uint32_t lane = threadIdx.x & 63u, grp = lane >> 3, j = lane & 7u, group_shift = lane & ~7u;
-  const uint32_t cx = 2u * sx + (grp >> 2), cy = 2u * sy + ((grp >> 1) & 1u), cz = 2u * sz + (grp & 1u);
-  const bool block_in_grid = cx < ncx && cy < ncy && cz < ncz;
-  const uint32_t b = (cx * ncy + cy) * ncz + cz;
-  const uint32_t nb[3] = {bricks_along(g.xe - g.xb, g.bl[0]), bricks_along(g.n[1], g.bl[1]), bricks_along(g.n[2], g.bl[2])};
-  const uint32_t c0[3] = {cx << log, cy << log, cz << log};   // first brick of the block
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t bk[3] = {4u * sx + (lane >> 4), 4u * sy + ((lane >> 2) & 3u), 4u * sz + (lane & 3u)};
+  const bool in_grid = bk[0] < nbx && bk[1] < nby && bk[2] < nbz;
   const uint32_t origin[3] = {g.xb, 0u, 0u};
-  // half extents (between voxel centres) of a brick and of the block, and their half diagonals
-  float r_brick = 0.0f, r_block = 0.0f, centre[3];
+  float r = 0.0f, qq[3];
   for (int k = 0; k < 3; ++k) {
-    const float as = fabsf(g.size[k]);
-    const float hb = 0.5f * (float)((1u << g.bl[k]) - 1u) * as, hB = 0.5f * (float)((1u << (g.bl[k] + log)) - 1u) * as;
-    r_brick = __builtin_fmaf(hb, hb, r_brick);
-    r_block = __builtin_fmaf(hB, hB, r_block);
-    centre[k] = g.first[k] + ((float)(origin[k] + (c0[k] << g.bl[k])) + 0.5f * (float)((1u << (g.bl[k] + log)) - 1u)) * g.size[k];
+    const float hb = 0.5f * (float)((1u << g.bl[k]) - 1u) * fabsf(g.size[k]);   // half extent between voxel centres
+    r = __builtin_fmaf(hb, hb, r);
+    qq[k] = g.first[k] + ((float)(origin[k] + (bk[k] << g.bl[k])) + 0.5f * (float)((1u << g.bl[k]) - 1u)) * g.size[k];
   }
-  r_brick = sqrtf(r_brick) * 1.0001f;
-  r_block = sqrtf(r_block) * 1.0001f;
-  // This lane's brick: its centre q, and R with   |voxel - q| <= r_brick,   distance(voxel, seed triangle of the
-  // brick) <= r_brick + distance(q, seed triangle) =: D   (the distance to a triangle is 1-Lipschitz), so a subtree X
-  // with bound(q, X) > D + r_brick (+ margins) holds nothing within the final minimum of any voxel of that brick.
-  // A subtree is dropped for a block when that holds for every brick of the block.
-  const float scale = fmaxf(mesh_scale(mesh), fmaxf(fabsf(centre[0]), fmaxf(fabsf(centre[1]), fabsf(centre[2]))) + r_block);
-  const uint32_t bk[3] = {c0[0] + (j >> 2), c0[1] + ((j >> 1) & 1u), c0[2] + (j & 1u)};
-  f3 q = mk3(0.0f, 0.0f, 0.0f);
-  float R2 = -1.0f, R = 0.0f;                                // brick outside the grid: never keeps anything
-  if (block_in_grid && bk[0] < nb[0] && bk[1] < nb[1] && bk[2] < nb[2]) {
+  r = sqrtf(r) * 1.0001f;
+  const f3 q = mk3(qq[0], qq[1], qq[2]);
+  const float scale = fmaxf(mesh_scale(mesh), fmaxf(fabsf(q.x), fmaxf(fabsf(q.y), fabsf(q.z))) + r);
+  const float abs_margin = 6.4e-5f * scale + 4.0e-5f;        // the packet walk's own slack is <= 4e-6 * scale + 2.5e-6
+  float R2 = -1.0f, R = 0.0f, D = 0.0f;                      // brick outside the grid: never keeps anything
+  f3 e = mk3(0.0f, 0.0f, 0.0f);
+  float grad_c0 = __builtin_inff(), grad_c1 = 0.0f;          // gradient test: drop if L * (1 - 1e-4) - grad_c0 > grad_c1 * |n - e|
+  if (in_grid) {
     const uint32_t slot = min(seeds[(bk[0] * seed_ny + bk[1]) * seed_nz + bk[2]], mesh.n_tris - 1);
     const TriRec& t = mesh.tris[slot];
-    float qq[3];
-    for (int k = 0; k < 3; ++k)
-      qq[k] = g.first[k] + ((float)(origin[k] + (bk[k] << g.bl[k])) + 0.5f * (float)((1u << g.bl[k]) - 1u)) * g.size[k];
-    q = mk3(qq[0], qq[1], qq[2]);
     const f3 a = mk3(t.ax, t.ay, t.az), bq = mk3(t.bx, t.by, t.bz), c = mk3(t.cx, t.cy, t.cz);
-    const TriEdges e = {mk3(t.abx, t.aby, t.abz), mk3(t.acx, t.acy, t.acz), mk3(t.bcx, t.bcy, t.bcz)};
-    float d = point_triangle_dist2(q, a, bq, c, e, t.cls);   // what k_packet's seed evaluation finds at the brick centre
-    d = (d == d) ? sqrtf(d) : __builtin_inff();
-    // the packet walk keeps a node while bound <= d * 1.00002 + slack (slack <= 4e-6 * scale + 2.5e-6): stay well above that
-    R = (d * 1.0001f + 2.0f * r_brick) * 1.0003f + 6.4e-5f * scale + 4.0e-5f;
+    const TriEdges ed = {mk3(t.abx, t.aby, t.abz), mk3(t.acx, t.acy, t.acz), mk3(t.bcx, t.bcy, t.bcz)};
+    const f3 s = closest_point_triangle(q, a, bq, c, ed, t.cls);
+    const f3 av = sub3(q, s);
+    const float d2 = dot3(av, av);
+    D = (d2 == d2) ? sqrtf(d2) : __builtin_inff();
+    // sphere: the packet walk keeps a node while bound <= d * 1.00002 + slack: stay well above that
+    R = (D * 1.0001f + 2.0f * r) * 1.0003f + abs_margin;
     R2 = R * R;                                              // inf: nothing is dropped
+    if (D > r && D < 3.0e37f) {                              // (valid for any D > 0; useless when r^2 / 2D is large)
+      const float inv = 1.0f / D;
+      e = mk3(av.x * inv, av.y * inv, av.z * inv);
+      grad_c0 = D * 1.0003f + (r * r * 0.5f * inv) * 1.01f + abs_margin;
+      grad_c1 = r * 1.001f;
+    }
   }
-  float Rmax = R;
-  for (int m = 1; m < 8; m <<= 1) Rmax = fmaxf(Rmax, __shfl_xor(Rmax, m));
-  const float emit_radius = fmaxf(emit_near * r_block, Rmax * emit_far);   // per block
+  const float emit_radius = fmaxf(emit_near * r, R * emit_far);
 
   constexpr uint32_t NB = (uint32_t)sizeof(NodeExt);
   const uint32_t end = mesh.n_nodes * NB;
-  uint32_t* out = lists + (size_t)b * CUT_WORDS;
-  uint32_t n = 0, last_start = 0, last_end = 0, resume = 0;   // per block (identical in its eight lanes)
+  uint32_t* out = lists + ((size_t)(in_grid ? (bk[0] * nby + bk[1]) * nbz + bk[2] : 0u)) * CUT_WORDS;
+  uint32_t n = 0, last_start = 0, last_end = 0, resume = 0, opened = 0;   // per lane
   uint32_t off = 0;                                           // wave-uniform
   while (off < end) {
     off = __builtin_amdgcn_readfirstlane(off);
     const NodeExt nr = *reinterpret_cast<const NodeExt*>(reinterpret_cast<const char*>(mesh.ext) + off);
-    const bool active = off >= resume;                        // this block has not dropped / emitted an ancestor
-    const bool mine = active & !(ext_dist2(q, nr) > R2);      // NaN keeps the node
-    const unsigned long long bal = __ballot(mine);
+    const bool active = off >= resume;                        // this brick has not dropped / emitted an ancestor
+    // closest point of the disc-slab to q:  q - c = ax * n_s + lat * l / |l|   (common.h NodeExt, ext_dist2)
+    const float vx = q.x - nr.cx, vy = q.y - nr.cy, vz = q.z - nr.cz;
+    const float t = __builtin_fmaf(nr.nz, vz, __builtin_fmaf(nr.ny, vy, nr.nx * vx));
+    const float v2 = __builtin_fmaf(vz, vz, __builtin_fmaf(vy, vy, vx * vx));
+    const float l2 = __builtin_fmaf(-1.0e-6f, v2, __builtin_fmaf(-t, t, v2));
+    const float ell = __builtin_amdgcn_sqrtf(fmaxf(l2, 0.0f));
+    const float lat = fmaxf(ell - nr.R, 0.0f);
+    const float dt = t - nr.mid;
+    const float ax = copysignf(fmaxf(fabsf(dt) - nr.half, 0.0f), dt);
+    const float L2 = __builtin_fmaf(ax, ax, lat * lat);
+    bool keep = active & !(L2 > R2);                          // sphere test; NaN keeps the node
+    if (__ballot(keep) == 0ull) { off = nr.skip; continue; }
+    {
+      // gradient test (lanes without it carry grad_c0 = inf: never dropped).  rcp / rsq instead of IEEE divisions: their
+      // 1-ulp error is nothing beside the 2e-5 added under the root
+      const float ne_s = __builtin_fmaf(nr.nz, e.z, __builtin_fmaf(nr.ny, e.y, nr.nx * e.x));            // n_s . e
+      const float ve = __builtin_fmaf(vz, e.z, __builtin_fmaf(vy, e.y, vx * e.x));                       // (q - c0) . e
+      const float le = ve - t * ne_s;                                                                    // l . e
+      const float lat_dir = lat > 0.0f ? lat * __builtin_amdgcn_rcpf(ell) : 0.0f;
+      const float num = __builtin_fmaf(ax, ne_s, lat_dir * le);                                          // (q - c) . e
+      const float cosne = fminf(num * __builtin_amdgcn_rsqf(L2), 1.0f);                                  // n . e (NaN / inf if L == 0: kept)
+      const float nme = __builtin_amdgcn_sqrtf(fmaxf(2.0f - 2.0f * cosne, 0.0f) + 2.0e-5f);              // >= |n - e|
+      const float L = L2 * __builtin_amdgcn_rsqf(L2);
+      const bool drop = __builtin_fmaf(L, 0.9999f, -grad_c0) > grad_c1 * nme;                            // false on NaN
+      keep = keep & !drop;
+    }
+    const unsigned long long bal = __ballot(keep);
     if (bal == 0ull) { off = nr.skip; continue; }
-    const bool keep = ((bal >> group_shift) & 0xffull) != 0ull;
-    const bool emit = keep & (nr.tri >= 0 || fmaxf(nr.R, nr.half) <= emit_radius);
+    // Where many triangles are (nearly) equidistant — towards the medial axis, e.g. deep inside a round body — the brick-level
+    // test keeps a large part of the tree however far it descends: a brick that has already opened `budget` nodes emits what
+    // it meets next as it is and leaves the rest to the packet's per-voxel tests (which are 200 times sharper there).
+    // (a saturated list — CUT_MAX ranges — only grows its last range over every gap from here on: nothing finer can be said)
+    const bool emit = keep & (nr.tri >= 0 || fmaxf(nr.R, nr.half) <= emit_radius || opened >= budget || n == CUT_MAX);
     if (emit) {
       // keep this subtree: [off, skip).  Adjacent subtrees merge; past CUT_MAX ranges the last one grows over the gap
       if (n > 0 && (last_end == off || n == CUT_MAX)) last_end = nr.skip;
       else {
-        if (n > 0 && j == 0) { out[1 + 2 * (n - 1)] = last_start; out[2 + 2 * (n - 1)] = last_end; }
+        if (n > 0) { out[1 + 2 * (n - 1)] = last_start; out[2 + 2 * (n - 1)] = last_end; }
         ++n; last_start = off; last_end = nr.skip;
       }
     }
+    opened += (keep & !emit) ? 1u : 0u;
     if (active & (emit | !keep)) resume = nr.skip;            // done with this subtree either way
-    off = (__ballot(keep & !emit) != 0ull) ? off + NB : nr.skip;   // some block still has to look inside
+    off = (__ballot(keep & !emit) != 0ull) ? off + NB : nr.skip;   // some brick still has to look inside
   }
-  if (!block_in_grid) return;
+  if (!in_grid) return;
   if (n == 0) { n = 1; last_start = 0; last_end = end; }    // cannot happen with finite input; never walk nothing
-  if (j == 0) {
-    out[1 + 2 * (n - 1)] = last_start;
-    out[2 + 2 * (n - 1)] = last_end;
-    out[0] = n;
-  }
+  out[1 + 2 * (n - 1)] = last_start;
+  out[2 + 2 * (n - 1)] = last_end;
+  out[0] = n;
 }
 
 // ---- k_brute --------------------------------------------------------------------------------
@@ -937,7 +995,7 @@ static size_t cut_blocks(const GridParams& g, uint32_t log) {
 
 size_t grid_distance_workspace_bytes(const GridParams& g) {
   const size_t bricks = (size_t)host_brick_count(g);
-  return bricks * 16 + bricks + 16384 + cut_blocks(g, 1) * CUT_WORDS * 4 + 1024;   // seeds + cut lists (the smallest blocks)
+  return bricks * 16 + bricks + 16384 + cut_blocks(g, 0) * CUT_WORDS * 4 + 1024;   // seeds + cut lists (one per brick)
 }
 
 __global__ __launch_bounds__(256) void k_seed_remap(uint32_t* __restrict__ ids, size_t n, const uint32_t* __restrict__ slot_of, uint32_t n_tris) {
@@ -1028,17 +1086,17 @@ int prepare_grid_walk(Arena& ws, hipStream_t st, const DeviceMesh& mesh, const G
   const uint32_t cut_min_packets = getenv("M2S_CUT_MIN_PACKETS") ? (uint32_t)atoi(getenv("M2S_CUT_MIN_PACKETS")) : (pipelined ? 50000u : 100000u);
   static const int cut_env = getenv("M2S_CUT") ? atoi(getenv("M2S_CUT")) : 1;   // 0 = off
   if (!brute && !lane_walk && seed1 != nullptr && sh1 == 0 && cut_env > 0 && packets >= cut_min_packets) {
-    const uint32_t log = 1;   // k_cut holds the block's bricks in registers: 2 x 2 x 2
-    static const float emit_near = getenv("M2S_CUT_NEAR") ? (float)atof(getenv("M2S_CUT_NEAR")) : 2.0f;
-    static const float emit_far = getenv("M2S_CUT_FAR") ? (float)atof(getenv("M2S_CUT_FAR")) : 1.0f / 3.0f;
+    // emission radius of a list entry: emit_near brick radii next to the surface, emit_far of the distance far from it
+    const float emit_near = getenv("M2S_CUT_NEAR") ? (float)atof(getenv("M2S_CUT_NEAR")) : 2.0f;
+    const float emit_far = getenv("M2S_CUT_FAR") ? (float)atof(getenv("M2S_CUT_FAR")) : 1.0f / 16.0f;
+    const uint32_t budget = getenv("M2S_CUT_BUDGET") ? (uint32_t)atoi(getenv("M2S_CUT_BUDGET")) : 100000u;
     const uint32_t nbx = bricks_along(g.xe - g.xb, g.bl[0]), nby = bricks_along(g.n[1], g.bl[1]), nbz = bricks_along(g.n[2], g.bl[2]);
-    const uint32_t ncx = bricks_along(nbx, log), ncy = bricks_along(nby, log), ncz = bricks_along(nbz, log);
-    const size_t blocks = (size_t)ncx * ncy * ncz;
-    uint32_t* lists = ws.take<uint32_t>(blocks * CUT_WORDS);
+    const size_t bricks = (size_t)nbx * nby * nbz;
+    uint32_t* lists = ws.take<uint32_t>(bricks * CUT_WORDS);
     if (!lists) { set_error("internal: cut-list workspace too small"); return M2S_ERR_HIP_INTERNAL; }
-    const size_t super_blocks = (size_t)bricks_along(ncx, 1) * bricks_along(ncy, 1) * bricks_along(ncz, 1);
-    hipLaunchKernelGGL(k_cut, dim3((unsigned)super_blocks), dim3(64), 0, st, mesh, g, seed1, s1ny, s1nz, log, ncx, ncy, ncz, lists, emit_near, emit_far);
-    cut = {lists, log, ncy, ncz, 0};
+    const size_t waves = (size_t)bricks_along(nbx, 2) * bricks_along(nby, 2) * bricks_along(nbz, 2);
+    hipLaunchKernelGGL(k_cut, dim3((unsigned)waves), dim3(64), 0, st, mesh, g, seed1, s1ny, s1nz, nbx, nby, nbz, lists, emit_near, emit_far, budget);
+    cut = {lists, 0, nby, nbz, 0};
   }
   plan->seeds = seed1; plan->seed_shift = sh1; plan->seed_ny = s1ny; plan->seed_nz = s1nz;
   plan->cut_lists = cut.lists; plan->cut_log = cut.log; plan->cut_ny = cut.ny; plan->cut_nz = cut.nz;

@@ -1,2 +1,10 @@
-for W in 2 4; do echo "wpb=$W"; M2S_WPB=$W python bench.py --steps 6 --warmup 2 --no-cpu-baseline | python -c "import sys,json; d=json.loads(sys.stdin.readline()); print(d['value'], d['ms_per_step'], d['phases_ms']['distance_per_launch'])"; done
-for mb in 16 32 64 128; do echo "piece_mb=$mb"; M2S_HOST_PIECE_MB=$mb python tools/exp_host_calls.py 2>&1 | grep -E "512\^3|256\^3" | cut -c1-120; done
+#!/bin/bash
+# usage: tools/exp_sweep.sh VAR v1 v2 ... -- [extra env assignments]   : bench step + phases for each value of an experiment knob
+VAR=$1; shift
+VALS=()
+while [ $# -gt 0 ] && [ "$1" != "--" ]; do VALS+=("$1"); shift; done
+[ "$1" == "--" ] && shift
+for v in "${VALS[@]}"; do
+  echo -n "$VAR=$v $* : "
+  env $VAR=$v "$@" python bench.py --no-cpu-baseline --steps 10 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['phases_ms'])"
+done
