@@ -1079,11 +1079,12 @@ int prepare_grid_walk(Arena& ws, hipStream_t st, const DeviceMesh& mesh, const G
   const bool lane_walk = !brute && mesh.n_tris && (lane_env >= 0 ? lane_env == 1 : (double)mesh.n_tris > 60.0 * surface_bricks);   // measured crossover: 40 per brick favours the packet walk, 65 the lane walk
   // cut lists: the top of the tree is walked once per block of 2^log bricks per axis (k_cut)
   CutList cut = {nullptr, 0, 0, 0, 0};
-  // k_cut is a chain of dependent loads (0.17-0.24 ms whatever the grid); below ~100k packets it costs more than the
-  // shorter walks save (128^3: +0.15 ms).  Read per call: the tests lower it to cover small grids.
+  // k_cut costs about 0.25 us per brick plus a latency floor of ~0.1 ms; measured crossover (blob-100k / blob-6k,
+  // tools/exp_cutmin.py): 192^3 = 110 592 packets loses 0.1-0.2 ms with the lists, 256^3 = 262 144 packets breaks even or
+  // gains, 512^3 gains 1.3 ms.  Read per call: the tests lower it to cover small grids.
   // (asynchronous calls are the pieces of a caller who pipelines them on two streams: k_cut then runs under the previous
   // piece's walk and pays from about half that size)
-  const uint32_t cut_min_packets = getenv("M2S_CUT_MIN_PACKETS") ? (uint32_t)atoi(getenv("M2S_CUT_MIN_PACKETS")) : (pipelined ? 50000u : 100000u);
+  const uint32_t cut_min_packets = getenv("M2S_CUT_MIN_PACKETS") ? (uint32_t)atoi(getenv("M2S_CUT_MIN_PACKETS")) : (pipelined ? 100000u : 200000u);
   static const int cut_env = getenv("M2S_CUT") ? atoi(getenv("M2S_CUT")) : 1;   // 0 = off
   if (!brute && !lane_walk && seed1 != nullptr && sh1 == 0 && cut_env > 0 && packets >= cut_min_packets) {
     // emission radius of a list entry: emit_near brick radii next to the surface, emit_far of the distance far from it

@@ -66,6 +66,36 @@ int main(int argc, char** argv) {
   CHECK(rc == M2S_OK && memcmp(cells, cells2, sizeof(cells)) == 0 && m2s_mesh_triangle_count(mesh) == 1, "persistent mesh == one-shot");
   m2s_mesh_destroy(mesh);
 
+  /* the same call spread over a device list (here: this GPU three times = three shards, three host threads inside the
+   * library); host pointers, every shard writes its x-slab straight into the caller's array */
+  {
+    const int32_t devs[3] = {0, 0, 0};
+    m2s_multi_opts mo;
+    memset(&mo, 0, sizeof(mo));
+    mo.struct_size = sizeof(mo);
+    mo.n_devices = 3;
+    mo.devices = devs;
+    mo.mem_kind = M2S_MEM_HOST;
+    int used = -1;
+    mo.exchange_used = &used;
+    float cells3[27];
+    float* outs[1] = {cells3};
+    rc = m2s_generate_grid_sdf_multi(vertices, 3, indices, 3, 4, M2S_TRIANGLE_LIST, &grid, M2S_SIGN_RAYCAST, outs, &mo);
+    uint64_t a, b;
+    m2s_slab_bounds(3, 3, 1, &a, &b);
+    CHECK(rc == M2S_OK && memcmp(cells, cells3, sizeof(cells)) == 0 && used == M2S_XCHG_NONE && a == 1 && b == 2,
+          "m2s_generate_grid_sdf_multi over {0,0,0} == single call");
+    /* a version-0.1 caller's options (struct_size = M2S_OPTS_V1_SIZE) still work */
+    m2s_opts o1;
+    memset(&o1, 0, sizeof(o1));
+    o1.struct_size = M2S_OPTS_V1_SIZE;
+    o1.device = -1;
+    o1.synchronous = 1;
+    o1.lane = 12345;   /* garbage beyond the v1 size must be ignored */
+    rc = m2s_generate_grid_sdf(vertices, 3, indices, 3, 4, M2S_TRIANGLE_LIST, &grid, M2S_SIGN_RAYCAST, cells3, &o1);
+    CHECK(rc == M2S_OK && memcmp(cells, cells3, sizeof(cells)) == 0, "m2s_opts of version 0.1 accepted");
+  }
+
   /* container round trip through a file */
   const char* path = argc > 1 ? argv[1] : "/tmp/m2s_abi_smoke.bin";
   rc = m2s_sdf_save_grid(path, &grid, cells, 27, NULL);

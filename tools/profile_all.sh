@@ -17,5 +17,6 @@ for C in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INST
   ( cd /tmp && timeout 600 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_$i -o p -- $BENCH > $OUT/pmc_$i.log 2>&1 )
 done
 python tools/pmc_summary.py $OUT k_packet > $OUT/pmc_k_packet.txt 2>&1
+python tools/pmc_summary.py $OUT k_cut > $OUT/pmc_k_cut.txt 2>&1
 find $OUT -name "*.db" -size +20M -delete
 du -sh $OUT
