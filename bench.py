@@ -47,7 +47,56 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=150.0, help="budget for the CPU baseline run (512^3 needs ~40-60 s)")
     ap.add_argument("--chunks", type=int, default=0, help="x-chunks per step whose all-gathers overlap compute (0 = auto)")
-    return ap.parse_args()
+    ap.add_argument("--config", type=int, default=0, choices=[0, 2, 3, 4, 5],
+                    help="another BASELINE.json config on ONE GPU instead of the headline (0): 2 = 256^3 blob-100k Raycast, 3 = 10 M queries "
+                         "RtreeBvh, 4 = 512^3 blob-1M Raycast, 5 = 1024^3 sheet-100k Normal; same JSON line with that config's roofline")
+    args = ap.parse_args()
+    if args.config in (2, 4, 5):
+        args.mesh, args.grid, args.sign = {2: ("blob-100k", 256, "Raycast"), 4: ("blob-1M", 512, "Raycast"), 5: ("sheet-100k", 1024, "Normal")}[args.config]
+        args.no_cpu_baseline = True      # the CPU baseline belongs to the headline line
+    return args
+
+
+def bench_queries(args):
+    """BASELINE config 3: generate_sdf on 10 M uniform random queries x blob-100k, AccelerationMethod::RtreeBvh, one GPU,
+    queries and distances resident in HBM; one step = one complete m2s_generate_sdf call (build + Morton sort + walk)."""
+    import torch
+
+    from mesh_to_sdf_amd import AccelerationMethod, M2STimings, Topology, generate_sdf, meshes
+
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    v, idx = meshes.named("blob-100k")
+    lo, hi = meshes.extended_bbox(v, 0.1)
+    nq = 10_000_000
+    dq = torch.as_tensor(meshes.uniform_queries(lo, hi, nq), device=dev)
+    dv = torch.as_tensor(v, device=dev)
+    topo = Topology.TriangleList(torch.as_tensor(idx.astype(np.int64), device=dev).to(torch.int32))
+    tims = []
+    for _ in range(args.warmup):
+        generate_sdf(dv, topo, dq, AccelerationMethod.RtreeBvh)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        t = M2STimings()
+        generate_sdf(dv, topo, dq, AccelerationMethod.RtreeBvh, timings=t)
+        tims.append(t)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    dist_ms = float(np.mean([t.distance_ms for t in tims]))      # Morton sort + seed lattice + k_packet<LIST, UNSIGNED, RAYS3>
+    b_alg = 16.0 * nq + 12.0 * v.shape[0] + 12.0 * int(tims[0].n_triangles)   # SURVEY.md 8(d): 16 B per query + the mesh once
+    achieved = b_alg / (dist_ms * 1e-3) / 1e9
+    print(json.dumps({
+        "metric": "Mqueries/s for generate_sdf (10M random queries, 100k tris, RtreeBvh)", "value": round(nq * args.steps / elapsed / 1e6, 2),
+        "unit": "Mqueries/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed * 1e3 / args.steps, 4),
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BASELINE config 3: generate_sdf, 10 000 000 uniform queries in the extended bbox, blob-100k, AccelerationMethod::RtreeBvh "
+                               "(nearest distance + best of three rays), inputs/outputs resident in HBM", "queries": nq, "mesh": "blob-100k"},
+        "phases_ms": {"accel_build": round(float(np.mean([t.accel_build_ms for t in tims])), 4), "sort_seed_walk": round(dist_ms, 4)},
+        "roofline": {"bound": "hbm", "kernel": "k_packet<LIST, MODE_UNSIGNED, SIGN_RAYS3> (+ the query sort and seed lattice in front of it)",
+                     "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                     "algorithmic_bytes_per_launch": b_alg, "avg_launch_ms": round(dist_ms, 4)},
+    }), flush=True)
 
 
 def cpu_baseline(v, idx, lo, hi, sign, budget_s, headline_n):
@@ -105,6 +154,8 @@ def cpu_baseline(v, idx, lo, hi, sign, budget_s, headline_n):
 
 def main():
     args = parse()
+    if args.config == 3:
+        return bench_queries(args)
     import torch
     import torch.distributed as dist
 
@@ -272,7 +323,8 @@ def main():
                     "rccl": f"{chunks} chunked in-place RCCL all-gathers overlapping the next chunk's compute",
                     "in-process": f"peer writes over xGMI ({peer_mode.name}) or RCCL where peers cannot map each other"}[exchange]
         res = {
-            "metric": "Mvoxels/s for generate_grid_sdf (512^3, 100k tris, Raycast)",
+            "metric": ("Mvoxels/s for generate_grid_sdf (512^3, 100k tris, Raycast)" if args.config == 0 else
+                       f"Mvoxels/s for generate_grid_sdf (BASELINE config {args.config}: {n}^3, {args.mesh}, {args.sign}, one GPU)"),
             "value": round(value, 2),
             "unit": "Mvoxels/s",
             "n_gpus": world_label,
@@ -306,7 +358,7 @@ def main():
                           "one_shot_device_total": round(total_ms, 4)},
             "roofline": {
                 "bound": "hbm",
-                "kernel": "k_packet<GRID, MODE_UNSIGNED, SIGN_GRID_PLANE>",
+                "kernel": ("k_packet<GRID, MODE_UNSIGNED, SIGN_GRID_PLANE>" if args.sign == "Raycast" else "k_packet<GRID, MODE_NORMAL_FOLD, SIGN_NONE>"),
                 "achieved": round(achieved, 3),
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",

@@ -270,40 +270,51 @@ int finish_call(const CallCtx& c, DeviceState& st, int* d_err, m2s_timings* t, s
 
 // Seed passes + dominant launch (+ optional M2S_STATS counters); records ev[4] before and ev[3] after
 // the dominant launch.
+// M2S_STATS: traversal counters of the packet walk (a counting variant of k_packet), printed on stderr.
+static int stats_begin(Arena& ws, hipStream_t stream, DeviceMesh* mesh, unsigned long long** d_stats) {
+  *d_stats = nullptr;
+  if (!getenv("M2S_STATS")) return 0;
+  *d_stats = ws.take<unsigned long long>(72);
+  if (!*d_stats) return fail(M2S_ERR_HIP, "internal: workspace");
+  unsigned long long init[72] = {0};
+  init[7] = (unsigned long long)atoi(getenv("M2S_STATS"));
+  M2S_HIP_CHECK(hipMemcpyAsync(*d_stats, init, sizeof(init), hipMemcpyHostToDevice, stream));
+  M2S_HIP_CHECK(hipStreamSynchronize(stream));
+  mesh->stats = *d_stats;
+  return 0;
+}
+static int stats_end(hipStream_t stream, const unsigned long long* d_stats) {
+  if (!d_stats) return 0;
+  unsigned long long h[72];
+  M2S_HIP_CHECK(hipMemcpyAsync(h, d_stats, sizeof(h), hipMemcpyDeviceToHost, stream));
+  M2S_HIP_CHECK(hipStreamSynchronize(stream));
+  const double w = h[3] ? (double)h[3] : 1.0;
+  fprintf(stderr, "[m2s stats] packets %llu: per packet node tests %.1f, leaf pre-tests %.1f, exact triangle tests %.1f; node tests that pruned %.1f (by the slab term alone %.1f, by a sphere test %.1f)\n",
+          h[3], h[0] / w, h[1] / w, h[2] / w, h[4] / w, h[5] / w, h[6] / w);
+  // grid path: by distance of the packet's first voxel to its seed triangle, in cells: [0,1) [1,2) [2,4) ... [64,inf)
+  for (int bk = 0; bk < 8; ++bk) {
+    const unsigned long long* q = h + 8 + 8 * bk;
+    if (q[3])
+      fprintf(stderr, "[m2s stats]   band %d (d >= %d cells): %5.1f %% of packets, node tests %.1f, pre-tests %.1f, exact %.1f (reached lanes per exact test %.1f), cut ranges %.1f\n", bk, bk ? 1 << (bk - 1) : 0,
+              100.0 * q[3] / w, (double)q[0] / q[3], (double)q[1] / q[3], (double)q[2] / q[3], q[2] ? (double)q[5] / q[2] : 0.0, (double)q[4] / q[3]);
+  }
+  return 0;
+}
+
 int run_grid_distance(Arena& ws, const CallCtx& c, DeviceState& st, DeviceMesh mesh, const GridParams& g, int sign_method,
                       const uint32_t* plane, float* d_out, int* d_err) {
   unsigned long long* d_stats = nullptr;
-  if (getenv("M2S_STATS")) {
-    d_stats = ws.take<unsigned long long>(72);
-    unsigned long long init[72] = {0};
-    init[7] = (unsigned long long)atoi(getenv("M2S_STATS"));
-    M2S_HIP_CHECK(hipMemcpyAsync(d_stats, init, sizeof(init), hipMemcpyHostToDevice, c.stream));
-    M2S_HIP_CHECK(hipStreamSynchronize(c.stream));
-    mesh.stats = d_stats;
-  }
+  int rc = stats_begin(ws, c.stream, &mesh, &d_stats);
+  if (rc) return rc;
   // peers: M2S_PEER_STORE hands them to the walk's epilogue; M2S_PEER_PUSH (run_grid_distance_push) never comes here with any
-  int rc = launch_grid_distance(ws, c.stream, mesh, g, sign_method == M2S_SIGN_RAYCAST ? MODE_UNSIGNED : MODE_NORMAL_FOLD,
-                                plane, c.algorithm, d_out, d_err, st.ev[4], st.planes_done, !c.sync,
-                                st.have_raw_seeds ? &st.raw_seeds : nullptr, st.have_raw_seeds ? st.seeds_done : nullptr,
-                                c.peers.n ? &c.peers : nullptr);
+  rc = launch_grid_distance(ws, c.stream, mesh, g, sign_method == M2S_SIGN_RAYCAST ? MODE_UNSIGNED : MODE_NORMAL_FOLD,
+                            plane, c.algorithm, d_out, d_err, st.ev[4], st.planes_done, !c.sync,
+                            st.have_raw_seeds ? &st.raw_seeds : nullptr, st.have_raw_seeds ? st.seeds_done : nullptr,
+                            c.peers.n ? &c.peers : nullptr);
   st.have_raw_seeds = false;
   if (rc) return rc;
   M2S_HIP_CHECK(hipEventRecord(st.ev[3], c.stream));
-  if (d_stats) {
-    unsigned long long h[72];
-    M2S_HIP_CHECK(hipMemcpyAsync(h, d_stats, sizeof(h), hipMemcpyDeviceToHost, c.stream));
-    M2S_HIP_CHECK(hipStreamSynchronize(c.stream));
-    const double w = h[3] ? (double)h[3] : 1.0;
-    fprintf(stderr, "[m2s stats] packets %llu: per packet node tests %.1f, leaf pre-tests %.1f, exact triangle tests %.1f; node tests that pruned %.1f (by the slab term alone %.1f, by a sphere test %.1f)\n",
-            h[3], h[0] / w, h[1] / w, h[2] / w, h[4] / w, h[5] / w, h[6] / w);
-    // by distance of the packet's first voxel to its seed triangle, in cells: [0,1) [1,2) [2,4) ... [64,inf)
-    for (int bk = 0; bk < 8; ++bk) {
-      const unsigned long long* q = h + 8 + 8 * bk;
-      if (q[3]) fprintf(stderr, "[m2s stats]   band %d (d >= %d cells): %5.1f %% of packets, node tests %.1f, pre-tests %.1f, exact %.1f, cut ranges %.1f\n", bk, bk ? 1 << (bk - 1) : 0,
-                        100.0 * q[3] / w, (double)q[0] / q[3], (double)q[1] / q[3], (double)q[2] / q[3], (double)q[4] / q[3]);
-    }
-  }
-  return 0;
+  return stats_end(c.stream, d_stats);
 }
 
 
@@ -948,9 +959,14 @@ int m2s_generate_sdf(const float* vertices, size_t n_vertices, const void* indic
   if (rc) return rc;
   M2S_HIP_CHECK(hipEventRecord(st->ev[1], c.stream));
   M2S_HIP_CHECK(hipEventRecord(st->ev[2], c.stream));
+  unsigned long long* d_stats = nullptr;
+  rc = stats_begin(ws, c.stream, &mesh, &d_stats);
+  if (rc) return rc;
   rc = launch_query_distance(ws, c.stream, mesh, d_q, n_queries, mode, sign_src, algorithm, d_out, d_err);
   if (rc) return rc;
   M2S_HIP_CHECK(hipEventRecord(st->ev[3], c.stream));
+  rc = stats_end(c.stream, d_stats);
+  if (rc) return rc;
   if (c.mem_kind == M2S_MEM_HOST) {
     rc = staged_d2h(*st, c.stream, reinterpret_cast<char*>(out), reinterpret_cast<const char*>(d_out), n_queries * 4);
     if (rc) return rc;

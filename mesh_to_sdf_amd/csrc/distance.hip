@@ -327,7 +327,7 @@ __global__ __launch_bounds__(256) void k_packet(DeviceMesh mesh, GridParams g, c
 
   Best<MODE> best;
   uint32_t st_box = 0, st_ext = 0, st_leaf = 0;   // wave-uniform traversal counters (SGPRs)
-  uint32_t st_pruned = 0, st_slab = 0, st_sphere = 0, st_ranges = 0, st_band = 0;
+  uint32_t st_pruned = 0, st_slab = 0, st_sphere = 0, st_ranges = 0, st_band = 0, st_pairs = 0;
   if (mesh.n_nodes) {
     const float scale = fmaxf(mesh_scale(mesh), fmaxf(fabsf(p.x), fmaxf(fabsf(p.y), fabsf(p.z))));
     const float slack = 4.0e-6f * scale + (MODE == MODE_NORMAL_FOLD ? 2.5e-6f : 0.0f);
@@ -419,7 +419,7 @@ __global__ __launch_bounds__(256) void k_packet(DeviceMesh mesh, GridParams g, c
           const TriPlanes tp = record_at(mesh.planes, (uint32_t)nr.tri + k);   // scalar: small, needed for every leaf triangle
           const bool reach = !(planes_dist2(p, tp) > thr);
           if (__ballot(reach) != 0ull) {   // some lane's bound reaches the triangle itself
-            if (STATS) ++st_leaf;
+            if (STATS) { ++st_leaf; st_pairs += (uint32_t)__popcll(__ballot(reach)); }
             const TriRec tr = record_at_vec(mesh.tris, (uint32_t)nr.tri + k);
             eval_triangle_leaf<MODE>(best, p, tr, reach);
             thr = prune_bound(best.d2, slack);
@@ -448,6 +448,7 @@ __global__ __launch_bounds__(256) void k_packet(DeviceMesh mesh, GridParams g, c
     atomicAdd(&q[2], (unsigned long long)st_leaf);
     atomicAdd(&q[3], 1ull);
     atomicAdd(&q[4], (unsigned long long)st_ranges);
+    atomicAdd(&q[5], (unsigned long long)st_pairs);
   }
 
   bool negate = false;

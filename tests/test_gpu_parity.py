@@ -712,6 +712,73 @@ def test_fuzz_tree_walk_equals_brute_force(seed):
             assert_bit_equal(a, b, f"queries seed {seed} accel {am.kind}")
 
 
+def _uv_sphere(nu, nv, radius=1.0, centre=(0.0, 0.0, 0.0)):
+    th = np.linspace(0.0, np.pi, nv + 1)[:, None]
+    ph = np.linspace(0.0, 2 * np.pi, nu, endpoint=False)[None, :]
+    pts = np.stack([np.sin(th) * np.cos(ph), np.sin(th) * np.sin(ph), np.cos(th) * np.ones_like(ph)], -1).reshape(-1, 3)
+    tris = []
+    for i in range(nv):
+        for j in range(nu):
+            a, b = i * nu + j, i * nu + (j + 1) % nu
+            c, d = a + nu, b + nu
+            tris += [[a, c, b], [b, c, d]]
+    return (pts * radius + np.asarray(centre)).astype(F), np.asarray(tris, np.uint32).reshape(-1)
+
+
+def _box_surface(n):
+    """Six faces of [-1, 1]^3, each an n x n grid of quads (two triangles each)."""
+    u = np.linspace(-1.0, 1.0, n + 1)
+    verts, tris = [], []
+    for axis in range(3):
+        for side in (-1.0, 1.0):
+            base = len(verts)
+            for a in u:
+                for b in u:
+                    p = [0.0, 0.0, 0.0]
+                    p[axis], p[(axis + 1) % 3], p[(axis + 2) % 3] = side, a, b
+                    verts.append(p)
+            for i in range(n):
+                for j in range(n):
+                    q0 = base + i * (n + 1) + j
+                    tris += [[q0, q0 + 1, q0 + n + 1], [q0 + 1, q0 + n + 2, q0 + n + 1]]
+    return np.asarray(verts, F), np.asarray(tris, np.uint32).reshape(-1)
+
+
+@pytest.mark.parametrize("shape", ["sphere from inside", "sphere from outside", "box", "two sheets", "shell far from the origin"])
+@pytest.mark.parametrize("sign", [SignMethod.Raycast, SignMethod.Normal])
+def test_cut_lists_where_many_triangles_are_equidistant(shape, sign):
+    """The brick-level tests of k_cut (sphere and gradient test, distance.hip) on inputs built to hurt them: voxels for which
+    hundreds of triangles are (nearly) equidistant — the centre of a sphere, the medial planes of a box, the mid-plane between
+    two sheets — and far-field bricks at many cells from the surface, where the gradient test does the pruning.  The lists are
+    forced onto these small grids (fixture) and the result must equal the on-device brute force bit for bit."""
+    import os
+
+    os.environ["M2S_CUT_MIN_PACKETS"] = "8"
+    try:
+        if shape.startswith("sphere"):
+            v, idx = _uv_sphere(96, 48)
+            lo, hi = (np.array([-0.6] * 3, F), np.array([0.6] * 3, F)) if "inside" in shape else (np.array([-4.0, -3.0, -2.5], F), np.array([3.0, 4.0, 5.0], F))
+        elif shape == "box":
+            v, idx = _box_surface(24)
+            lo, hi = np.array([-0.97] * 3, F), np.array([0.97] * 3, F)
+        elif shape == "two sheets":
+            a, ia = meshes.sheet(40, 40)
+            b = a.copy()
+            a[:, 2] = 0.5
+            b[:, 2] = -0.5
+            v, idx = np.concatenate([a, b]), np.concatenate([ia, ia + a.shape[0]]).astype(np.uint32)
+            lo, hi = np.array([-0.8, -0.8, -0.45], F), np.array([0.8, 0.8, 0.45], F)
+        else:
+            v, idx = _uv_sphere(64, 32, radius=3.0, centre=(900.0, -450.0, 120.0))
+            lo, hi = v.min(0) - 8.0, v.max(0) + 8.0
+        g = Grid.from_bounding_box(lo, hi, [72, 64, 80])
+        a = generate_grid_sdf(v, Topology.TriangleList(idx), g, sign, algorithm=0)
+        b = generate_grid_sdf(v, Topology.TriangleList(idx), g, sign, algorithm=1)
+        assert_bit_equal(a, b, f"{shape} {sign.name}")
+    finally:
+        os.environ.pop("M2S_CUT_MIN_PACKETS", None)
+
+
 @pytest.mark.parametrize("counts", [[260, 9, 33], [7, 300, 5], [3, 6, 500], [64, 1, 64]])
 def test_anisotropic_grids_use_non_cubic_bricks(suzanne, counts):
     """Strongly anisotropic cell sizes make the kernels pick a packet brick that is not 4x4x4 (64x1x1 ... 1x1x64):
