@@ -130,13 +130,16 @@ typedef struct m2s_opts {
   int32_t peer_mode;    /* how: 0 = M2S_PEER_PUSH, one copy kernel per slab piece after its walk, 16 B per lane = 1 KiB per wave
                                     store instruction (xGMI-friendly request size; the default);
                                 1 = M2S_PEER_STORE, the walk's epilogue stores every value to every peer itself (no extra pass over
-                                    the slab, but 16-byte runs: a 4x4x4 brick row) */
+                                    the slab, but 16-byte runs: a 4x4x4 brick row);
+                                2 = M2S_PEER_TRAIL, one walk over the whole slab whose packets count themselves per unit of 8
+                                    x-layers, and a copy kernel beside it that pushes every unit (1 KiB per wave store) as soon as
+                                    it is complete: no pieces, and only the last unit's push is exposed */
   int32_t reserved2;
 } m2s_opts;
 #define M2S_OPTS_V1_SIZE 56
 #define M2S_MAX_LANES 16
 #define M2S_MAX_PEERS 15
-enum m2s_peer_mode { M2S_PEER_PUSH = 0, M2S_PEER_STORE = 1 };
+enum m2s_peer_mode { M2S_PEER_PUSH = 0, M2S_PEER_STORE = 1, M2S_PEER_TRAIL = 2 };
 
 /* generate_sdf — lib.rs:291-311.
  * vertices: n_vertices packed xyz f32.  indices: n_indices values of index_bytes (2 or 4) each, or NULL.

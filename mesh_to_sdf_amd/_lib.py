@@ -59,7 +59,7 @@ class M2SOpts(C.Structure):
 
 OPTS_V1_SIZE = 56
 MAX_PEERS = 15
-PEER_PUSH, PEER_STORE = 0, 1
+PEER_PUSH, PEER_STORE, PEER_TRAIL = 0, 1, 2
 XCHG_AUTO, XCHG_PEER, XCHG_RCCL, XCHG_NONE = 0, 1, 2, 3
 IPC_HANDLE_BYTES = 64
 

@@ -280,6 +280,7 @@ class PeerMode(enum.IntEnum):
     """include/m2s.h `m2s_peer_mode`: how a slab reaches the peers' whole-grid buffers."""
     Push = 0    # one wide copy kernel per slab piece, overlapped with the next piece's walk
     Store = 1   # the walk's epilogue stores every value to every peer
+    Trail = 2   # one walk; a copy kernel beside it pushes each unit of 8 x-layers as soon as the walk has finished it
 
 
 class Exchange(enum.IntEnum):

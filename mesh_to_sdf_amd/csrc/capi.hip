@@ -125,7 +125,7 @@ int resolve_ctx(const m2s_opts* opts, CallCtx* c, DeviceState** st) {
       if (opts->lane < 0 || opts->lane >= M2S_MAX_LANES) return fail(M2S_ERR_BAD_ARG, "m2s_opts.lane %d outside [0, %d)", opts->lane, M2S_MAX_LANES);
       if (opts->n_peer_out > M2S_MAX_PEERS) return fail(M2S_ERR_BAD_ARG, "m2s_opts.n_peer_out %u > %d", opts->n_peer_out, M2S_MAX_PEERS);
       if (opts->n_peer_out && !opts->peer_out) return fail(M2S_ERR_BAD_ARG, "m2s_opts.peer_out is NULL");
-      if (opts->peer_mode != M2S_PEER_PUSH && opts->peer_mode != M2S_PEER_STORE) return fail(M2S_ERR_BAD_ARG, "bad m2s_opts.peer_mode");
+      if (opts->peer_mode < M2S_PEER_PUSH || opts->peer_mode > M2S_PEER_TRAIL) return fail(M2S_ERR_BAD_ARG, "bad m2s_opts.peer_mode");
       c->lane = opts->lane;
       c->peer_mode = opts->peer_mode;
       c->peers.n = opts->n_peer_out;
@@ -264,6 +264,7 @@ int finish_call(const CallCtx& c, DeviceState& st, int* d_err, m2s_timings* t, s
   const int e = *st.h_err;
   if (e & ERRF_INDEX_OOB) return fail(M2S_ERR_BAD_ARG, "vertex index out of range (the reference panics indexing `vertices`)");
   if (e & ERRF_NAN) return fail(M2S_ERR_NAN, "NaN distance (lib.rs:257)");
+  if (e & ERRF_TRAIL_TIMEOUT) return fail(M2S_ERR_HIP, "the trailing peer push gave up waiting for the walk (M2S_PEER_TRAIL)");
   return M2S_OK;
 }
 
@@ -295,8 +296,9 @@ static int stats_end(hipStream_t stream, const unsigned long long* d_stats) {
   for (int bk = 0; bk < 8; ++bk) {
     const unsigned long long* q = h + 8 + 8 * bk;
     if (q[3])
-      fprintf(stderr, "[m2s stats]   band %d (d >= %d cells): %5.1f %% of packets, node tests %.1f, pre-tests %.1f, exact %.1f (reached lanes per exact test %.1f), cut ranges %.1f\n", bk, bk ? 1 << (bk - 1) : 0,
-              100.0 * q[3] / w, (double)q[0] / q[3], (double)q[1] / q[3], (double)q[2] / q[3], q[2] ? (double)q[5] / q[2] : 0.0, (double)q[4] / q[3]);
+      fprintf(stderr, "[m2s stats]   band %d (d >= %d cells): %5.1f %% of packets, node tests %.1f, pre-tests %.1f, exact %.1f (reached lanes per exact test %.1f), cut ranges %.1f (%.0f B of node records; all within 4 KiB for %.1f %% of the packets)\n", bk, bk ? 1 << (bk - 1) : 0,
+              100.0 * q[3] / w, (double)q[0] / q[3], (double)q[1] / q[3], (double)q[2] / q[3], q[2] ? (double)q[5] / q[2] : 0.0, (double)q[4] / q[3],
+              (double)q[6] / q[3], 100.0 * q[7] / q[3]);
   }
   return 0;
 }
@@ -368,6 +370,66 @@ int run_grid_distance_push(Arena& ws, const CallCtx& c, DeviceState& st, const D
   return 0;
 }
 
+// M2S_PEER_TRAIL: ONE walk over the whole slab (no pieces, no tails between them) with its packets ordered so that the
+// x-layers finish in order (super-bricks at most 2 bricks wide in x); the walk counts finished packets per unit of 2 bricks
+// of layers, and k_push_trailing — a few workgroups on the copy stream, launched AFTER the walk so that a runtime that maps
+// both streams onto one hardware queue merely serialises them — pushes every unit to the peers as soon as it is complete.
+// Only the last unit's push (1/8 of a 64-layer slab) is exposed, and every store instruction still carries 1 KiB.
+int run_grid_distance_trail(Arena& ws, const CallCtx& c, DeviceState& st, const DeviceMesh& mesh, const GridParams& g0,
+                            int sign_method, const uint32_t* plane, float* d_out, int* d_err) {
+  GridParams g = g0;
+  static const int dbg = getenv("M2S_TRAIL_DEBUG") ? atoi(getenv("M2S_TRAIL_DEBUG")) : 0;   // experiment: 1 = no copy kernel, 2 = default packet order
+  g.xl_cap = (dbg & 2) ? 0u : trail_unit_log(g) + 1u;
+  set_super_brick_magic(g);
+  if (!st.copy_stream) M2S_HIP_CHECK(hipStreamCreateWithFlags(&st.copy_stream, hipStreamNonBlocking));
+  while (st.piece_events.size() < 2) {
+    hipEvent_t e;
+    M2S_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    st.piece_events.push_back(e);
+  }
+  const int mode = sign_method == M2S_SIGN_RAYCAST ? MODE_UNSIGNED : MODE_NORMAL_FOLD;
+  GridWalkPlan plan;
+  if (st.have_raw_seeds) M2S_HIP_CHECK(hipStreamWaitEvent(c.stream, st.seeds_done, 0));
+  int rc = prepare_grid_walk(ws, c.stream, mesh, g, c.algorithm, !c.sync, &plan, st.have_raw_seeds ? &st.raw_seeds : nullptr);
+  st.have_raw_seeds = false;
+  if (rc) return rc;
+  const uint64_t row = (uint64_t)g.n[1] * g.n[2];
+  const bool trailing = !plan.lane_walk && c.algorithm == 0 && mesh.n_nodes != 0;   // k_packet counts its packets; the other walks do not
+  PeerOut walk_peers{};
+  if (trailing) {
+    const size_t counters = (size_t)trail_units(g) * (trail_rows(g) + 1u);
+    uint32_t* progress = ws.take<uint32_t>(counters);
+    if (!progress) return fail(M2S_ERR_HIP, "internal: workspace");
+    M2S_HIP_CHECK(hipMemsetAsync(progress, 0, counters * sizeof(uint32_t), c.stream));
+    walk_peers.progress = progress;
+    walk_peers.unit_log = trail_unit_log(g);
+    walk_peers.rows = trail_rows(g);
+    walk_peers.units = trail_units(g);
+  }
+  if (st.planes_done) M2S_HIP_CHECK(hipStreamWaitEvent(c.stream, st.planes_done, 0));
+  M2S_HIP_CHECK(hipEventRecord(st.piece_events[0], c.stream));          // counters are zero, inputs are ready
+  M2S_HIP_CHECK(hipEventRecord(st.ev[4], c.stream));
+  rc = launch_grid_walk(c.stream, mesh, g, mode, plane, c.algorithm, plan, 0, d_out, d_err, trailing ? &walk_peers : nullptr);
+  if (rc) return rc;
+  M2S_HIP_CHECK(hipEventRecord(st.ev[3], c.stream));
+  if (trailing) {
+    PeerOut push = c.peers;
+    push.progress = walk_peers.progress;
+    push.unit_log = walk_peers.unit_log;
+    push.rows = walk_peers.rows;
+    push.units = walk_peers.units;
+    M2S_HIP_CHECK(hipStreamWaitEvent(st.copy_stream, st.piece_events[0], 0));
+    if (!(dbg & 1)) rc = launch_push_trailing(st.copy_stream, d_out, push, g, d_err);
+  } else {
+    M2S_HIP_CHECK(hipStreamWaitEvent(st.copy_stream, st.ev[3], 0));
+    rc = launch_push_cells(st.copy_stream, d_out, c.peers, (uint64_t)g.xb * row - g.out_off, (uint64_t)(g.xe - g.xb) * row);
+  }
+  if (rc) return rc;
+  M2S_HIP_CHECK(hipEventRecord(st.piece_events[1], st.copy_stream));
+  M2S_HIP_CHECK(hipStreamWaitEvent(c.stream, st.piece_events[1], 0));
+  return 0;
+}
+
 // AccelerationMethod + SignMethod -> kernel mode, sign source, algorithm (include/m2s.h lists the rules).
 void select_generic_mode(int accel, int sign_method, int req_algorithm, int* mode, int* sign_src, int* algorithm) {
   *mode = MODE_UNSIGNED;
@@ -405,7 +467,7 @@ int fill_grid_params(const m2s_grid* grid, const m2s_opts* opts, GridParams* g, 
   g->xe = (uint32_t)xe;
   g->nzw = (uint32_t)((gz + 31) / 32);
   g->out_off = 0;
-  g->pad_ = 0;
+  g->xl_cap = 0;
   static const bool cube_only = getenv("M2S_BRICK_CUBE") && atoi(getenv("M2S_BRICK_CUBE")) != 0;
   if (cube_only) g->bl[0] = g->bl[1] = g->bl[2] = 2;
   else choose_brick_shape(g->size, g->bl);
@@ -892,9 +954,10 @@ int m2s_generate_grid_sdf(const float* vertices, size_t n_vertices, const void* 
     if (c.timings) c.timings->distance_launches = pieces;   // distance_ms then covers the seed passes of every piece too
     return rc;
   }
-  if (c.peers.n && c.peer_mode == M2S_PEER_PUSH && !getenv("M2S_STATS")) {
+  if (c.peers.n && c.peer_mode != M2S_PEER_STORE && !getenv("M2S_STATS")) {
     uint32_t pieces = 1;
-    rc = run_grid_distance_push(ws, c, *st, mesh, g, sign_method, plane, d_out, d_err, &pieces);
+    rc = c.peer_mode == M2S_PEER_TRAIL ? run_grid_distance_trail(ws, c, *st, mesh, g, sign_method, plane, d_out, d_err)
+                                       : run_grid_distance_push(ws, c, *st, mesh, g, sign_method, plane, d_out, d_err, &pieces);
     if (rc) return rc;
     rc = finish_call(c, *st, d_err, c.timings, n_tris, slab_cells, sign_method == M2S_SIGN_RAYCAST, true);
     if (c.timings) c.timings->distance_launches = pieces;
@@ -1151,7 +1214,9 @@ int m2s_mesh_generate_grid_sdf(m2s_mesh* m, const m2s_grid* grid, int sign_metho
     return rc;
   }
   uint32_t walk_launches = 1;
-  if (c.peers.n && c.peer_mode == M2S_PEER_PUSH && !getenv("M2S_STATS"))
+  if (c.peers.n && c.peer_mode == M2S_PEER_TRAIL && !getenv("M2S_STATS"))
+    rc = run_grid_distance_trail(ws, c, *st, m->dm, g, sign_method, plane, d_out, d_err);
+  else if (c.peers.n && c.peer_mode == M2S_PEER_PUSH && !getenv("M2S_STATS"))
     rc = run_grid_distance_push(ws, c, *st, m->dm, g, sign_method, plane, d_out, d_err, &walk_launches);
   else
     rc = run_grid_distance(ws, c, *st, m->dm, g, sign_method, plane, d_out, d_err);

@@ -110,7 +110,8 @@ struct GridParams {
   // index by them: one multiply-high instead of a 30-instruction u32 division per wave); 0 = divide (d == 1, or a grid so
   // large that the product could be off by one)
   uint32_t sz_magic, sy_magic;
-  uint32_t pad_;
+  uint32_t xl_cap;   // 0: super-bricks up to 8 bricks wide in x (distance.hip super_brick_xlog); k: at most 2^(k-1) bricks wide, so
+                     // that the x-layers of a slab are finished in order at that granularity (M2S_PEER_TRAIL)
 };
 
 // Brick shape for a cell size: minimises max/min of the world extents |size[k]| * 2^bl[k] over all splits of 6.
@@ -150,10 +151,16 @@ constexpr uint32_t MAX_PEERS = 15;
 struct PeerOut {
   float* p[MAX_PEERS];
   uint32_t n;
+  // M2S_PEER_TRAIL: the walk counts finished packets per x-unit of 2^unit_log bricks (progress[unit], device scope release)
+  // and a copy kernel that runs beside it pushes every unit to the peers as soon as it is complete
+  uint32_t unit_log;
+  uint32_t rows;       // brick rows (bricks along y) = row counters per unit
+  uint32_t units;
+  uint32_t* progress;  // [0, units): finished rows per unit;  [units + unit * rows + brick row]: finished packets of that row
 };
 
 // Device-side error flags (OR-ed into one int by kernels).
-enum : int { ERRF_INDEX_OOB = 1, ERRF_NAN = 2 };
+enum : int { ERRF_INDEX_OOB = 1, ERRF_NAN = 2, ERRF_TRAIL_TIMEOUT = 4 };
 
 // Result modes of the nearest search.
 enum : int {
@@ -240,6 +247,11 @@ int launch_grid_walk(hipStream_t st, const DeviceMesh& mesh, const GridParams& g
 // M2S_PEER_PUSH: copies the cells [first, first + count) of the whole-grid buffer `src` to the same range of every peer
 // (16 B per lane where the range allows).
 int launch_push_cells(hipStream_t st, const float* src, const PeerOut& peers, uint64_t first, uint64_t count);
+// M2S_PEER_TRAIL: bricks per progress unit (log2), number of units of the slab, and the copy kernel that trails the walk.
+uint32_t trail_unit_log(const GridParams& g);
+uint32_t trail_units(const GridParams& g);
+uint32_t trail_rows(const GridParams& g);
+int launch_push_trailing(hipStream_t st, const float* src, const PeerOut& peers, const GridParams& g, int* d_err);
 // Records `ev_before_final` (if non-null) between the seed passes and the final k_packet launch.
 int launch_grid_distance(Arena& ws, hipStream_t st, const DeviceMesh& mesh, const GridParams& g, int mode,
                          const uint32_t* d_inside_plane, int algorithm, float* d_out, int* d_err,

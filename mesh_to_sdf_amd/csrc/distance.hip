@@ -69,8 +69,8 @@ struct GridBrick {
 __host__ __device__ __forceinline__ uint32_t bricks_along(uint32_t cells, uint32_t log2_extent) {
   return (cells + (1u << log2_extent) - 1u) >> log2_extent;
 }
-__host__ __device__ __forceinline__ uint32_t super_brick_xlog(uint32_t nbx) {
-  for (uint32_t xl = 3; xl > 0; --xl) {
+__host__ __device__ __forceinline__ uint32_t super_brick_xlog(uint32_t nbx, uint32_t xl_cap = 0) {
+  for (uint32_t xl = xl_cap ? xl_cap - 1u : 3u; xl > 0; --xl) {
     const uint32_t padded = ((nbx + (1u << xl) - 1u) >> xl) << xl;
     if ((padded - nbx) * 8u <= nbx) return xl;
   }
@@ -82,7 +82,7 @@ __device__ __forceinline__ uint32_t div_magic(uint32_t n, uint32_t d, uint32_t m
 __device__ __forceinline__ void brick_coords(const GridParams& g, uint32_t brick, uint32_t* bx, uint32_t* by, uint32_t* bz) {
   const uint32_t nby = bricks_along(g.n[1], g.bl[1]), nbz = bricks_along(g.n[2], g.bl[2]);
   const uint32_t sy = (nby + 7) >> 3, sz = (nbz + 7) >> 3;
-  const uint32_t xl = super_brick_xlog(bricks_along(g.xe - g.xb, g.bl[0]));
+  const uint32_t xl = super_brick_xlog(bricks_along(g.xe - g.xb, g.bl[0]), g.xl_cap);
   const uint32_t sb = brick >> (6 + xl), in = brick & ((64u << xl) - 1u);   // super-brick index, position inside (padded grid)
   const uint32_t t = div_magic(sb, sz, g.sz_magic), sbz = sb - t * sz;
   const uint32_t sbx = div_magic(t, sy, g.sy_magic), sby = t - sbx * sy;
@@ -294,7 +294,10 @@ struct CutList {
 // ---- k_packet -------------------------------------------------------------------------------
 // `seed_in` (one TriRec slot per 2^seed_shift bricks per axis, may be null) replaces the greedy descent:
 // the packet starts from a triangle near its own centre (jump-flooding seed pass below).
-template <bool GRID, int MODE, int SIGN, bool STATS>
+// STAGE (experiment, M2S_LDS_STAGE=1): a cut range of at most STAGE_CAP bytes is copied into LDS by the whole wave (16 B per
+// lane and instruction) before it is walked, and its node records are then read from LDS instead of through the scalar cache.
+constexpr uint32_t STAGE_CAP = 3072;   // 64 node records
+template <bool GRID, int MODE, int SIGN, bool STATS, bool STAGE = false>
 __global__ __launch_bounds__(256) void k_packet(DeviceMesh mesh, GridParams g, const float4* __restrict__ qsorted,
                                                 const uint32_t* __restrict__ perm, uint32_t n_q,
                                                 const uint32_t* __restrict__ plane, float* __restrict__ out,
@@ -327,7 +330,7 @@ __global__ __launch_bounds__(256) void k_packet(DeviceMesh mesh, GridParams g, c
 
   Best<MODE> best;
   uint32_t st_box = 0, st_ext = 0, st_leaf = 0;   // wave-uniform traversal counters (SGPRs)
-  uint32_t st_pruned = 0, st_slab = 0, st_sphere = 0, st_ranges = 0, st_band = 0, st_pairs = 0;
+  uint32_t st_pruned = 0, st_slab = 0, st_sphere = 0, st_ranges = 0, st_band = 0, st_pairs = 0, st_rbytes = 0, st_rmax = 0;
   if (mesh.n_nodes) {
     const float scale = fmaxf(mesh_scale(mesh), fmaxf(fabsf(p.x), fmaxf(fabsf(p.y), fabsf(p.z))));
     const float slack = 4.0e-6f * scale + (MODE == MODE_NORMAL_FOLD ? 2.5e-6f : 0.0f);
@@ -397,9 +400,28 @@ __global__ __launch_bounds__(256) void k_packet(DeviceMesh mesh, GridParams g, c
     for (uint32_t range = 0; range < n_ranges; ++range) {
     uint32_t off = cl ? cl[1 + 2 * range] : 0u;
     const uint32_t end = cl ? cl[2 + 2 * range] : mesh.n_nodes * NB;
+    if (STATS) { st_rbytes += end - off; st_rmax = max(st_rmax, end - off); }
+    extern __shared__ float4 stage_lds[];
+    const uint32_t stage_base = off;
+    bool staged = false;
+    char* stage_bytes = nullptr;
+    if (STAGE) {
+      stage_bytes = reinterpret_cast<char*>(stage_lds) + (threadIdx.x >> 6) * STAGE_CAP;
+      const uint32_t bytes = end - off;
+      staged = bytes <= STAGE_CAP;
+      if (staged) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");          // the previous range's reads are done
+        for (uint32_t o = (uint32_t)lane * 16u; o < bytes; o += 1024u)
+          *reinterpret_cast<float4*>(stage_bytes + o) = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(mesh.ext) + off + o);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
     while (off < end) {
       off = __builtin_amdgcn_readfirstlane(off);
-      const NodeExt nr = *reinterpret_cast<const NodeExt*>(reinterpret_cast<const char*>(mesh.ext) + off);
+      NodeExt nr;
+      if (STAGE && staged) nr = *reinterpret_cast<const NodeExt*>(stage_bytes + (off - stage_base));
+      else nr = *reinterpret_cast<const NodeExt*>(reinterpret_cast<const char*>(mesh.ext) + off);
       if (STATS) ++st_box;
       const float ed2 = ext_dist2(p, nr);
       if (STATS && __ballot(!(ed2 > thr)) == 0ull) {
@@ -449,6 +471,8 @@ __global__ __launch_bounds__(256) void k_packet(DeviceMesh mesh, GridParams g, c
     atomicAdd(&q[3], 1ull);
     atomicAdd(&q[4], (unsigned long long)st_ranges);
     atomicAdd(&q[5], (unsigned long long)st_pairs);
+    atomicAdd(&q[6], (unsigned long long)st_rbytes);
+    atomicAdd(&q[7], (unsigned long long)(st_rbytes <= 4096u ? 1u : 0u));
   }
 
   bool negate = false;
@@ -463,11 +487,76 @@ __global__ __launch_bounds__(256) void k_packet(DeviceMesh mesh, GridParams g, c
   }
   if (MODE == MODE_NORMAL_FOLD && best.nan) atomicOr(err, ERRF_NAN);
   const float result = finish<MODE>(best, negate);
+  if (GRID && peers.progress != nullptr) {
+    // M2S_PEER_TRAIL: the copy kernel that trails this walk runs on other XCDs, whose L2s are separate.  The values are
+    // stored write-through at device scope (no L2 write-back fence: a release fence per wave — buffer_wbl2 — made the walk ten
+    // times slower), the wave waits until the store has been acknowledged, and only then counts the packet.
+    if (store) __hip_atomic_store(&out[out_index], result, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // one counter per (unit, brick row): thousands of device-scope atomics on ONE address serialise at the memory side
+    // and the packet that completes a row counts the row on the unit's own counter, the only address the copy kernel polls
+    if (lane == 0) {
+      const uint32_t unit = vox.bx >> peers.unit_log;
+      const uint32_t nbx = bricks_along(g.xe - g.xb, g.bl[0]), nbz = bricks_along(g.n[2], g.bl[2]);
+      const uint32_t bricks = min((unit + 1u) << peers.unit_log, nbx) - (unit << peers.unit_log);
+      const uint32_t old = __hip_atomic_fetch_add(&peers.progress[peers.units + unit * peers.rows + vox.by], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (old + 1u == bricks * nbz) __hip_atomic_fetch_add(&peers.progress[unit], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return;
+  }
   if (store) out[out_index] = result;
   // M2S_PEER_STORE: the same value into every peer's whole-grid buffer (grid path; indices are whole-grid there)
   if (GRID && peers.n != 0u && store) {
     const size_t gi = out_index + (size_t)g.out_off;
     for (uint32_t i = 0; i < peers.n; ++i) peers.p[i][gi] = result;
+  }
+}
+
+// M2S_PEER_TRAIL: pushes the slab to the peers unit by unit while the walk is still running.  Unit u = the x-layers of
+// 2^unit_log bricks; it is complete when progress[u] has reached the number of packets that lie in it.  Every workgroup waits
+// for the unit (one lane polls, s_sleep between polls), then copies its share of it with 16 B per lane to every peer.
+// A walk that never finishes (a fault on its stream) would leave this kernel spinning: after ~2 s without progress it
+// raises ERRF_TRAIL_TIMEOUT and leaves.
+__global__ __launch_bounds__(256) void k_push_trailing(const float* __restrict__ src, PeerOut peers, uint64_t slab_first, uint64_t row_cells,
+                                                       uint32_t layers, uint32_t layers_per_unit, uint32_t n_units, int* __restrict__ err) {
+  __shared__ int ok;
+  for (uint32_t u = 0; u < n_units; ++u) {
+    if (threadIdx.x == 0) {
+      int good = 1;
+      uint32_t spins = 0;
+      while (__hip_atomic_load(&peers.progress[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < peers.rows) {   // all brick rows of the unit
+        __builtin_amdgcn_s_sleep(127);
+        if (++spins > 10000000u) { good = 0; atomicOr(err, ERRF_TRAIL_TIMEOUT); break; }
+      }
+      ok = good;
+    }
+    __syncthreads();
+    if (!ok) return;
+    const uint32_t x0 = u * layers_per_unit, x1 = min(layers, x0 + layers_per_unit);
+    const uint64_t first = slab_first + (uint64_t)x0 * row_cells, count = (uint64_t)(x1 - x0) * row_cells;
+    // row_cells * 4 B and the slab start need not be 16-byte multiples: head / body / tail as in k_push_cells
+    const uint64_t head = min(count, (uint64_t)((4u - (uint32_t)(first & 3u)) & 3u));
+    const uint64_t n4 = (count - head) >> 2, tail0 = head + (n4 << 2);
+    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (uint64_t)gridDim.x * blockDim.x;
+    // the values were written by waves on other XCDs: read them past this XCD's L2 (device-scope loads; they only exist in 32 bits)
+    const float* s1 = src + first + head;
+    for (uint64_t i = tid; i < n4; i += stride) {
+      float4 v;
+      v.x = __hip_atomic_load(s1 + 4 * i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      v.y = __hip_atomic_load(s1 + 4 * i + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      v.z = __hip_atomic_load(s1 + 4 * i + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      v.w = __hip_atomic_load(s1 + 4 * i + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (uint32_t k = 0; k < peers.n; ++k) reinterpret_cast<float4*>(peers.p[k] + first + head)[i] = v;
+    }
+    if (tid < head) {
+      const float v = __hip_atomic_load(src + first + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (uint32_t k = 0; k < peers.n; ++k) peers.p[k][first + tid] = v;
+    }
+    if (tid < count - tail0) {
+      const float v = __hip_atomic_load(src + first + tail0 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (uint32_t k = 0; k < peers.n; ++k) peers.p[k][first + tail0 + tid] = v;
+    }
+    __syncthreads();                                         // `ok` is rewritten for the next unit
   }
 }
 
@@ -944,6 +1033,9 @@ void launch_packet(hipStream_t st, const DeviceMesh& mesh, const GridParams& g, 
     if (mesh.stats != nullptr)
       hipLaunchKernelGGL((k_packet<GRID, MODE, SIGN, true>), dim3(grid_blocks), dim3(64 * wpb), 0, st, mesh, g,
                          qs, perm, n_q, plane, out, err, n_packets, code, seed_in, seed_shift, seed_ny, seed_nz, seed_lattice, cut, peers);
+    else if (GRID && MODE == MODE_UNSIGNED && SIGN == SIGN_GRID_PLANE && getenv("M2S_LDS_STAGE") && atoi(getenv("M2S_LDS_STAGE")) != 0)
+      hipLaunchKernelGGL((k_packet<GRID, MODE_UNSIGNED, SIGN_GRID_PLANE, false, true>), dim3(grid_blocks), dim3(64 * wpb), wpb * STAGE_CAP, st, mesh, g,
+                         qs, perm, n_q, plane, out, err, n_packets, code, seed_in, seed_shift, seed_ny, seed_nz, seed_lattice, cut, peers);
     else
       hipLaunchKernelGGL((k_packet<GRID, MODE, SIGN, false>), dim3(grid_blocks), dim3(64 * wpb), 0, st, mesh, g,
                          qs, perm, n_q, plane, out, err, n_packets, code, seed_in, seed_shift, seed_ny, seed_nz, seed_lattice, cut, peers);
@@ -967,7 +1059,7 @@ void launch_brute(hipStream_t st, const DeviceMesh& mesh, const GridParams& g, c
 
 uint32_t host_brick_count(const GridParams& g) {   // padded to whole super-bricks
   const uint32_t nbx = bricks_along(g.xe - g.xb, g.bl[0]), nby = bricks_along(g.n[1], g.bl[1]), nbz = bricks_along(g.n[2], g.bl[2]);
-  const uint32_t xl = super_brick_xlog(nbx);
+  const uint32_t xl = super_brick_xlog(nbx, g.xl_cap);
   return ((nbx + (1u << xl) - 1u) >> xl) * ((nby + 7) >> 3) * ((nbz + 7) >> 3) * (64u << xl);
 }
 
@@ -996,7 +1088,8 @@ static size_t cut_blocks(const GridParams& g, uint32_t log) {
 
 size_t grid_distance_workspace_bytes(const GridParams& g) {
   const size_t bricks = (size_t)host_brick_count(g);
-  return bricks * 16 + bricks + 16384 + cut_blocks(g, 0) * CUT_WORDS * 4 + 1024;   // seeds + cut lists (one per brick)
+  const size_t trail_counters = (size_t)bricks_along(g.xe - g.xb, g.bl[0]) * (bricks_along(g.n[1], g.bl[1]) + 1) * 4;   // M2S_PEER_TRAIL progress
+  return bricks * 16 + bricks + 16384 + cut_blocks(g, 0) * CUT_WORDS * 4 + trail_counters + 1024;   // seeds + cut lists (one per brick)
 }
 
 __global__ __launch_bounds__(256) void k_seed_remap(uint32_t* __restrict__ ids, size_t n, const uint32_t* __restrict__ slot_of, uint32_t n_tris) {
@@ -1114,6 +1207,27 @@ int launch_push_cells(hipStream_t st, const float* src, const PeerOut& peers, ui
   const uint64_t want = (count / 4 + 255) / 256 + 1;
   const unsigned blocks = (unsigned)std::min<uint64_t>(max_blocks, want);
   hipLaunchKernelGGL(k_push_cells, dim3(blocks), dim3(256), 0, st, src, peers, first, count);
+  M2S_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+uint32_t trail_unit_log(const GridParams& g) {
+  static const uint32_t ul = getenv("M2S_TRAIL_UNIT_LOG") ? (uint32_t)std::min(3, std::max(0, atoi(getenv("M2S_TRAIL_UNIT_LOG")))) : 2u;
+  (void)g;
+  return ul;   // 4 bricks = 16 layers of a 4^3-brick grid (16 MB per peer and unit at 512^2 rows): 2-brick units stream finer but
+               // their packet order (super-bricks 2 bricks wide) costs the walk 20 % of its locality
+}
+uint32_t trail_units(const GridParams& g) {
+  const uint32_t nbx = bricks_along(g.xe - g.xb, g.bl[0]), ul = trail_unit_log(g);
+  return (nbx + (1u << ul) - 1u) >> ul;
+}
+uint32_t trail_rows(const GridParams& g) { return bricks_along(g.n[1], g.bl[1]); }
+int launch_push_trailing(hipStream_t st, const float* src, const PeerOut& peers, const GridParams& g, int* d_err) {
+  if (peers.n == 0 || g.xe <= g.xb) return 0;
+  static const unsigned blocks = getenv("M2S_PUSH_BLOCKS") ? (unsigned)std::max(1, atoi(getenv("M2S_PUSH_BLOCKS"))) : 64u;
+  const uint64_t row = (uint64_t)g.n[1] * g.n[2];
+  hipLaunchKernelGGL(k_push_trailing, dim3(blocks), dim3(256), 0, st, src, peers, (uint64_t)g.xb * row - g.out_off, row, g.xe - g.xb,
+                     (1u << g.bl[0]) << peers.unit_log, trail_units(g), d_err);
   M2S_HIP_CHECK(hipGetLastError());
   return 0;
 }

@@ -196,7 +196,7 @@ int m2s_generate_grid_sdf_multi(const float* vertices, size_t n_vertices, const 
   int exchange = opts ? opts->exchange : M2S_XCHG_AUTO;
   if (exchange < M2S_XCHG_AUTO || exchange > M2S_XCHG_NONE) return fail(M2S_ERR_BAD_ARG, "bad exchange");
   const int peer_mode = opts ? opts->peer_mode : M2S_PEER_PUSH;
-  if (peer_mode != M2S_PEER_PUSH && peer_mode != M2S_PEER_STORE) return fail(M2S_ERR_BAD_ARG, "bad peer_mode");
+  if (peer_mode < M2S_PEER_PUSH || peer_mode > M2S_PEER_TRAIL) return fail(M2S_ERR_BAD_ARG, "bad peer_mode");
   const uint64_t nx = grid->cell_count[0], row = grid->cell_count[1] * grid->cell_count[2];
   const bool empty = nx == 0 || row == 0;
   for (int k = 0; k < (mem_kind == M2S_MEM_HOST ? 1 : n); ++k)

@@ -35,7 +35,7 @@ def main():
 
     if mode == "ipc_peer":
         pg = PeerGrid(g.get_total_cell_count(), dev)
-        for pm in (PeerMode.Push, PeerMode.Store, PeerMode.Push):
+        for pm in (PeerMode.Push, PeerMode.Store, PeerMode.Trail, PeerMode.Push):
             pg.tensor.fill_(float("nan"))
             torch.cuda.synchronize()
             dist.barrier()

@@ -44,7 +44,7 @@ def test_multi_host_result_equals_single_call(sign, devices):
     assert [int(t.n_units) for t in info["timings"]] == [(b - a) * 40 * 36 for a, b in (slab_bounds(nx, len(devices), k) for k in range(len(devices)))]
 
 
-@pytest.mark.parametrize("mode", [PeerMode.Push, PeerMode.Store])
+@pytest.mark.parametrize("mode", [PeerMode.Push, PeerMode.Store, PeerMode.Trail])
 @pytest.mark.parametrize("sign", [SignMethod.Raycast, SignMethod.Normal])
 def test_multi_device_resident_peer_exchange_two_shards_one_gpu(mode, sign):
     import torch
@@ -59,6 +59,24 @@ def test_multi_device_resident_peer_exchange_two_shards_one_gpu(mode, sign):
     assert info["exchange"] == "Peer"
     for k, o in enumerate(got):     # EVERY buffer holds the whole grid
         assert torch.equal(o.view(torch.int32), want.view(torch.int32)), f"buffer {k}"
+
+
+@pytest.mark.parametrize("sign", [SignMethod.Raycast, SignMethod.Normal])
+def test_multi_peer_trailing_push_large_slab(sign):
+    """M2S_PEER_TRAIL on slabs large enough for cut lists and many progress units, with an x extent that is not a multiple of
+    the unit (ragged last unit) and y/z extents that are not multiples of the brick."""
+    import torch
+
+    v, idx = meshes.named("blob-100k")
+    lo, hi = meshes.extended_bbox(v, 0.1)
+    g = Grid.from_bounding_box(lo, hi, [270, 250, 254])
+    dv, di = _device_inputs(v, idx)
+    want = generate_grid_sdf(dv, Topology.TriangleList(di), g, sign)
+    info = {}
+    outs = generate_grid_sdf_multi(dv, Topology.TriangleList(di), g, sign, devices=[0, 0], exchange=Exchange.Peer, peer_mode=PeerMode.Trail, info=info)
+    assert [int(t.distance_launches) for t in info["timings"]] == [1, 1]
+    for o in outs:
+        assert torch.equal(o.view(torch.int32), want.view(torch.int32))
 
 
 def test_multi_peer_push_large_slab_in_pieces():

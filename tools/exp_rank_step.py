@@ -23,7 +23,7 @@ def main():
     ap.add_argument("--grid", type=int, default=512)
     ap.add_argument("--mesh", default="blob-100k")
     ap.add_argument("--sign", default="Raycast")
-    ap.add_argument("--modes", default="push,store,none")
+    ap.add_argument("--modes", default="none,trail,push,store")
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--ranks", default="")
     args = ap.parse_args()
@@ -62,7 +62,7 @@ def main():
             worst = 0.0
             for r in ranks:
                 xs = slab_bounds(n, world, r)
-                kw = {} if mode == "none" else {"peer_out": peers, "peer_mode": PeerMode.Push if mode == "push" else PeerMode.Store}
+                kw = {} if mode == "none" else {"peer_out": peers, "peer_mode": {"push": PeerMode.Push, "store": PeerMode.Store, "trail": PeerMode.Trail}[mode]}
                 t = M2STimings()
                 med, mn = timed(lambda: generate_grid_sdf(dv, topo, grid, sign, x_slab=xs, out=out, timings=t, **kw))
                 worst = max(worst, med)
