@@ -233,6 +233,7 @@ struct SeedLattice {
   uint32_t* ids = nullptr;
   uint32_t ny = 0, nz = 0;
   size_t points = 0;
+  uint32_t shift = 0;   // 2^shift packet bricks per axis share one lattice point
 };
 bool grid_walk_wants_seeds(const GridParams& g, size_t n_tris, int algorithm);
 uint32_t host_packet_bricks(const GridParams& g);   // packet bricks of the slab (= points of its seed lattice), padded to super-bricks

@@ -591,8 +591,8 @@ __global__ __launch_bounds__(256) void k_push_cells(const float* __restrict__ sr
 template <int MODE, int SIGN>
 __global__ __launch_bounds__(256) void k_lane(DeviceMesh mesh, GridParams g, const uint32_t* __restrict__ plane,
                                               float* __restrict__ out, int* __restrict__ err, uint32_t n_packets,
-                                              const uint32_t* __restrict__ seed_in, uint32_t seed_ny, uint32_t seed_nz, uint32_t bx_off,
-                                              PeerOut peers) {
+                                              const uint32_t* __restrict__ seed_in, uint32_t seed_shift, uint32_t seed_ny, uint32_t seed_nz,
+                                              uint32_t bx_off, PeerOut peers) {
   const int lane = threadIdx.x & 63;
   const uint32_t packet = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (packet >= n_packets) return;
@@ -606,7 +606,8 @@ __global__ __launch_bounds__(256) void k_lane(DeviceMesh mesh, GridParams g, con
     const float scale = fmaxf(mesh_scale(mesh), fmaxf(fabsf(p.x), fmaxf(fabsf(p.y), fabsf(p.z))));
     const float slack = 4.0e-6f * scale + (MODE == MODE_NORMAL_FOLD ? 2.5e-6f : 0.0f);
     uint32_t slot = 0;
-    if (seed_in != nullptr) slot = min(seed_in[((vox.bx + bx_off) * seed_ny + vox.by) * seed_nz + vox.bz], mesh.n_tris - 1);
+    if (seed_in != nullptr)
+      slot = min(seed_in[(((vox.bx + bx_off) >> seed_shift) * seed_ny + (vox.by >> seed_shift)) * seed_nz + (vox.bz >> seed_shift)], mesh.n_tris - 1);
     eval_triangle<MODE>(best, p, mesh.tris[slot]);
     float thr = prune_bound(best.d2, slack);
     constexpr uint32_t NB = (uint32_t)sizeof(NodeExt);
@@ -740,7 +741,7 @@ __global__ __launch_bounds__(256) void k_jfa_pass(DeviceMesh mesh, GridParams g0
 // Earlier versions (512^3 x blob-100k / the 64-layer slab of an 8-GPU rank; lists per block of 2 x 2 x 2 bricks, sphere
 // test): one lane per block, per-lane record fetches: 0.27 / 0.24 ms; eight lanes per block: 0.40 / 0.15 ms; one wave per
 // eight blocks with scalar record loads: 0.22 / 0.07 ms.
-__global__ __launch_bounds__(64) void k_cut(DeviceMesh mesh, GridParams g, const uint32_t* __restrict__ seeds,
+__global__ __launch_bounds__(64) void k_cut(DeviceMesh mesh, GridParams g, const uint32_t* __restrict__ seeds, uint32_t seed_shift,
                                             uint32_t seed_ny, uint32_t seed_nz, uint32_t nbx, uint32_t nby, uint32_t nbz,
                                             uint32_t* __restrict__ lists, float emit_near, float emit_far, uint32_t budget) {
   const uint32_t nsy = (nby + 3u) >> 2, nsz = (nbz + 3u) >> 2;
@@ -764,7 +765,7 @@ __global__ __launch_bounds__(64) void k_cut(DeviceMesh mesh, GridParams g, const
   f3 e = mk3(0.0f, 0.0f, 0.0f);
   float grad_c0 = __builtin_inff(), grad_c1 = 0.0f;          // gradient test: drop if L * (1 - 1e-4) - grad_c0 > grad_c1 * |n - e|
   if (in_grid) {
-    const uint32_t slot = min(seeds[(bk[0] * seed_ny + bk[1]) * seed_nz + bk[2]], mesh.n_tris - 1);
+    const uint32_t slot = min(seeds[((bk[0] >> seed_shift) * seed_ny + (bk[1] >> seed_shift)) * seed_nz + (bk[2] >> seed_shift)], mesh.n_tris - 1);
     const TriRec& t = mesh.tris[slot];
     const f3 a = mk3(t.ax, t.ay, t.az), bq = mk3(t.bx, t.by, t.bz), c = mk3(t.cx, t.cy, t.cz);
     const TriEdges ed = {mk3(t.abx, t.aby, t.abz), mk3(t.acx, t.acy, t.acz), mk3(t.bcx, t.bcy, t.bcz)};
@@ -1114,7 +1115,10 @@ int launch_grid_seeds(Arena& ws, hipStream_t st, const float4* cen, uint32_t n_t
   DeviceMesh mesh{};
   mesh.cen = cen;
   mesh.n_tris = n_tris;
-  const GridParams g1 = coarse_level(g, g.bl, g.xb);   // one lattice point per packet brick, at its centre
+  // one lattice point per 2^shift packet bricks per axis, at the centre of that block of bricks (M2S_SEED_SHIFT, default 0)
+  static const uint32_t seed_shift = getenv("M2S_SEED_SHIFT") ? (uint32_t)std::min(3, std::max(0, atoi(getenv("M2S_SEED_SHIFT")))) : 0u;
+  const uint32_t stride_log[3] = {g.bl[0] + seed_shift, g.bl[1] + seed_shift, g.bl[2] + seed_shift};
+  const GridParams g1 = coarse_level(g, stride_log, g.xb);
   const size_t points1 = (size_t)g1.n[0] * g1.n[1] * g1.n[2];
   uint32_t* s1 = ws.take<uint32_t>(points1);
   uint32_t* s1b = ws.take<uint32_t>(points1);
@@ -1139,6 +1143,7 @@ int launch_grid_seeds(Arena& ws, hipStream_t st, const float4* cen, uint32_t n_t
   out->ny = g1.n[1];
   out->nz = g1.n[2];
   out->points = points1;
+  out->shift = seed_shift;
   return 0;
 }
 
@@ -1165,6 +1170,7 @@ int prepare_grid_walk(Arena& ws, hipStream_t st, const DeviceMesh& mesh, const G
     seed1 = lat.ids;
     s1ny = lat.ny;
     s1nz = lat.nz;
+    sh1 = lat.shift;
   }
   // Walk flavour: bricks that each meet MANY triangles (triangles much smaller than voxels) are better served by
   // independent per-lane walks.  Estimate: triangles per surface brick ~ T / (6 * bricks^(2/3)).
@@ -1180,7 +1186,7 @@ int prepare_grid_walk(Arena& ws, hipStream_t st, const DeviceMesh& mesh, const G
   // piece's walk and pays from about half that size)
   const uint32_t cut_min_packets = getenv("M2S_CUT_MIN_PACKETS") ? (uint32_t)atoi(getenv("M2S_CUT_MIN_PACKETS")) : (pipelined ? 100000u : 200000u);
   static const int cut_env = getenv("M2S_CUT") ? atoi(getenv("M2S_CUT")) : 1;   // 0 = off
-  if (!brute && !lane_walk && seed1 != nullptr && sh1 == 0 && cut_env > 0 && packets >= cut_min_packets) {
+  if (!brute && !lane_walk && seed1 != nullptr && cut_env > 0 && packets >= cut_min_packets) {
     // emission radius of a list entry: emit_near brick radii next to the surface, emit_far of the distance far from it
     const float emit_near = getenv("M2S_CUT_NEAR") ? (float)atof(getenv("M2S_CUT_NEAR")) : 2.0f;
     const float emit_far = getenv("M2S_CUT_FAR") ? (float)atof(getenv("M2S_CUT_FAR")) : 1.0f / 16.0f;
@@ -1190,7 +1196,7 @@ int prepare_grid_walk(Arena& ws, hipStream_t st, const DeviceMesh& mesh, const G
     uint32_t* lists = ws.take<uint32_t>(bricks * CUT_WORDS);
     if (!lists) { set_error("internal: cut-list workspace too small"); return M2S_ERR_HIP_INTERNAL; }
     const size_t waves = (size_t)bricks_along(nbx, 2) * bricks_along(nby, 2) * bricks_along(nbz, 2);
-    hipLaunchKernelGGL(k_cut, dim3((unsigned)waves), dim3(64), 0, st, mesh, g, seed1, s1ny, s1nz, nbx, nby, nbz, lists, emit_near, emit_far, budget);
+    hipLaunchKernelGGL(k_cut, dim3((unsigned)waves), dim3(64), 0, st, mesh, g, seed1, sh1, s1ny, s1nz, nbx, nby, nbz, lists, emit_near, emit_far, budget);
     cut = {lists, 0, nby, nbz, 0};
   }
   plan->seeds = seed1; plan->seed_shift = sh1; plan->seed_ny = s1ny; plan->seed_nz = s1nz;
@@ -1245,11 +1251,11 @@ int launch_grid_walk(hipStream_t st, const DeviceMesh& mesh, const GridParams& g
   if (plan.lane_walk) {
     const unsigned blocks = (packets + 3) / 4;
     if (mode == MODE_UNSIGNED && d_inside_plane)
-      hipLaunchKernelGGL((k_lane<MODE_UNSIGNED, SIGN_GRID_PLANE>), dim3(blocks), dim3(256), 0, st, mesh, g, d_inside_plane, d_out, d_err, packets, seed1, s1ny, s1nz, bx_off, pz);
+      hipLaunchKernelGGL((k_lane<MODE_UNSIGNED, SIGN_GRID_PLANE>), dim3(blocks), dim3(256), 0, st, mesh, g, d_inside_plane, d_out, d_err, packets, seed1, sh1, s1ny, s1nz, bx_off, pz);
     else if (mode == MODE_UNSIGNED)
-      hipLaunchKernelGGL((k_lane<MODE_UNSIGNED, SIGN_NONE>), dim3(blocks), dim3(256), 0, st, mesh, g, nullptr, d_out, d_err, packets, seed1, s1ny, s1nz, bx_off, pz);
+      hipLaunchKernelGGL((k_lane<MODE_UNSIGNED, SIGN_NONE>), dim3(blocks), dim3(256), 0, st, mesh, g, nullptr, d_out, d_err, packets, seed1, sh1, s1ny, s1nz, bx_off, pz);
     else
-      hipLaunchKernelGGL((k_lane<MODE_NORMAL_FOLD, SIGN_NONE>), dim3(blocks), dim3(256), 0, st, mesh, g, nullptr, d_out, d_err, packets, seed1, s1ny, s1nz, bx_off, pz);
+      hipLaunchKernelGGL((k_lane<MODE_NORMAL_FOLD, SIGN_NONE>), dim3(blocks), dim3(256), 0, st, mesh, g, nullptr, d_out, d_err, packets, seed1, sh1, s1ny, s1nz, bx_off, pz);
     M2S_HIP_CHECK(hipGetLastError());
     return 0;
   }
