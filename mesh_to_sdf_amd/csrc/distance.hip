@@ -743,7 +743,7 @@ __global__ __launch_bounds__(256) void k_jfa_pass(DeviceMesh mesh, GridParams g0
 // eight blocks with scalar record loads: 0.22 / 0.07 ms.
 __global__ __launch_bounds__(64) void k_cut(DeviceMesh mesh, GridParams g, const uint32_t* __restrict__ seeds, uint32_t seed_shift,
                                             uint32_t seed_ny, uint32_t seed_nz, uint32_t nbx, uint32_t nby, uint32_t nbz,
-                                            uint32_t* __restrict__ lists, float emit_near, float emit_far, uint32_t budget) {
+                                            uint32_t* __restrict__ lists, float emit_near, float emit_far, uint32_t budget, uint32_t wave_cap) {
   const uint32_t nsy = (nby + 3u) >> 2, nsz = (nbz + 3u) >> 2;
   const uint32_t sb = blockIdx.x;                            // 4 x 4 x 4 bricks
   const uint32_t sz = sb % nsz, sy = (sb / nsz) % nsy, sx = sb / (nsz * nsy);
@@ -789,9 +789,10 @@ __global__ __launch_bounds__(64) void k_cut(DeviceMesh mesh, GridParams g, const
   const uint32_t end = mesh.n_nodes * NB;
   uint32_t* out = lists + ((size_t)(in_grid ? (bk[0] * nby + bk[1]) * nbz + bk[2] : 0u)) * CUT_WORDS;
   uint32_t n = 0, last_start = 0, last_end = 0, resume = 0, opened = 0;   // per lane
-  uint32_t off = 0;                                           // wave-uniform
+  uint32_t off = 0, steps = 0;                                // wave-uniform
   while (off < end) {
     off = __builtin_amdgcn_readfirstlane(off);
+    ++steps;
     const NodeExt nr = *reinterpret_cast<const NodeExt*>(reinterpret_cast<const char*>(mesh.ext) + off);
     const bool active = off >= resume;                        // this brick has not dropped / emitted an ancestor
     // closest point of the disc-slab to q:  q - c = ax * n_s + lat * l / |l|   (common.h NodeExt, ext_dist2)
@@ -826,7 +827,7 @@ __global__ __launch_bounds__(64) void k_cut(DeviceMesh mesh, GridParams g, const
     // test keeps a large part of the tree however far it descends: a brick that has already opened `budget` nodes emits what
     // it meets next as it is and leaves the rest to the packet's per-voxel tests (which are 200 times sharper there).
     // (a saturated list — CUT_MAX ranges — only grows its last range over every gap from here on: nothing finer can be said)
-    const bool emit = keep & (nr.tri >= 0 || fmaxf(nr.R, nr.half) <= emit_radius || opened >= budget || n == CUT_MAX);
+    const bool emit = keep & (nr.tri >= 0 || fmaxf(nr.R, nr.half) <= emit_radius || opened >= budget || n == CUT_MAX || steps >= wave_cap);
     if (emit) {
       // keep this subtree: [off, skip).  Adjacent subtrees merge; past CUT_MAX ranges the last one grows over the gap
       if (n > 0 && (last_end == off || n == CUT_MAX)) last_end = nr.skip;
@@ -1190,13 +1191,20 @@ int prepare_grid_walk(Arena& ws, hipStream_t st, const DeviceMesh& mesh, const G
     // emission radius of a list entry: emit_near brick radii next to the surface, emit_far of the distance far from it
     const float emit_near = getenv("M2S_CUT_NEAR") ? (float)atof(getenv("M2S_CUT_NEAR")) : 2.0f;
     const float emit_far = getenv("M2S_CUT_FAR") ? (float)atof(getenv("M2S_CUT_FAR")) : 1.0f / 16.0f;
+    // A wave that has visited this many nodes lets its bricks emit whatever they meet next: the long union walks of the
+    // regions with many near-ties (deep inside a round body) are the tail of the launch — on the 64-layer slab of an 8-GPU
+    // rank, 4 waves per SIMD, they WERE its duration (0.39 -> 0.19 ms; 512^3: flat between 300 and 450, 200 costs the
+    // packets 0.5 ms) — and what they still decide so deep in the tree the packets decide almost as cheaply.
+    uint32_t depth = 1;
+    while ((1ull << depth) < (unsigned long long)mesh.n_tris + 1ull) ++depth;
+    const uint32_t wave_cap = getenv("M2S_CUT_WAVE_CAP") ? (uint32_t)atoi(getenv("M2S_CUT_WAVE_CAP")) : std::max(120u, 20u * depth);
     const uint32_t budget = getenv("M2S_CUT_BUDGET") ? (uint32_t)atoi(getenv("M2S_CUT_BUDGET")) : 100000u;
     const uint32_t nbx = bricks_along(g.xe - g.xb, g.bl[0]), nby = bricks_along(g.n[1], g.bl[1]), nbz = bricks_along(g.n[2], g.bl[2]);
     const size_t bricks = (size_t)nbx * nby * nbz;
     uint32_t* lists = ws.take<uint32_t>(bricks * CUT_WORDS);
     if (!lists) { set_error("internal: cut-list workspace too small"); return M2S_ERR_HIP_INTERNAL; }
     const size_t waves = (size_t)bricks_along(nbx, 2) * bricks_along(nby, 2) * bricks_along(nbz, 2);
-    hipLaunchKernelGGL(k_cut, dim3((unsigned)waves), dim3(64), 0, st, mesh, g, seed1, sh1, s1ny, s1nz, nbx, nby, nbz, lists, emit_near, emit_far, budget);
+    hipLaunchKernelGGL(k_cut, dim3((unsigned)waves), dim3(64), 0, st, mesh, g, seed1, sh1, s1ny, s1nz, nbx, nby, nbz, lists, emit_near, emit_far, budget, wave_cap);
     cut = {lists, 0, nby, nbz, 0};
   }
   plan->seeds = seed1; plan->seed_shift = sh1; plan->seed_ny = s1ny; plan->seed_nz = s1nz;
