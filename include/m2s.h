@@ -134,7 +134,11 @@ typedef struct m2s_opts {
                                 2 = M2S_PEER_TRAIL, one walk over the whole slab whose packets count themselves per unit of 8
                                     x-layers, and a copy kernel beside it that pushes every unit (1 KiB per wave store) as soon as
                                     it is complete: no pieces, and only the last unit's push is exposed */
-  int32_t reserved2;
+  uint32_t x_period;    /* grid path, device memory; 0 = [x_begin, x_end) is one contiguous slab.  Otherwise the call owns the CHUNKS
+                           [x_begin + j * x_period, x_end + j * x_period), j = 0, 1, ... up to the end of the grid: interleaved slabs.
+                           Shards that take the chunks r and N + r of 2N balance far better than N contiguous slabs when the
+                           cost of a layer varies along x (the deep interior of a body is the expensive part).  x_end - x_begin must
+                           be a power of two and a multiple of 4 packet bricks (16 layers for cubic cells), x_period a multiple of it */
 } m2s_opts;
 #define M2S_OPTS_V1_SIZE 56
 #define M2S_MAX_LANES 16
@@ -185,12 +189,24 @@ typedef struct m2s_multi_opts {
   m2s_timings* timings;     /* optional, n_devices entries: per-shard phase timings */
   float* wall_ms;           /* optional: host wall time of the whole call */
   int32_t* exchange_used;   /* optional: the exchange that ran (M2S_XCHG_PEER / RCCL / NONE) */
+  /* ---- fields below exist when struct_size >= sizeof(m2s_multi_opts) of version 0.2 final (M2S_MULTI_OPTS_V1_SIZE = without) ---- */
+  int32_t partition;        /* enum m2s_partition */
+  int32_t reserved;
 } m2s_multi_opts;
+#define M2S_MULTI_OPTS_V1_SIZE 56
+/* How the grid is cut.  CONTIGUOUS: shard k computes one x-slab.  INTERLEAVED: shard k computes the chunks k and n + k of 2n
+ * (m2s_interleaved_slab): the cost of a layer varies along x — the deep interior of a body is the expensive part — and
+ * contiguous slabs leave the middle shards with 30 % more work than the outer ones.  AUTO: interleaved for device-resident
+ * results where the grid allows it, contiguous otherwise (host results stream out slab by slab). */
+enum m2s_partition { M2S_PART_AUTO = 0, M2S_PART_CONTIGUOUS = 1, M2S_PART_INTERLEAVED = 2 };
 int m2s_generate_grid_sdf_multi(const float* vertices, size_t n_vertices, const void* indices, size_t n_indices,
                                 int index_bytes, int topology, const m2s_grid* grid, int sign_method, float* const* outs,
                                 const m2s_multi_opts* opts);
 /* x-slab [*x_begin, *x_end) of shard `k` out of `n` for a grid with `nx` layers (sizes differ by at most one layer). */
 void m2s_slab_bounds(uint64_t nx, int n, int k, uint64_t* x_begin, uint64_t* x_end);
+/* The balanced partition: shard k takes the chunks k and n + k of 2n (m2s_opts.x_begin / x_end / x_period) when the grid allows
+ * it — returns 1 — else its contiguous slab with *x_period = 0 — returns 0. */
+int m2s_interleaved_slab(const m2s_grid* grid, int n, int k, uint64_t* x_begin, uint64_t* x_end, uint64_t* x_period);
 
 /* One process per GPU (torch.distributed / MPI launchers): the same no-collective exchange across processes.
  * Every rank allocates its whole-grid buffer with m2s_shared_alloc (a dedicated hipMalloc block, so that its IPC handle

@@ -53,7 +53,7 @@ class M2SOpts(C.Structure):
         ("n_peer_out", C.c_uint32),
         ("peer_out", C.POINTER(C.c_void_p)),
         ("peer_mode", C.c_int32),
-        ("reserved2", C.c_int32),
+        ("x_period", C.c_uint32),
     ]
 
 
@@ -76,7 +76,12 @@ class M2SMultiOpts(C.Structure):
         ("timings", C.POINTER(M2STimings)),
         ("wall_ms", C.POINTER(C.c_float)),
         ("exchange_used", C.POINTER(C.c_int32)),
+        ("partition", C.c_int32),
+        ("reserved", C.c_int32),
     ]
+
+
+PART_AUTO, PART_CONTIGUOUS, PART_INTERLEAVED = 0, 1, 2
 
 
 class M2SSdfInfo(C.Structure):
@@ -142,6 +147,7 @@ EXPORTS = [
     "m2s_gltf_close",
     "m2s_generate_grid_sdf_multi",
     "m2s_slab_bounds",
+    "m2s_interleaved_slab",
     "m2s_shared_alloc",
     "m2s_shared_free",
     "m2s_ipc_export",
@@ -248,6 +254,8 @@ def lib():
                                                   C.POINTER(M2SGrid), C.c_int, C.POINTER(C.c_void_p), C.POINTER(M2SMultiOpts)]
         L.m2s_slab_bounds.restype = None
         L.m2s_slab_bounds.argtypes = [C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.m2s_interleaved_slab.restype = C.c_int
+        L.m2s_interleaved_slab.argtypes = [C.POINTER(M2SGrid), C.c_int, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.m2s_shared_alloc.restype = C.c_int
         L.m2s_shared_alloc.argtypes = [C.c_size_t, C.c_int, C.POINTER(C.c_void_p)]
         L.m2s_shared_free.restype = C.c_int

@@ -221,11 +221,12 @@ class _Args:
                 self.keep.append(q)
         self.topology = topology.kind
 
-    def opts(self, timings=None, algorithm=0, x_begin=0, x_end=0, synchronous=True, peer_out=None, peer_mode=0, lane=0):
+    def opts(self, timings=None, algorithm=0, x_begin=0, x_end=0, synchronous=True, peer_out=None, peer_mode=0, lane=0, x_period=0):
         o = M2SOpts()
         o.struct_size = C.sizeof(M2SOpts)
         o.algorithm = int(algorithm)
         o.x_begin, o.x_end = int(x_begin), int(x_end)
+        o.x_period = int(x_period)
         o.synchronous = 1 if synchronous else 0
         o.lane = int(lane)
         if peer_out:
@@ -283,6 +284,13 @@ class PeerMode(enum.IntEnum):
     Trail = 2   # one walk; a copy kernel beside it pushes each unit of 8 x-layers as soon as the walk has finished it
 
 
+class Partition(enum.IntEnum):
+    """include/m2s.h `m2s_partition`."""
+    Auto = 0
+    Contiguous = 1
+    Interleaved = 2
+
+
 class Exchange(enum.IntEnum):
     """include/m2s.h `m2s_exchange` (device-resident results of generate_grid_sdf_multi)."""
     Auto = 0
@@ -293,10 +301,12 @@ class Exchange(enum.IntEnum):
 
 def generate_grid_sdf(vertices, indices: Topology, grid: Grid, sign_method: SignMethod = SignMethod.Raycast, *,
                       timings: M2STimings = None, algorithm: int = 0, x_slab: Sequence[int] = None, out=None,
-                      peer_out=None, peer_mode: PeerMode = PeerMode.Push, lane: int = 0, synchronous: bool = True):
+                      peer_out=None, peer_mode: PeerMode = PeerMode.Push, lane: int = 0, synchronous: bool = True,
+                      x_period: int = 0):
     """generate/grid.rs:265-378.  `x_slab=(x0, x1)` computes only cells with x0 <= x < x1 (the rest
-    of `out` is left untouched); used by the multi-GPU driver in distributed.py.  `peer_out`: whole-grid device
-    buffers (tensors or raw pointers, usually on other GPUs) that receive the same slab (m2s_opts.peer_out)."""
+    of `out` is left untouched); used by the multi-GPU driver in distributed.py.  With `x_period` > 0 the call owns the
+    interleaved chunks [x0 + j * x_period, x1 + j * x_period), j = 0, 1, ... (m2s_opts.x_period).  `peer_out`: whole-grid
+    device buffers (tensors or raw pointers, usually on other GPUs) that receive the same cells (m2s_opts.peer_out)."""
     a = _Args(vertices, indices)
     total = grid.get_total_cell_count()
     if out is None:
@@ -313,12 +323,20 @@ def generate_grid_sdf(vertices, indices: Topology, grid: Grid, sign_method: Sign
     xb, xe = (0, 0) if x_slab is None else (int(x_slab[0]), int(x_slab[1]))
     if x_slab is not None and xb == xe:
         return out
-    o = a.opts(timings, algorithm, xb, xe, synchronous or not a.device, peer_out, peer_mode, lane)
+    o = a.opts(timings, algorithm, xb, xe, synchronous or not a.device, peer_out, peer_mode, lane, x_period)
     rc = _lib.lib().m2s_generate_grid_sdf(a.p_verts, a.n_verts, a.p_idx, a.n_idx, a.index_bytes, a.topology,
                                           C.byref(grid._g), int(sign_method), p_out, C.byref(o))
     if rc != _lib.M2S_OK:
         _raise(rc)
     return out
+
+
+def interleaved_slab(grid: "Grid", n: int, k: int):
+    """m2s_interleaved_slab: (x0, x1, x_period) of shard k of n — the chunks k and n + k of 2n where the grid allows it
+    (x_period > 0), else the contiguous slab with x_period = 0."""
+    a, b, p = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+    _lib.lib().m2s_interleaved_slab(C.byref(grid._g), int(n), int(k), C.byref(a), C.byref(b), C.byref(p))
+    return int(a.value), int(b.value), int(p.value)
 
 
 def slab_bounds(nx: int, n: int, k: int):
@@ -330,7 +348,8 @@ def slab_bounds(nx: int, n: int, k: int):
 
 def generate_grid_sdf_multi(vertices, indices: Topology, grid: Grid, sign_method: SignMethod = SignMethod.Raycast, *,
                             devices: Sequence[int] = None, outs=None, exchange: Exchange = Exchange.Auto,
-                            peer_mode: PeerMode = PeerMode.Push, algorithm: int = 0, info: dict = None):
+                            peer_mode: PeerMode = PeerMode.Push, algorithm: int = 0, info: dict = None,
+                            partition: Partition = Partition.Auto):
     """generate_grid_sdf over several GPUs from this one process (m2s_generate_grid_sdf_multi): one host thread per
     device inside the library, contiguous x-slabs, no data-path collective.
 
@@ -353,6 +372,7 @@ def generate_grid_sdf_multi(vertices, indices: Topology, grid: Grid, sign_method
     mo.exchange = int(exchange)
     mo.peer_mode = int(peer_mode)
     mo.algorithm = int(algorithm)
+    mo.partition = int(partition)
     tims = (M2STimings * max(n, 1))()
     mo.timings = C.cast(tims, C.POINTER(M2STimings))
     wall, used = C.c_float(0.0), C.c_int32(-1)

@@ -271,6 +271,16 @@ int finish_call(const CallCtx& c, DeviceState& st, int* d_err, m2s_timings* t, s
 
 // Seed passes + dominant launch (+ optional M2S_STATS counters); records ev[4] before and ev[3] after
 // the dominant launch.
+// Real x-ranges [first, first + count) layers of the slab's chunks (one for a contiguous slab).
+static std::vector<std::pair<uint32_t, uint32_t>> slab_chunks(const GridParams& g) {
+  std::vector<std::pair<uint32_t, uint32_t>> r;
+  const uint32_t layers = g.xe - g.xb;
+  if (g.chunk_log >= 31u) { r.emplace_back(g.xb, layers); return r; }
+  const uint32_t C = 1u << g.chunk_log;
+  for (uint32_t v = 0; v < layers; v += C) r.emplace_back(slab_x(g, v), std::min(C, layers - v));
+  return r;
+}
+
 // M2S_STATS: traversal counters of the packet walk (a counting variant of k_packet), printed on stderr.
 static int stats_begin(Arena& ws, hipStream_t stream, DeviceMesh* mesh, unsigned long long** d_stats) {
   *d_stats = nullptr;
@@ -332,11 +342,14 @@ int run_grid_distance_push(Arena& ws, const CallCtx& c, DeviceState& st, const D
   static const uint32_t want_pieces = getenv("M2S_PUSH_PIECES") ? (uint32_t)std::max(1, atoi(getenv("M2S_PUSH_PIECES"))) : 4u;
   const uint64_t bx = 2ull << g.bl[0];                              // whole cut-list blocks (2 bricks) along x
   uint64_t lpp = (layers + want_pieces - 1) / want_pieces;
+  if (g.chunk_log < 31u) lpp = 1ull << g.chunk_log;                // interleaved slab: a piece = a chunk (contiguous in the grid)
   lpp = std::max<uint64_t>(bx, (lpp + bx - 1) / bx * bx);
   // thin pieces walk badly (one launch per piece, each ending in a partly filled tail; 512^3 x blob-100k cut into pieces of
   // 64 / 32 / 16 layers: 10.9 / 11.6 / 16.1 ms of walks in total): at least 8 bricks of layers per piece
-  lpp = std::max<uint64_t>(lpp, 8ull << g.bl[0]);
-  if ((uint64_t)layers * row * 4 < (8u << 20)) lpp = std::max<uint64_t>(lpp, layers);   // small slabs: one piece
+  if (g.chunk_log >= 31u) {
+    lpp = std::max<uint64_t>(lpp, 8ull << g.bl[0]);
+    if ((uint64_t)layers * row * 4 < (8u << 20)) lpp = std::max<uint64_t>(lpp, layers);   // small slabs: one piece
+  }
   const uint32_t pieces = (uint32_t)((layers + lpp - 1) / lpp);
   *pieces_out = pieces;
   if (!st.copy_stream) M2S_HIP_CHECK(hipStreamCreateWithFlags(&st.copy_stream, hipStreamNonBlocking));
@@ -355,8 +368,10 @@ int run_grid_distance_push(Arena& ws, const CallCtx& c, DeviceState& st, const D
   M2S_HIP_CHECK(hipEventRecord(st.ev[4], c.stream));
   for (uint32_t i = 0; i < pieces; ++i) {
     GridParams gp = g;
-    gp.xb = g.xb + (uint32_t)(i * lpp);
-    gp.xe = (uint32_t)std::min<uint64_t>(g.xe, gp.xb + lpp);
+    gp.xb = slab_x(g, (uint32_t)(i * lpp));                          // a piece is contiguous in the grid
+    gp.xe = gp.xb + (uint32_t)std::min<uint64_t>(lpp, layers - i * lpp);
+    gp.chunk_log = 31;
+    gp.period = 0;
     rc = launch_grid_walk(c.stream, mesh, gp, mode, plane, c.algorithm, plan, (uint32_t)((i * lpp) >> g.bl[0]), d_out, d_err);
     if (rc) return rc;
     if (i + 1 == pieces) M2S_HIP_CHECK(hipEventRecord(st.ev[3], c.stream));
@@ -394,7 +409,7 @@ int run_grid_distance_trail(Arena& ws, const CallCtx& c, DeviceState& st, const 
   st.have_raw_seeds = false;
   if (rc) return rc;
   const uint64_t row = (uint64_t)g.n[1] * g.n[2];
-  const bool trailing = !plan.lane_walk && c.algorithm == 0 && mesh.n_nodes != 0;   // k_packet counts its packets; the other walks do not
+  const bool trailing = !plan.lane_walk && c.algorithm == 0 && mesh.n_nodes != 0 && g.chunk_log >= 31u;   // k_packet counts its packets; the other walks do not
   PeerOut walk_peers{};
   if (trailing) {
     const size_t counters = (size_t)trail_units(g) * (trail_rows(g) + 1u);
@@ -422,7 +437,10 @@ int run_grid_distance_trail(Arena& ws, const CallCtx& c, DeviceState& st, const 
     if (!(dbg & 1)) rc = launch_push_trailing(st.copy_stream, d_out, push, g, d_err);
   } else {
     M2S_HIP_CHECK(hipStreamWaitEvent(st.copy_stream, st.ev[3], 0));
-    rc = launch_push_cells(st.copy_stream, d_out, c.peers, (uint64_t)g.xb * row - g.out_off, (uint64_t)(g.xe - g.xb) * row);
+    for (const auto& ch : slab_chunks(g)) {
+      rc = launch_push_cells(st.copy_stream, d_out, c.peers, (uint64_t)ch.first * row - g.out_off, (uint64_t)ch.second * row);
+      if (rc) return rc;
+    }
   }
   if (rc) return rc;
   M2S_HIP_CHECK(hipEventRecord(st.piece_events[1], st.copy_stream));
@@ -468,13 +486,37 @@ int fill_grid_params(const m2s_grid* grid, const m2s_opts* opts, GridParams* g, 
   g->nzw = (uint32_t)((gz + 31) / 32);
   g->out_off = 0;
   g->xl_cap = 0;
+  g->chunk_log = 31;
+  g->period = 0;
   static const bool cube_only = getenv("M2S_BRICK_CUBE") && atoi(getenv("M2S_BRICK_CUBE")) != 0;
   if (cube_only) g->bl[0] = g->bl[1] = g->bl[2] = 2;
   else choose_brick_shape(g->size, g->bl);
+  uint64_t layers = xe - xb;
+  const uint64_t period = (opts && opts->struct_size >= sizeof(m2s_opts)) ? opts->x_period : 0;
+  if (period != 0 && layers != 0) {
+    // interleaved slab: chunks [xb + j * period, + C), C = x_end - x_begin a power of two that holds whole cut-list waves
+    // (4 bricks along x), every chunk inside the grid; the virtual slab is the chunks laid end to end
+    const uint64_t C = layers, brick_layers = 1ull << g->bl[0];    // a packet brick must not straddle two chunks
+    uint32_t clog = 0;
+    while ((1ull << clog) < C) ++clog;
+    if ((1ull << clog) != C || C % brick_layers != 0 || period % C != 0 || period < C || period >= (1ull << 31))
+      return fail(M2S_ERR_BAD_ARG, "x_period %llu with a chunk of %llu layers: the chunk must be a power of two and a multiple of the packet brick (%llu layers), the period a multiple of the chunk",
+                  (unsigned long long)period, (unsigned long long)C, (unsigned long long)brick_layers);
+    uint64_t chunks = 0;
+    while (xb + chunks * period < gx) {
+      if (xb + chunks * period + C > gx) return fail(M2S_ERR_BAD_ARG, "x_period: the chunk at x = %llu leaves the grid (%llu layers)", (unsigned long long)(xb + chunks * period), (unsigned long long)gx);
+      ++chunks;
+    }
+    g->chunk_log = clog;
+    g->period = (uint32_t)period;
+    layers = chunks * C;
+    g->xe = g->xb + (uint32_t)layers;       // end of the VIRTUAL slab (common.h slab_x)
+  }
   set_super_brick_magic(*g);
-  *slab_cells = (size_t)(xe - xb) * gy * gz;
+  *slab_cells = (size_t)layers * gy * gz;
   return 0;
 }
+
 
 
 }  // namespace
@@ -767,6 +809,23 @@ size_t m2s_triangle_count(size_t n_vertices, size_t n_indices, int has_indices, 
   return n >= 3 ? n - 2 : 0;                             // tuple_windows
 }
 
+int m2s_interleaved_slab(const m2s_grid* grid, int n, int k, uint64_t* x_begin, uint64_t* x_end, uint64_t* x_period) {
+  // shard k of n takes the chunks k and n + k of 2n where the grid allows it (m2s_opts.x_period), else its contiguous slab
+  uint64_t a = 0, b = 0;
+  const uint64_t nx = grid ? grid->cell_count[0] : 0;
+  m2s_slab_bounds(nx, n, k, &a, &b);
+  *x_begin = a; *x_end = b; *x_period = 0;
+  if (!grid || n < 2 || k < 0 || k >= n || nx % (2ull * (uint64_t)n) != 0) return 0;
+  const uint64_t C = nx / (2ull * (uint64_t)n);
+  uint32_t bl[3];
+  static const bool cube_only = getenv("M2S_BRICK_CUBE") && atoi(getenv("M2S_BRICK_CUBE")) != 0;
+  if (cube_only) bl[0] = bl[1] = bl[2] = 2;
+  else choose_brick_shape(grid->cell_size, bl);
+  if ((C & (C - 1)) != 0 || C % (1ull << bl[0]) != 0 || C < 16) return 0;
+  *x_begin = (uint64_t)k * C; *x_end = (uint64_t)(k + 1) * C; *x_period = (uint64_t)n * C;
+  return 1;
+}
+
 int m2s_version(void) { return M2S_VERSION_MAJOR * 1000 + M2S_VERSION_MINOR; }
 
 int m2s_device_count(void) {
@@ -849,6 +908,7 @@ int m2s_generate_grid_sdf(const float* vertices, size_t n_vertices, const void* 
   DeviceState* st = nullptr;
   rc = resolve_ctx(opts, &c, &st);
   if (rc) return rc;
+  if (g.chunk_log < 31u && c.mem_kind != M2S_MEM_DEVICE) return fail(M2S_ERR_BAD_ARG, "m2s_opts.x_period needs mem_kind == M2S_MEM_DEVICE");
 
   size_t need = bvh_workspace_bytes(n_tris) + 4096;
   if (sign_method == M2S_SIGN_RAYCAST) need += sign_workspace_bytes(g, n_tris);
@@ -1142,6 +1202,7 @@ int m2s_mesh_generate_grid_sdf(m2s_mesh* m, const m2s_grid* grid, int sign_metho
   DeviceState* st = nullptr;
   rc = resolve_ctx(&o, &c, &st);
   if (rc) return rc;
+  if (g.chunk_log < 31u && c.mem_kind != M2S_MEM_DEVICE) return fail(M2S_ERR_BAD_ARG, "m2s_opts.x_period needs mem_kind == M2S_MEM_DEVICE");
   const uint64_t ny = grid->cell_count[1], nz = grid->cell_count[2], xb = g.xb;
 
   size_t need = grid_distance_workspace_bytes(g) + 8192;

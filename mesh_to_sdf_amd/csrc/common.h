@@ -112,7 +112,15 @@ struct GridParams {
   uint32_t sz_magic, sy_magic;
   uint32_t xl_cap;   // 0: super-bricks up to 8 bricks wide in x (distance.hip super_brick_xlog); k: at most 2^(k-1) bricks wide, so
                      // that the x-layers of a slab are finished in order at that granularity (M2S_PEER_TRAIL)
+  // Interleaved slab (m2s_opts.x_period): the call owns the chunks [xb + j * period, xb + j * period + 2^chunk_log), j = 0, 1, ...
+  // [xb, xe) then is the VIRTUAL slab — the chunks laid end to end — which is what bricks, seeds and cut lists are numbered
+  // by; slab_x() turns a virtual layer into the grid's x.  chunk_log = 31: one contiguous slab (slab_x(v) = xb + v).
+  uint32_t chunk_log, period;
 };
+// Grid x of virtual layer `v` (0-based) of the slab.
+__host__ __device__ __forceinline__ uint32_t slab_x(const GridParams& g, uint32_t v) {
+  return g.xb + (v >> g.chunk_log) * g.period + (v & ((1u << g.chunk_log) - 1u));
+}
 
 // Brick shape for a cell size: minimises max/min of the world extents |size[k]| * 2^bl[k] over all splits of 6.
 // Exact for n * d < 2^32 (Granlund-Montgomery with a 32-bit multiplier): q = mulhi(n, ceil(2^32 / d)).

@@ -95,13 +95,13 @@ __device__ __forceinline__ GridBrick grid_lane_voxel(const GridParams& g, uint32
   brick_coords(g, brick, &bx, &by, &bz);
   GridBrick v;
   const uint32_t lx = g.bl[0], ly = g.bl[1], lz = g.bl[2], l = (uint32_t)lane;   // z in the low bits: the fastest axis
-  v.x = g.xb + (bx << lx) + (l >> (ly + lz));
+  const uint32_t layers = g.xe - g.xb, xv = (bx << lx) + (l >> (ly + lz));   // layer of the (virtual) slab
   v.y = (by << ly) + ((l >> lz) & ((1u << ly) - 1u));
   v.z = (bz << lz) + (l & ((1u << lz) - 1u));
-  v.in_range = v.x < g.xe && v.y < g.n[1] && v.z < g.n[2];
-  v.brick_in_grid = (g.xb + (bx << lx) < g.xe) && ((by << ly) < g.n[1]) && ((bz << lz) < g.n[2]);
+  v.in_range = xv < layers && v.y < g.n[1] && v.z < g.n[2];
+  v.brick_in_grid = ((bx << lx) < layers) && ((by << ly) < g.n[1]) && ((bz << lz) < g.n[2]);
   v.bx = bx; v.by = by; v.bz = bz;
-  v.x = min(v.x, g.xe - 1);
+  v.x = slab_x(g, min(xv, layers - 1u));
   v.y = min(v.y, g.n[1] - 1);
   v.z = min(v.z, g.n[2] - 1);
   return v;
@@ -652,7 +652,22 @@ __global__ __launch_bounds__(256) void k_lane(DeviceMesh mesh, GridParams g, con
 // the lattice cell of its centroid (clamped, so triangles outside an x-slab still enter at the
 // border); each k_jfa_pass lets a cell adopt the best candidate of its 26 neighbours at +-step.
 __device__ __forceinline__ f3 lattice_point(const GridParams& g, uint32_t x, uint32_t y, uint32_t z) {
-  return {cell_center(g.first[0], g.size[0], x), cell_center(g.first[1], g.size[1], y), cell_center(g.first[2], g.size[2], z)};
+  // x is numbered along the virtual slab (interleaved chunks laid end to end); g.xb of a lattice is 0
+  return {cell_center(g.first[0], g.size[0], slab_x(g, x)), cell_center(g.first[1], g.size[1], y), cell_center(g.first[2], g.size[2], z)};
+}
+// Lattice index along x (virtual numbering) of the point nearest to real position index `ir` (lattice units from the
+// slab's first point): inside another rank's chunks it is the nearer end of the neighbouring own chunk.
+__device__ __forceinline__ uint32_t lattice_x_from_real(const GridParams& g, float fr) {
+  if (g.chunk_log >= 31u) return min((uint32_t)fminf(fmaxf(fr, 0.0f), (float)(g.n[0] - 1u)), g.n[0] - 1u);
+  const float C = (float)(1u << g.chunk_log), P = (float)g.period;
+  fr = fmaxf(fr, 0.0f);
+  float j = floorf(fr / P), o = fr - j * P;                         // period, offset inside it
+  if (o >= C) {                                                      // between two own chunks
+    if (o - C < P - o) o = C - 1.0f;                                 // nearer to the end of chunk j
+    else { j += 1.0f; o = 0.0f; }                                    // nearer to the start of chunk j + 1
+  }
+  const float v = j * C + o;
+  return min((uint32_t)fminf(v, (float)(g.n[0] - 1u)), g.n[0] - 1u);
 }
 
 // `gp` (device pointer) overrides `g0` when the lattice is only known on the device (generic queries).
@@ -667,6 +682,7 @@ __global__ __launch_bounds__(256) void k_jfa_splat(DeviceMesh mesh, GridParams g
   for (int k = 0; k < 3; ++k) {
     float f = (cc[k] - g.first[k]) / g.size[k] + 0.5f;
     if (!(f == f)) return;                                   // NaN centroid: not a useful seed
+    if (k == 0) { cell[0] = lattice_x_from_real(g, f); continue; }
     f = fminf(fmaxf(f, 0.0f), (float)(g.n[k] - 1));
     cell[k] = min((uint32_t)f, g.n[k] - 1);
   }
@@ -750,12 +766,13 @@ __global__ __launch_bounds__(64) void k_cut(DeviceMesh mesh, GridParams g, const
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t bk[3] = {4u * sx + (lane >> 4), 4u * sy + ((lane >> 2) & 3u), 4u * sz + (lane & 3u)};
   const bool in_grid = bk[0] < nbx && bk[1] < nby && bk[2] < nbz;
-  const uint32_t origin[3] = {g.xb, 0u, 0u};
+  // first cell of the brick in the grid (a brick never straddles two chunks of an interleaved slab: capi.hip checks)
+  const uint32_t cell0[3] = {slab_x(g, bk[0] << g.bl[0]), bk[1] << g.bl[1], bk[2] << g.bl[2]};
   float r = 0.0f, qq[3];
   for (int k = 0; k < 3; ++k) {
     const float hb = 0.5f * (float)((1u << g.bl[k]) - 1u) * fabsf(g.size[k]);   // half extent between voxel centres
     r = __builtin_fmaf(hb, hb, r);
-    qq[k] = g.first[k] + ((float)(origin[k] + (bk[k] << g.bl[k])) + 0.5f * (float)((1u << g.bl[k]) - 1u)) * g.size[k];
+    qq[k] = g.first[k] + ((float)cell0[k] + 0.5f * (float)((1u << g.bl[k]) - 1u)) * g.size[k];
   }
   r = sqrtf(r) * 1.0001f;
   const f3 q = mk3(qq[0], qq[1], qq[2]);
@@ -1000,7 +1017,7 @@ __global__ void k_qlattice(const int* __restrict__ b, GridParams* __restrict__ L
     g.size[k] = cs;
     g.first[k] = ((lo == lo && fabsf(lo) < 3.0e38f) ? lo : 0.0f) + 0.5f * cs;
   }
-  g.xb = 0; g.xe = QL; g.nzw = 0; g.out_off = 0;
+  g.xb = 0; g.xe = QL; g.nzw = 0; g.out_off = 0; g.chunk_log = 31; g.period = 0;
   *L = g;
 }
 
@@ -1080,6 +1097,10 @@ static GridParams coarse_level(const GridParams& fine, const uint32_t log2_strid
   c.xb = 0;
   c.xe = c.n[0];
   c.out_off = 0;
+  if (fine.chunk_log < 31u) {           // interleaved slab: chunk and period in lattice points (whole numbers: capi.hip checks)
+    c.chunk_log = fine.chunk_log - log2_stride[0];
+    c.period = fine.period >> log2_stride[0];
+  }
   return c;
 }
 

@@ -103,7 +103,7 @@ int ensure_comms(const std::vector<int>& devices) {
 
 // In-place gather of the x-slabs: buffer k holds slab k on entry, every buffer the whole grid on return.
 int rccl_gather(const std::vector<int>& devices, float* const* outs, const std::vector<uint64_t>& xb,
-                const std::vector<uint64_t>& xe, uint64_t row) {
+                const std::vector<uint64_t>& xe, uint64_t row, uint64_t period, uint64_t nx) {
   std::lock_guard<std::mutex> lk(g_comms.mu);
   int rc = ensure_comms(devices);
   if (rc) return rc;
@@ -112,7 +112,12 @@ int rccl_gather(const std::vector<int>& devices, float* const* outs, const std::
   bool even = true;
   for (size_t k = 0; k < n; ++k) even &= (xe[k] - xb[k]) == (xe[0] - xb[0]);
   ncclResult_t e = r.GroupStart();
-  if (even) {
+  if (period) {
+    // interleaved: every period [j * period, (j + 1) * period) is n equal chunks in shard order: one in-place all-gather each
+    for (uint64_t x0 = 0; x0 < nx && e == ncclSuccess; x0 += period)
+      for (size_t k = 0; k < n && e == ncclSuccess; ++k)
+        e = r.AllGather(outs[k] + (x0 + xb[k]) * row, outs[k] + x0 * row, (size_t)((xe[k] - xb[k]) * row), ncclFloat, g_comms.comms[k], g_comms.streams[k]);
+  } else if (even) {
     for (size_t k = 0; k < n && e == ncclSuccess; ++k)   // sendbuff = recvbuff + rank * count: in place
       e = r.AllGather(outs[k] + xb[k] * row, outs[k], (size_t)((xe[k] - xb[k]) * row), ncclFloat, g_comms.comms[k], g_comms.streams[k]);
   } else {
@@ -176,7 +181,9 @@ int m2s_generate_grid_sdf_multi(const float* vertices, size_t n_vertices, const 
   const auto t0 = std::chrono::steady_clock::now();
   if (!grid) return fail(M2S_ERR_BAD_ARG, "grid is NULL");
   if (!outs) return fail(M2S_ERR_BAD_ARG, "outs is NULL");
-  if (opts && opts->struct_size != 0 && opts->struct_size < sizeof(m2s_multi_opts)) return fail(M2S_ERR_BAD_ARG, "m2s_multi_opts.struct_size too small");
+  if (opts && opts->struct_size != 0 && opts->struct_size < M2S_MULTI_OPTS_V1_SIZE) return fail(M2S_ERR_BAD_ARG, "m2s_multi_opts.struct_size too small");
+  int partition = (opts && opts->struct_size >= sizeof(m2s_multi_opts)) ? opts->partition : M2S_PART_AUTO;
+  if (partition < M2S_PART_AUTO || partition > M2S_PART_INTERLEAVED) return fail(M2S_ERR_BAD_ARG, "bad partition");
   const int visible = m2s_device_count();
   if (visible <= 0) return fail(M2S_ERR_HIP, "no HIP device available: the MI355X kernels cannot run (there is no CPU fallback)");
   int n = opts ? opts->n_devices : 0;
@@ -219,7 +226,17 @@ int m2s_generate_grid_sdf_multi(const float* vertices, size_t n_vertices, const 
   // the mesh lives on devices[0] in device mode: the other devices read it through a staging copy of their own
   const size_t vbytes = n_vertices * 12, ibytes = indices ? n_indices * (size_t)index_bytes : 0;
   std::vector<uint64_t> xb((size_t)n), xe((size_t)n);
+  uint64_t period = 0;
   for (int k = 0; k < n; ++k) m2s_slab_bounds(nx, n, k, &xb[k], &xe[k]);
+  if (partition != M2S_PART_CONTIGUOUS && mem_kind == M2S_MEM_DEVICE && n > 1) {
+    std::vector<uint64_t> ib((size_t)n), ie((size_t)n);
+    bool ok = true;
+    for (int k = 0; k < n && ok; ++k) ok = m2s_interleaved_slab(grid, n, k, &ib[k], &ie[k], &period) != 0;
+    if (ok) { xb = ib; xe = ie; }
+    else period = 0;
+  }
+  if (partition == M2S_PART_INTERLEAVED && period == 0 && n > 1)
+    return fail(M2S_ERR_BAD_ARG, "this grid cannot be cut into interleaved chunks (m2s_interleaved_slab; device memory only)");
 
   std::vector<int> rcs((size_t)n, 0);
   std::vector<std::string> errs((size_t)n);
@@ -232,6 +249,7 @@ int m2s_generate_grid_sdf_multi(const float* vertices, size_t n_vertices, const 
     o.algorithm = opts ? opts->algorithm : 0;
     o.x_begin = xb[k];
     o.x_end = xe[k];
+    o.x_period = (uint32_t)period;
     o.synchronous = 1;
     o.timings = (opts && opts->timings) ? &opts->timings[k] : nullptr;
     float* peers[M2S_MAX_PEERS];
@@ -274,7 +292,7 @@ int m2s_generate_grid_sdf_multi(const float* vertices, size_t n_vertices, const 
     if (rcs[k]) return fail(rcs[k], "shard %d (device %d): %s", k, devices[k], errs[k].c_str());
   // every shard returned synchronously: all slabs (and, with the peer exchange, all pushes) are complete
   if (exchange == M2S_XCHG_RCCL && !empty) {
-    const int rc = rccl_gather(devices, outs, xb, xe, row);
+    const int rc = rccl_gather(devices, outs, xb, xe, row, period, nx);
     if (rc) return rc;
   }
   if (opts && opts->wall_ms) *opts->wall_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();

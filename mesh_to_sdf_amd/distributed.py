@@ -22,7 +22,7 @@ stream that computed it.
 from typing import Callable, List, Optional, Tuple
 
 from .api import (AccelerationMethod, Grid, Mesh, PeerMode, SharedGrid, SignMethod, Topology, generate_grid_sdf,
-                  generate_sdf)
+                  generate_sdf, interleaved_slab)
 
 
 import os
@@ -172,13 +172,16 @@ class PeerGrid:
 def generate_grid_sdf_sharded(vertices, indices: Topology, grid: Grid, sign_method: SignMethod = SignMethod.Raycast, *,
                               group=None, out=None, compute_slab: Optional[Callable] = None, chunks: int = 1,
                               mesh: Optional[Mesh] = None, gather: bool = True, return_mesh: bool = False,
-                              peer_grid: Optional[PeerGrid] = None, peer_mode: PeerMode = PeerMode.Push, timings=None):
+                              peer_grid: Optional[PeerGrid] = None, peer_mode: PeerMode = PeerMode.Push, timings=None,
+                              interleave: bool = True):
     """generate_grid_sdf over all ranks of `group` (default: the world).  `vertices`/`indices` are this
     rank's copies (CUDA tensors for the HIP path); returns the full grid on every rank.
 
     Two ways to deliver the slabs:
-      peer_grid given   one m2s_generate_grid_sdf call per rank on its contiguous x-slab, writing into `peer_grid.tensor`
-                        and into every other rank's buffer (peer pushes over xGMI), then a barrier: no collective moves data;
+      peer_grid given   one m2s_generate_grid_sdf call per rank, writing into `peer_grid.tensor` and into every other rank's
+                        buffer (peer pushes over xGMI), then a barrier: no collective moves data.  The rank's cells are the
+                        chunks r and world + r of 2 world (`interleave`, m2s_opts.x_period: balanced — a contiguous middle
+                        slab costs 30 % more than an outer one), or its contiguous x-slab where the grid does not allow that;
       otherwise         `chunks` contiguous x-ranges, each gathered in place by an asynchronous RCCL all-gather that
                         overlaps the next chunk's compute.
 
@@ -193,10 +196,10 @@ def generate_grid_sdf_sharded(vertices, indices: Topology, grid: Grid, sign_meth
     rank = dist.get_rank(group) if inited else 0
     row = ny * nz
     if peer_grid is not None:
-        a, b = slab_bounds(nx, world, rank)
+        a, b, period = interleaved_slab(grid, world, rank) if interleave else (*slab_bounds(nx, world, rank), 0)
         out = peer_grid.tensor
-        generate_grid_sdf(vertices, indices, grid, sign_method, x_slab=(a, b), out=out, peer_out=peer_grid.peers,
-                          peer_mode=peer_mode, timings=timings)   # synchronous: this rank's slab and its pushes are complete
+        generate_grid_sdf(vertices, indices, grid, sign_method, x_slab=(a, b), x_period=period, out=out, peer_out=peer_grid.peers,
+                          peer_mode=peer_mode, timings=timings)   # synchronous: this rank's cells and their pushes are complete
         if world > 1:
             dist.barrier(group)                                   # ... and so are everybody else's into `out`
         return out

@@ -27,7 +27,7 @@ def main():
 
     v, idx = meshes.named("blob-6k")
     lo, hi = meshes.extended_bbox(v, 0.1)
-    g = Grid.from_bounding_box(lo, hi, [75, 40, 36])
+    g = Grid.from_bounding_box(lo, hi, [75, 40, 36] if mode != "ipc_peer" else [128, 44, 40])   # 128 = 2 ranks x 2 chunks x 32 layers
     dv = torch.as_tensor(v, device=f"cuda:{dev}")
     di = torch.as_tensor(idx.astype(np.int64), device=f"cuda:{dev}")
     topo = Topology.TriangleList(di)
@@ -39,9 +39,13 @@ def main():
             pg.tensor.fill_(float("nan"))
             torch.cuda.synchronize()
             dist.barrier()
-            out = generate_grid_sdf_sharded(dv, topo, g, SignMethod.Raycast, peer_grid=pg, peer_mode=pm)
-            assert out.data_ptr() == pg.tensor.data_ptr()
-            assert torch.equal(out.view(torch.int32), want.view(torch.int32)), f"rank {rank} mode {pm}"
+            for interleave in (True, False):
+                pg.tensor.fill_(float("nan"))
+                torch.cuda.synchronize()
+                dist.barrier()
+                out = generate_grid_sdf_sharded(dv, topo, g, SignMethod.Raycast, peer_grid=pg, peer_mode=pm, interleave=interleave)
+                assert out.data_ptr() == pg.tensor.data_ptr()
+                assert torch.equal(out.view(torch.int32), want.view(torch.int32)), f"rank {rank} mode {pm} interleave {interleave}"
         pg.close()
         print(f"ipc_peer ok rank {rank}", flush=True)
     elif mode == "nccl_one_rank":

@@ -11,8 +11,8 @@ import sys
 import numpy as np
 import pytest
 
-from mesh_to_sdf_amd import (Exchange, Grid, PeerMode, SignMethod, Topology, generate_grid_sdf, generate_grid_sdf_multi, meshes,
-                             slab_bounds)
+from mesh_to_sdf_amd import (Exchange, Grid, Partition, PeerMode, SignMethod, Topology, generate_grid_sdf, generate_grid_sdf_multi,
+                             interleaved_slab, meshes, slab_bounds)
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -79,6 +79,40 @@ def test_multi_peer_trailing_push_large_slab(sign):
         assert torch.equal(o.view(torch.int32), want.view(torch.int32))
 
 
+@pytest.mark.parametrize("mode", [PeerMode.Push, PeerMode.Store, PeerMode.Trail])
+@pytest.mark.parametrize("sign", [SignMethod.Raycast, SignMethod.Normal])
+def test_multi_interleaved_partition(mode, sign):
+    """m2s_partition INTERLEAVED: shard k computes the chunks k and n + k of 2n (m2s_opts.x_period) in one call; every
+    delivery mode; cut lists, seeds and walk are numbered along the virtual slab, addresses and geometry along the grid."""
+    import torch
+
+    v, idx = meshes.named("blob-100k")
+    lo, hi = meshes.extended_bbox(v, 0.1)
+    g = Grid.from_bounding_box(lo, hi, [256, 250, 254])
+    assert interleaved_slab(g, 4, 1) == (32, 64, 128) and interleaved_slab(g, 3, 1)[2] == 0
+    dv, di = _device_inputs(v, idx)
+    want = generate_grid_sdf(dv, Topology.TriangleList(di), g, sign)
+    info = {}
+    outs = generate_grid_sdf_multi(dv, Topology.TriangleList(di), g, sign, devices=[0, 0, 0, 0], exchange=Exchange.Peer, peer_mode=mode,
+                                   partition=Partition.Interleaved, info=info)
+    for o in outs:
+        assert torch.equal(o.view(torch.int32), want.view(torch.int32))
+    assert sum(int(t.n_units) for t in info["timings"]) == g.get_total_cell_count()
+
+
+def test_multi_interleaved_where_the_grid_does_not_allow_it():
+    from mesh_to_sdf_amd import M2SPanic
+
+    v, idx, g = _case((70, 40, 36))
+    dv, di = _device_inputs(v, idx)
+    with pytest.raises(M2SPanic):
+        generate_grid_sdf_multi(dv, Topology.TriangleList(di), g, SignMethod.Raycast, devices=[0, 0], exchange=Exchange.Peer, partition=Partition.Interleaved)
+    with pytest.raises(M2SPanic):   # host results stream out slab by slab: no interleaving
+        generate_grid_sdf(v, Topology.TriangleList(idx), Grid.from_bounding_box([-1, -1, -1], [1, 1, 1], [64, 64, 64]), SignMethod.Raycast, x_slab=(0, 16), x_period=32)
+    with pytest.raises(M2SPanic):   # chunk not a power of two
+        generate_grid_sdf(dv, Topology.TriangleList(di), Grid.from_bounding_box([-1, -1, -1], [1, 1, 1], [96, 64, 64]), SignMethod.Raycast, x_slab=(0, 24), x_period=48)
+
+
 def test_multi_peer_push_large_slab_in_pieces():
     """A slab big enough for the piece pipeline (walk of piece i+1 beside the push of piece i)."""
     import torch
@@ -89,7 +123,8 @@ def test_multi_peer_push_large_slab_in_pieces():
     dv, di = _device_inputs(v, idx)
     want = generate_grid_sdf(dv, Topology.TriangleList(di), g, SignMethod.Raycast)
     info = {}
-    outs = generate_grid_sdf_multi(dv, Topology.TriangleList(di), g, SignMethod.Raycast, devices=[0, 0], exchange=Exchange.Peer, info=info)
+    outs = generate_grid_sdf_multi(dv, Topology.TriangleList(di), g, SignMethod.Raycast, devices=[0, 0], exchange=Exchange.Peer, info=info,
+                                   partition=Partition.Contiguous)
     assert [int(t.distance_launches) for t in info["timings"]] == [4, 4]
     for o in outs:
         assert torch.equal(o.view(torch.int32), want.view(torch.int32))
@@ -115,7 +150,8 @@ def test_multi_exchange_none_leaves_other_slabs_alone():
     dv, di = _device_inputs(v, idx)
     want = generate_grid_sdf(dv, Topology.TriangleList(di), g, SignMethod.Raycast).view(70, -1)
     outs = [torch.full((70 * 40 * 36,), -7.0, device="cuda:0") for _ in range(2)]
-    generate_grid_sdf_multi(dv, Topology.TriangleList(di), g, SignMethod.Raycast, devices=[0, 0], outs=outs, exchange=Exchange.Nothing)
+    generate_grid_sdf_multi(dv, Topology.TriangleList(di), g, SignMethod.Raycast, devices=[0, 0], outs=outs, exchange=Exchange.Nothing,
+                            partition=Partition.Contiguous)
     for k in range(2):
         a, b = slab_bounds(70, 2, k)
         o = outs[k].view(70, -1)

@@ -26,10 +26,11 @@ def main():
     ap.add_argument("--modes", default="none,trail,push,store")
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--ranks", default="")
+    ap.add_argument("--partition", default="contiguous", choices=["contiguous", "interleaved"])
     args = ap.parse_args()
     import torch
 
-    from mesh_to_sdf_amd import Grid, M2STimings, PeerMode, SignMethod, Topology, generate_grid_sdf, meshes, slab_bounds
+    from mesh_to_sdf_amd import Grid, M2STimings, PeerMode, SignMethod, Topology, generate_grid_sdf, interleaved_slab, meshes, slab_bounds
 
     v, idx = meshes.named(args.mesh)
     lo, hi = meshes.extended_bbox(v, 0.1)
@@ -57,16 +58,19 @@ def main():
           f"seed+cut {t.seed_ms:.3f} distance {t.distance_ms:.3f} total {t.total_ms:.3f}")
     for world in [int(w) for w in args.world.split(",")]:
         peers = [torch.empty(n ** 3, dtype=torch.float32, device="cuda") for _ in range(world - 1)]
-        ranks = [int(r) for r in args.ranks.split(",")] if args.ranks else sorted({0, world // 2 - 1, world // 2, world - 1})
+        ranks = [int(r) for r in args.ranks.split(",")] if args.ranks else (list(range(world)) if args.partition == "interleaved" else sorted({0, world // 2 - 1, world // 2, world - 1}))
         for mode in args.modes.split(","):
             worst = 0.0
             for r in ranks:
-                xs = slab_bounds(n, world, r)
+                xs, period = slab_bounds(n, world, r), 0
+                if args.partition == "interleaved":
+                    a, b, period = interleaved_slab(grid, world, r)
+                    xs = (a, b)
                 kw = {} if mode == "none" else {"peer_out": peers, "peer_mode": {"push": PeerMode.Push, "store": PeerMode.Store, "trail": PeerMode.Trail}[mode]}
                 t = M2STimings()
-                med, mn = timed(lambda: generate_grid_sdf(dv, topo, grid, sign, x_slab=xs, out=out, timings=t, **kw))
+                med, mn = timed(lambda: generate_grid_sdf(dv, topo, grid, sign, x_slab=xs, x_period=period, out=out, timings=t, **kw))
                 worst = max(worst, med)
-                print(f"world {world} rank {r} slab {xs} delivery={mode}: wall median {med:.3f} ms (min {mn:.3f}); build {t.accel_build_ms:.3f} sign {t.sign_ms:.3f} "
+                print(f"world {world} rank {r} slab {xs}{' period ' + str(period) if period else ''} delivery={mode}: wall median {med:.3f} ms (min {mn:.3f}); build {t.accel_build_ms:.3f} sign {t.sign_ms:.3f} "
                       f"seed+cut {t.seed_ms:.3f} distance {t.distance_ms:.3f} ({t.distance_launches} launches) device total {t.total_ms:.3f}")
             print(f"## world {world} delivery={mode}: slowest rank {worst:.3f} ms -> compute-side speedup bound {med1 / worst:.2f}x of {world}")
         del peers
