@@ -696,21 +696,29 @@ __global__ __launch_bounds__(256) void k_jfa_splat(DeviceMesh mesh, GridParams g
   atomicMin(&keys[((size_t)cell[0] * g.n[1] + cell[1]) * g.n[2] + cell[2]], key);
 }
 
-__global__ __launch_bounds__(256) void k_jfa_unpack(const unsigned long long* __restrict__ keys, size_t n,
-                                                    uint32_t* __restrict__ ids) {
+// The lattice carries the candidate's centroid beside its id (xyz, id bits in w): a pass then reads 27 neighbouring 16-byte
+// records — structured, cache-friendly reads — instead of 27 ids plus a dependent random gather of each candidate's centroid.
+__global__ __launch_bounds__(256) void k_jfa_load(DeviceMesh mesh, const unsigned long long* __restrict__ keys, size_t n,
+                                                  float4* __restrict__ lat) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) ids[i] = (uint32_t)(keys[i] & 0xffffffffull);   // untouched cells hold ~0: id 0xffffffff = none
+  if (i >= n) return;
+  const uint32_t id = (uint32_t)(keys[i] & 0xffffffffull);    // untouched cells hold ~0: id 0xffffffff = none
+  float4 c = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  if (id != 0xffffffffu) c = mesh.cen[id];
+  c.w = __uint_as_float(id);
+  lat[i] = c;
 }
 
-__global__ __launch_bounds__(256) void k_jfa_pass(DeviceMesh mesh, GridParams g0, const GridParams* __restrict__ gp,
-                                                  const uint32_t* __restrict__ in, uint32_t* __restrict__ out, int step) {
+__global__ __launch_bounds__(256) void k_jfa_pass(GridParams g0, const GridParams* __restrict__ gp, const float4* __restrict__ in,
+                                                  float4* __restrict__ out, int step, uint32_t* __restrict__ ids_out) {
   const GridParams g = gp ? *gp : g0;
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t total = (size_t)g.n[0] * g.n[1] * g.n[2];
   if (i >= total) return;
   const int z = (int)(i % g.n[2]), y = (int)((i / g.n[2]) % g.n[1]), x = (int)(i / ((size_t)g.n[2] * g.n[1]));
   const f3 p = lattice_point(g, (uint32_t)x, (uint32_t)y, (uint32_t)z);
-  uint32_t best = 0xffffffffu, prev = 0xffffffffu;
+  uint32_t best = 0xffffffffu;
+  float4 bc = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0xffffffffu));
   float bd = __builtin_inff();
   for (int dx = -1; dx <= 1; ++dx) {
     const int xx = x + dx * step;
@@ -721,17 +729,17 @@ __global__ __launch_bounds__(256) void k_jfa_pass(DeviceMesh mesh, GridParams g0
       for (int dz = -1; dz <= 1; ++dz) {
         const int zz = z + dz * step;
         if (zz < 0 || zz >= (int)g.n[2]) continue;
-        const uint32_t cand = in[((size_t)xx * g.n[1] + yy) * g.n[2] + zz];
-        if (cand == 0xffffffffu || cand == best || cand == prev) continue;   // neighbours mostly agree: skip the gather
-        prev = cand;
-        const float4 c = mesh.cen[cand];
+        const float4 c = in[((size_t)xx * g.n[1] + yy) * g.n[2] + zz];
+        const uint32_t cand = __float_as_uint(c.w);
+        if (cand == 0xffffffffu) continue;
         const float ex = p.x - c.x, ey = p.y - c.y, ez = p.z - c.z;
         const float d = __builtin_fmaf(ex, ex, __builtin_fmaf(ey, ey, ez * ez));
-        if (d < bd || (d == bd && cand < best)) { bd = d; best = cand; }
+        if (d < bd || (d == bd && cand < best)) { bd = d; best = cand; bc = c; }
       }
     }
   }
-  out[i] = best;
+  out[i] = bc;
+  if (ids_out) ids_out[i] = best;
 }
 
 // ---- k_cut: one wave per 4 x 4 x 4 bricks, lane = brick, one cut list per brick (see CutList) ---------------
@@ -1112,7 +1120,7 @@ static size_t cut_blocks(const GridParams& g, uint32_t log) {
 size_t grid_distance_workspace_bytes(const GridParams& g) {
   const size_t bricks = (size_t)host_brick_count(g);
   const size_t trail_counters = (size_t)bricks_along(g.xe - g.xb, g.bl[0]) * (bricks_along(g.n[1], g.bl[1]) + 1) * 4;   // M2S_PEER_TRAIL progress
-  return bricks * 16 + bricks + 16384 + cut_blocks(g, 0) * CUT_WORDS * 4 + trail_counters + 1024;   // seeds + cut lists (one per brick)
+  return bricks * 44 + bricks + 16384 + cut_blocks(g, 0) * CUT_WORDS * 4 + trail_counters + 1024;   // seeds + cut lists (one per brick)
 }
 
 __global__ __launch_bounds__(256) void k_seed_remap(uint32_t* __restrict__ ids, size_t n, const uint32_t* __restrict__ slot_of, uint32_t n_tris) {
@@ -1142,26 +1150,27 @@ int launch_grid_seeds(Arena& ws, hipStream_t st, const float4* cen, uint32_t n_t
   const uint32_t stride_log[3] = {g.bl[0] + seed_shift, g.bl[1] + seed_shift, g.bl[2] + seed_shift};
   const GridParams g1 = coarse_level(g, stride_log, g.xb);
   const size_t points1 = (size_t)g1.n[0] * g1.n[1] * g1.n[2];
-  uint32_t* s1 = ws.take<uint32_t>(points1);
-  uint32_t* s1b = ws.take<uint32_t>(points1);
-  if (!s1 || !s1b) { set_error("internal: seed workspace too small"); return M2S_ERR_HIP_INTERNAL; }
+  uint32_t* ids = ws.take<uint32_t>(points1);
+  float4* la = ws.take<float4>(points1);
+  float4* lb = ws.take<float4>(points1);
   unsigned long long* keys = ws.take<unsigned long long>(points1);
-  if (!keys) { set_error("internal: seed workspace too small"); return M2S_ERR_HIP_INTERNAL; }
+  if (!ids || !la || !lb || !keys) { set_error("internal: seed workspace too small"); return M2S_ERR_HIP_INTERNAL; }
   const unsigned nb1 = (unsigned)((points1 + 255) / 256);
   M2S_HIP_CHECK(hipMemsetAsync(keys, 0xff, points1 * 8, st));
   hipLaunchKernelGGL(k_jfa_splat, dim3((mesh.n_tris + 255) / 256), dim3(256), 0, st, mesh, g1, nullptr, keys);
-  hipLaunchKernelGGL(k_jfa_unpack, dim3(nb1), dim3(256), 0, st, keys, points1, s1);
+  hipLaunchKernelGGL(k_jfa_load, dim3(nb1), dim3(256), 0, st, mesh, keys, points1, la);
   const uint32_t maxdim = max(g1.n[0], max(g1.n[1], g1.n[2]));
   int step = 1;
   while ((uint32_t)step * 2 < maxdim) step *= 2;
-  uint32_t *src = s1, *dst = s1b;
+  float4 *src = la, *dst = lb;
   const unsigned nb = (unsigned)((points1 + 255) / 256);
   for (; step >= 1; step /= 2) {
-    hipLaunchKernelGGL(k_jfa_pass, dim3(nb), dim3(256), 0, st, mesh, g1, nullptr, src, dst, step);
-    uint32_t* t = src; src = dst; dst = t;
+    hipLaunchKernelGGL(k_jfa_pass, dim3(nb), dim3(256), 0, st, g1, nullptr, src, dst, step, nullptr);
+    float4* t = src; src = dst; dst = t;
   }
-  hipLaunchKernelGGL(k_jfa_pass, dim3(nb), dim3(256), 0, st, mesh, g1, nullptr, src, dst, 1);   // "JFA+1": one more unit pass
-  out->ids = dst;
+  hipLaunchKernelGGL(k_jfa_pass, dim3(nb), dim3(256), 0, st, g1, nullptr, src, dst, 1, ids);   // "JFA+1": one more unit pass; leaves the ids
+  uint32_t* dst_ids = ids;
+  out->ids = dst_ids;
   out->ny = g1.n[1];
   out->nz = g1.n[2];
   out->points = points1;
@@ -1320,7 +1329,7 @@ size_t query_workspace_bytes(size_t n_q) {
   size_t n = n_q ? n_q : 1, tmp = 0;
   (void)rocprim::radix_sort_pairs(nullptr, tmp, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr,
                             n, 0, 64, (hipStream_t)0);
-  return n * (8 + 8 + 4 + 4 + 16) + tmp + 16 * 256 + (size_t)64 * 64 * 64 * 16 + 8192 + 24 * 1024 + 256;
+  return n * (8 + 8 + 4 + 4 + 16) + tmp + 16 * 256 + (size_t)64 * 64 * 64 * 44 + 8192 + 24 * 1024 + 256;
 }
 
 int launch_query_distance(Arena& ws, hipStream_t st, const DeviceMesh& mesh, const float* d_queries, size_t n_q,
@@ -1367,21 +1376,22 @@ int launch_query_distance(Arena& ws, hipStream_t st, const DeviceMesh& mesh, con
     const size_t cells = (size_t)QL * QL * QL;
     GridParams* lat = ws.take<GridParams>(1);
     unsigned long long* k64 = ws.take<unsigned long long>(cells);
-    uint32_t* s1 = ws.take<uint32_t>(cells);
-    uint32_t* s2 = ws.take<uint32_t>(cells);
-    if (!lat || !k64 || !s1 || !s2) { set_error("internal: query workspace too small"); return M2S_ERR_HIP_INTERNAL; }
+    uint32_t* ids = ws.take<uint32_t>(cells);
+    float4* la = ws.take<float4>(cells);
+    float4* lb = ws.take<float4>(cells);
+    if (!lat || !k64 || !ids || !la || !lb) { set_error("internal: query workspace too small"); return M2S_ERR_HIP_INTERNAL; }
     hipLaunchKernelGGL(k_qlattice, dim3(1), dim3(64), 0, st, qb, lat);
     M2S_HIP_CHECK(hipMemsetAsync(k64, 0xff, cells * 8, st));
     hipLaunchKernelGGL(k_jfa_splat, dim3((mesh.n_tris + 255) / 256), dim3(256), 0, st, mesh, g, lat, k64);
     const unsigned nbl = (unsigned)((cells + 255) / 256);
-    hipLaunchKernelGGL(k_jfa_unpack, dim3(nbl), dim3(256), 0, st, k64, cells, s1);
-    uint32_t *src = s1, *dst = s2;
+    hipLaunchKernelGGL(k_jfa_load, dim3(nbl), dim3(256), 0, st, mesh, k64, cells, la);
+    float4 *src = la, *dst = lb;
     for (int step = QL / 2; step >= 1; step /= 2) {
-      hipLaunchKernelGGL(k_jfa_pass, dim3(nbl), dim3(256), 0, st, mesh, g, lat, src, dst, step);
-      uint32_t* t = src; src = dst; dst = t;
+      hipLaunchKernelGGL(k_jfa_pass, dim3(nbl), dim3(256), 0, st, g, lat, src, dst, step, nullptr);
+      float4* t = src; src = dst; dst = t;
     }
-    hipLaunchKernelGGL(k_jfa_pass, dim3(nbl), dim3(256), 0, st, mesh, g, lat, src, dst, 1);
-    seeds = dst;
+    hipLaunchKernelGGL(k_jfa_pass, dim3(nbl), dim3(256), 0, st, g, lat, src, dst, 1, ids);
+    seeds = ids;
     d_lat = lat;
   }
   if (mode == MODE_UNSIGNED && sign_src == SIGN_RAYS3) launch_packet<false, MODE_UNSIGNED, SIGN_RAYS3>(st, mesh, g, sorted, perm, nq, nullptr, d_out, d_err, packets, seeds, 0, 0, 0, d_lat);
