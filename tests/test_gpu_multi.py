@@ -100,6 +100,42 @@ def test_multi_interleaved_partition(mode, sign):
     assert sum(int(t.n_units) for t in info["timings"]) == g.get_total_cell_count()
 
 
+@pytest.mark.parametrize("case", range(8))
+def test_interleaved_calls_fuzz(case):
+    """Random meshes / grids (anisotropic and negative cell sizes, ragged y and z, non-cubic packet bricks) cut into interleaved
+    chunks, one call per shard, with the cut lists forced on: the union must equal the single call bit for bit."""
+    import torch
+
+    rng = np.random.default_rng(7000 + case)
+    nt = int(rng.integers(50, 3000))
+    centers = rng.uniform(-1, 1, (nt, 1, 3))
+    tri = (centers + rng.standard_normal((nt, 3, 3)) * 10.0 ** rng.uniform(-2.5, -0.5, (nt, 1, 1))).astype(np.float32)
+    v, idx = tri.reshape(-1, 3), np.arange(3 * nt, dtype=np.uint32)
+    world = int(rng.choice([2, 4]))
+    nx = int(rng.choice([64, 128, 256]))
+    counts = [nx, int(rng.integers(5, 60)), int(rng.integers(5, 60))]
+    lo, hi = v.min(0) - rng.uniform(0, 0.5, 3).astype(np.float32), v.max(0) + rng.uniform(0, 0.5, 3).astype(np.float32)
+    if case % 3 == 1:
+        lo[0], hi[0] = hi[0], lo[0]           # negative cell size along x
+    if case % 4 == 2:
+        hi[0] = lo[0] + (hi[0] - lo[0]) * 8   # anisotropic: long cells along x, so packet bricks thin along x
+    g = Grid.from_bounding_box(lo, hi, counts)
+    os.environ["M2S_CUT_MIN_PACKETS"] = "8"
+    try:
+        dv, di = torch.as_tensor(v, device="cuda:0"), torch.as_tensor(idx.astype(np.int64), device="cuda:0")
+        for sign in (SignMethod.Raycast, SignMethod.Normal):
+            want = generate_grid_sdf(dv, Topology.TriangleList(di), g, sign)
+            out = torch.full_like(want, float("nan"))
+            used = 0
+            for k in range(world):
+                a, b, period = interleaved_slab(g, world, k)
+                used += period != 0
+                generate_grid_sdf(dv, Topology.TriangleList(di), g, sign, x_slab=(a, b), x_period=period, out=out)
+            assert torch.equal(out.view(torch.int32), want.view(torch.int32)), (case, sign, counts, world, used)
+    finally:
+        os.environ.pop("M2S_CUT_MIN_PACKETS", None)
+
+
 def test_multi_interleaved_where_the_grid_does_not_allow_it():
     from mesh_to_sdf_amd import M2SPanic
 
