@@ -8,6 +8,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <new>
+#include <stdexcept>
 #include <vector>
 
 #include "../../include/m2s.h"
@@ -356,7 +358,7 @@ int m2s_sdf_encode_generic(const float* queries, size_t n_queries, const float* 
   return rc;
 }
 
-int m2s_sdf_probe(const uint8_t* bytes, size_t n_bytes, m2s_sdf_info* info, const m2s_opts* opts) {
+static int m2s_sdf_probe_body(const uint8_t* bytes, size_t n_bytes, m2s_sdf_info* info, const m2s_opts* opts) {
   clear_error();
   if (!bytes || !info) return fail(M2S_ERR_BAD_ARG, "bytes / info is NULL");
   std::vector<uint8_t> host_copy;
@@ -368,7 +370,7 @@ int m2s_sdf_probe(const uint8_t* bytes, size_t n_bytes, m2s_sdf_info* info, cons
   return probe_impl(bytes, n_bytes, c.mem_kind, c.stream, info, &host_copy);
 }
 
-int m2s_sdf_decode(const uint8_t* bytes, size_t n_bytes, float* queries_out, float* distances_out, const m2s_opts* opts) {
+static int m2s_sdf_decode_body(const uint8_t* bytes, size_t n_bytes, float* queries_out, float* distances_out, const m2s_opts* opts) {
   clear_error();
   if (!bytes) return fail(M2S_ERR_BAD_ARG, "bytes is NULL");
   CallCtx c;
@@ -398,7 +400,7 @@ int m2s_sdf_save_generic(const char* path, const float* queries, size_t n_querie
   return save_impl(path, L, queries, n_queries, distances, n_distances, opts);
 }
 
-int m2s_sdf_probe_file(const char* path, m2s_sdf_info* info) {
+static int m2s_sdf_probe_file_body(const char* path, m2s_sdf_info* info) {
   clear_error();
   if (!path || !info) return fail(M2S_ERR_BAD_ARG, "path / info is NULL");
   MappedFile file;
@@ -409,7 +411,7 @@ int m2s_sdf_probe_file(const char* path, m2s_sdf_info* info) {
   return probe_impl(file.n ? file.p : &kEmpty, file.n, M2S_MEM_HOST, nullptr, info, &unused);
 }
 
-int m2s_sdf_read_file(const char* path, float* queries_out, float* distances_out, const m2s_opts* opts) {
+static int m2s_sdf_read_file_body(const char* path, float* queries_out, float* distances_out, const m2s_opts* opts) {
   clear_error();
   if (!path) return fail(M2S_ERR_BAD_ARG, "path is NULL");
   MappedFile file;
@@ -533,6 +535,50 @@ int m2s_merge_instances(const m2s_instance* instances, size_t n_instances, float
   M2S_HIP_CHECK(hipStreamSynchronize(c.stream));   // always: the instance tables above are call-local
   if (bbox) memcpy(bbox, st->h_err + 4, 24);
   return M2S_OK;
+}
+
+// An exception must not cross the C ABI (a container whose header promises more than the process can allocate).
+int m2s_sdf_probe(const uint8_t* bytes, size_t n_bytes, m2s_sdf_info* info, const m2s_opts* opts) {
+  try {
+    return m2s_sdf_probe_body(bytes, n_bytes, info, opts);
+  } catch (const std::bad_alloc&) {
+    return fail(M2S_ERR_BAD_ARG, "DeserializationFailed: the container announces more elements than can be allocated");
+  } catch (const std::exception& e) {
+    return fail(M2S_ERR_BAD_ARG, "DeserializationFailed: %s", e.what());
+  }
+}
+
+// An exception must not cross the C ABI (a container whose header promises more than the process can allocate).
+int m2s_sdf_decode(const uint8_t* bytes, size_t n_bytes, float* queries_out, float* distances_out, const m2s_opts* opts) {
+  try {
+    return m2s_sdf_decode_body(bytes, n_bytes, queries_out, distances_out, opts);
+  } catch (const std::bad_alloc&) {
+    return fail(M2S_ERR_BAD_ARG, "DeserializationFailed: the container announces more elements than can be allocated");
+  } catch (const std::exception& e) {
+    return fail(M2S_ERR_BAD_ARG, "DeserializationFailed: %s", e.what());
+  }
+}
+
+// An exception must not cross the C ABI (a container whose header promises more than the process can allocate).
+int m2s_sdf_probe_file(const char* path, m2s_sdf_info* info) {
+  try {
+    return m2s_sdf_probe_file_body(path, info);
+  } catch (const std::bad_alloc&) {
+    return fail(M2S_ERR_BAD_ARG, "DeserializationFailed: the container announces more elements than can be allocated");
+  } catch (const std::exception& e) {
+    return fail(M2S_ERR_BAD_ARG, "DeserializationFailed: %s", e.what());
+  }
+}
+
+// An exception must not cross the C ABI (a container whose header promises more than the process can allocate).
+int m2s_sdf_read_file(const char* path, float* queries_out, float* distances_out, const m2s_opts* opts) {
+  try {
+    return m2s_sdf_read_file_body(path, queries_out, distances_out, opts);
+  } catch (const std::bad_alloc&) {
+    return fail(M2S_ERR_BAD_ARG, "DeserializationFailed: the container announces more elements than can be allocated");
+  } catch (const std::exception& e) {
+    return fail(M2S_ERR_BAD_ARG, "DeserializationFailed: %s", e.what());
+  }
 }
 
 }  // extern "C"

@@ -171,6 +171,23 @@ def test_other_number_forms_decode_like_serde():
     assert np.array_equal(de.distances, np.arange(5, dtype=np.float32))
 
 
+def test_crafted_header_with_huge_counts_is_rejected_not_allocated():
+    """A 30-byte container whose array headers promise 2^32 - 1 elements (rmp-serde caps such preallocation): the decoder must
+    answer DeserializationFailed — not allocate 48 GB, not let std::bad_alloc cross the C ABI."""
+    L = _lib.lib()
+    hdr = b"\x81\xa2V1\x81\xa7Generic\x92"
+    crafted = hdr + b"\xdd\xff\xff\xff\xff" + b"\x93\x01\x02\x03"          # array32 of 2^32-1 points, one point present (ints: scalar reader)
+    q = np.zeros(16, np.float32)
+    d = np.zeros(16, np.float32)
+    buf = np.frombuffer(crafted, np.uint8).copy()
+    assert L.m2s_sdf_decode(buf.ctypes.data, buf.size, q.ctypes.data, d.ctypes.data, None) == _lib.ERR_BAD_ARG
+    crafted = hdr + b"\x91\x93\x01\x02\x03" + b"\xdd\xff\xff\xff\xff\x01"   # one point, then 2^32-1 distances, one present
+    buf = np.frombuffer(crafted, np.uint8).copy()
+    assert L.m2s_sdf_decode(buf.ctypes.data, buf.size, q.ctypes.data, d.ctypes.data, None) == _lib.ERR_BAD_ARG
+    with pytest.raises(SerdeError):
+        deserialize(crafted)
+
+
 def test_capacity_and_argument_errors():
     from mesh_to_sdf_amd.serde import _opts
 
