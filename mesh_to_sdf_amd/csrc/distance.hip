@@ -335,6 +335,16 @@ __global__ __launch_bounds__(256) void k_packet(DeviceMesh mesh, GridParams g, c
     const float scale = fmaxf(mesh_scale(mesh), fmaxf(fabsf(p.x), fmaxf(fabsf(p.y), fabsf(p.z))));
     const float slack = 4.0e-6f * scale + (MODE == MODE_NORMAL_FOLD ? 2.5e-6f : 0.0f);
 
+    // pre-order ranges to walk: the brick's cut list (grid path), or the whole tree.  The list is 128 bytes that nobody has
+    // touched before (written by k_cut, read once): both of its cache lines are requested here, in front of the seed
+    // evaluation, so that the ~1 us of the miss passes under its 120 instructions instead of in front of the walk.
+    const uint32_t* cl = nullptr;
+    uint32_t n_ranges = 1;
+    if (GRID && cut.lists != nullptr) {
+      const uint32_t cb = __builtin_amdgcn_readfirstlane((((vox.bx + cut.bx_off) >> cut.log) * cut.ny + (vox.by >> cut.log)) * cut.nz + (vox.bz >> cut.log));
+      cl = cut.lists + (size_t)cb * CUT_WORDS;
+      n_ranges = cl[0] + cl[CUT_WORDS - 1];   // the last word is always 0 (k_cut): it only pulls the second line in
+    }
     if (seed_in != nullptr) {
       // seed: a triangle near this packet's centre, from the seed pass
       uint32_t sidx = packet;
@@ -388,14 +398,6 @@ __global__ __launch_bounds__(256) void k_packet(DeviceMesh mesh, GridParams g, c
     // The walk addresses NodeExt by BYTE offset (its skip links are stored that way): the scalar loads then take
     // the offset operand directly and the loop carries no address arithmetic.
     constexpr uint32_t NB = (uint32_t)sizeof(NodeExt);
-    // pre-order ranges to walk: the block's cut list (grid path), or the whole tree
-    const uint32_t* cl = nullptr;
-    uint32_t n_ranges = 1;
-    if (GRID && cut.lists != nullptr) {
-      const uint32_t cb = __builtin_amdgcn_readfirstlane((((vox.bx + cut.bx_off) >> cut.log) * cut.ny + (vox.by >> cut.log)) * cut.nz + (vox.bz >> cut.log));
-      cl = cut.lists + (size_t)cb * CUT_WORDS;
-      n_ranges = cl[0];
-    }
     if (STATS) st_ranges = n_ranges;
     for (uint32_t range = 0; range < n_ranges; ++range) {
     uint32_t off = cl ? cl[1 + 2 * range] : 0u;
@@ -870,6 +872,7 @@ __global__ __launch_bounds__(64) void k_cut(DeviceMesh mesh, GridParams g, const
   out[1 + 2 * (n - 1)] = last_start;
   out[2 + 2 * (n - 1)] = last_end;
   out[0] = n;
+  out[CUT_WORDS - 1] = 0;   // unused word in the list's second cache line, read by k_packet to prefetch that line
 }
 
 // ---- k_brute --------------------------------------------------------------------------------
