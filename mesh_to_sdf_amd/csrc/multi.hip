@@ -266,8 +266,9 @@ int m2s_generate_grid_sdf_multi(const float* vertices, size_t n_vertices, const 
     void* staged = nullptr;
     int rc = 0;
     if (xe[k] == xb[k]) { rcs[k] = 0; return; }   // more shards than layers
-    if (mem_kind == M2S_MEM_DEVICE && devices[k] != devices[0] && (vbytes || ibytes)) {
-      // replicate the mesh: one peer copy into a block of this device (1.8 MB for 100k triangles)
+    // With peer access enabled the kernels of device k read the mesh where it lies, on devices[0], over xGMI (1.8 MB for 100k
+    // triangles, read once by the first kernel of the build).  Without it (RCCL exchange) the mesh is replicated by a peer copy.
+    if (mem_kind == M2S_MEM_DEVICE && devices[k] != devices[0] && (vbytes || ibytes) && exchange != M2S_XCHG_PEER) {
       if (hipSetDevice(devices[k]) != hipSuccess || hipMalloc(&staged, vbytes + ibytes + 512) != hipSuccess) rc = fail(M2S_ERR_HIP, "mesh replica: hipMalloc failed on device %d", devices[k]);
       char* sv = (char*)staged;
       char* si = sv + (vbytes + 255) / 256 * 256;
