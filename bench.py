@@ -86,7 +86,7 @@ def bench_queries(args):
     dist_ms = float(np.mean([t.distance_ms for t in tims]))      # Morton sort + seed lattice + k_packet<LIST, UNSIGNED, RAYS3>
     b_alg = 16.0 * nq + 12.0 * v.shape[0] + 12.0 * int(tims[0].n_triangles)   # 16 B per query + the mesh once
     achieved = b_alg / (dist_ms * 1e-3) / 1e9
-    print(json.dumps({
+    emit(json.dumps({
         "metric": "Mqueries/s for generate_sdf (10M random queries, 100k tris, RtreeBvh)", "value": round(nq * args.steps / elapsed / 1e6, 2),
         "unit": "Mqueries/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed * 1e3 / args.steps, 4),
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -96,7 +96,7 @@ def bench_queries(args):
         "roofline": {"bound": "hbm", "kernel": "k_packet<LIST, MODE_UNSIGNED, SIGN_RAYS3> (+ the query sort and seed lattice in front of it)",
                      "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
                      "algorithmic_bytes_per_launch": b_alg, "avg_launch_ms": round(dist_ms, 4)},
-    }), flush=True)
+    }))
 
 
 def cpu_baseline(v, idx, lo, hi, sign, budget_s, headline_n):
@@ -152,8 +152,28 @@ def cpu_baseline(v, idx, lo, hi, sign, budget_s, headline_n):
     return res, n, ref
 
 
+_JSON_FD = None
+
+
+def _stdout_is_for_the_json_line_only():
+    """RCCL prints a version banner on STDOUT when a communicator is created (and libraries below us may print more): the driver
+    reads one JSON line from stdout, so file descriptor 1 is pointed at stderr for the whole run and the JSON line is written
+    to a duplicate of the original stdout at the end."""
+    global _JSON_FD
+    if _JSON_FD is None:
+        sys.stdout.flush()
+        _JSON_FD = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit(line: str):
+    sys.stdout.flush()
+    os.write(_JSON_FD if _JSON_FD is not None else 1, (line + "\n").encode())
+
+
 def main():
     args = parse()
+    _stdout_is_for_the_json_line_only()
     if args.config == 3:
         return bench_queries(args)
     import torch
@@ -392,7 +412,7 @@ def main():
                 times.append((time.perf_counter() - t1) * 1e3)
             res["host_pointer_call_ms"] = round(min(times[1:]), 2)
             res["host_pointer_first_call_ms"] = round(times[0], 2)
-        print(json.dumps(res), flush=True)
+        emit(json.dumps(res))
     if pg is not None:
         pg.close()
     if dist.is_initialized():

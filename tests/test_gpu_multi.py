@@ -276,3 +276,34 @@ def test_nccl_backend_one_rank():
     issued from the piece streams (M2S_FORCE_COLLECTIVES), result equal to the single call."""
     out = _run_worker("nccl_one_rank", 1, {"M2S_FORCE_COLLECTIVES": "1"})
     assert "nccl_one_rank ok" in out, out
+
+
+def _bench(args, env=None, launcher=None):
+    e = dict(os.environ)
+    e.update(env or {})
+    cmd = (launcher or [sys.executable]) + [os.path.join(ROOT, "bench.py")] + args
+    r = subprocess.run(cmd, env=e, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, f"stdout must hold exactly one line (the JSON): {lines[:5]}"    # RCCL's banner and the like belong on stderr
+    import json
+
+    return json.loads(lines[0])
+
+
+def test_bench_contract_single_line_json_in_every_mode():
+    """bench.py prints ONE JSON line on stdout whatever runs underneath (RCCL prints a banner on stdout when a communicator is
+    created), carries `roofline`, and the multi-shard modes verify the delivered grid against the single-GPU result."""
+    small = ["--grid", "128", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+    d = _bench(small)
+    assert d["n_gpus"] == 1 and d["unit"] == "Mvoxels/s" and d["roofline"]["bound"] == "hbm" and d["roofline"]["frac"] > 0
+    d = _bench(small + ["--gpus", "3"], {"M2S_BENCH_DEVICES": "0,0,0"})                       # one process, three shards on this GPU
+    assert d["n_gpus"] == 3 and d["config"]["gather_verified"] is True and d["config"]["exchange"] == "in-process"
+    launch = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+              "--master-port", str(29700 + os.getpid() % 200)]
+    for exchange in ("peer", "rccl"):                                                           # two ranks share this GPU (gloo: RCCL refuses that)
+        d = _bench(small + ["--gpus", "2"], {"M2S_DIST_BACKEND": "gloo", "M2S_EXCHANGE": exchange}, launch)
+        assert d["n_gpus"] == 2 and d["config"]["exchange"] == exchange and d["config"]["gather_verified"] is True
+    d = _bench(small, {"M2S_FORCE_COLLECTIVES": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(29900 + os.getpid() % 90), "RANK": "0",
+                       "WORLD_SIZE": "1", "M2S_EXCHANGE": "rccl"})                              # 1-rank nccl group: the banner case
+    assert d["config"]["exchange"] == "rccl" and d["config"]["gather_verified"] is True
