@@ -32,6 +32,8 @@ sys.path.insert(0, ROOT)
 # stream, two piece streams and RCCL's: one more stream anywhere and two of them share a queue and serialise (measured:
 # +0.4 ms per step of an 8-GPU rank).  Must be set before the HIP runtime starts.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# the host driver only supports dmabuf IPC: RCCL and the peer exchange (m2s_ipc_*) map each other's buffers through it
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
@@ -233,7 +235,7 @@ def main():
             why = f"{type(e).__name__}: {e}"
         if not all_agree(pg is not None):
             if pg is not None:
-                pg.close()
+                pg.close(sync=False)      # not every rank has one: no collective here
             pg, exchange = None, "rccl"
     out = pg.tensor if pg is not None else torch.empty(n ** 3, dtype=torch.float32, device=dev)
     outs = devices = None

@@ -151,22 +151,39 @@ class PeerGrid:
         self.group = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
-        self.local = SharedGrid(n_cells, device)
+        self.peers, self.local, self.tensor = [], None, None
+        handle, why = None, None
+        try:
+            self.local = SharedGrid(n_cells, device)
+            handle = self.local.handle
+        except Exception as e:   # noqa: BLE001  — every rank still takes part in the exchange below, or the others would hang
+            why = e
         handles = [None] * self.world
-        dist.all_gather_object(handles, self.local.handle, group=group)
-        self.peers = [SharedGrid.open(h, n_cells, device) for r, h in enumerate(handles) if r != self.rank]
-        self.tensor = self.local.tensor
+        dist.all_gather_object(handles, handle, group=group)
+        if any(h is None for h in handles):
+            self.close(sync=False)
+            raise RuntimeError(f"a rank could not allocate / export its shared grid buffer ({why})")
+        try:
+            self.peers = [SharedGrid.open(h, n_cells, device) for r, h in enumerate(handles) if r != self.rank]
+            self.tensor = self.local.tensor
+        except Exception:
+            self.close(sync=False)
+            raise
 
-    def close(self):
+    def close(self, sync: bool = True):
+        """`sync`: barrier between unmapping the peers and freeing the own buffer (nobody frees under a peer that is still
+        writing).  Pass False when the ranks did not all get this far (a collective would hang)."""
         import torch.distributed as dist
 
         for p in self.peers:
             p.close()
         self.peers = []
-        if dist.is_initialized():
-            dist.barrier(self.group)   # nobody unmaps-then-frees under a peer that is still writing
+        if sync and dist.is_initialized():
+            dist.barrier(self.group)
         self.tensor = None
-        self.local.close()
+        if self.local is not None:
+            self.local.close()
+            self.local = None
 
 
 def generate_grid_sdf_sharded(vertices, indices: Topology, grid: Grid, sign_method: SignMethod = SignMethod.Raycast, *,
