@@ -270,35 +270,34 @@ static bool use_big_list(const GridParams& g) {
 }
 
 size_t sign_workspace_bytes(const GridParams& g, size_t n_tris) {
-  return 3 * ((size_t)g.n[0] * g.n[1] * g.nzw * 4 + 256) + 1024 + (use_big_list(g) ? 3 * n_tris * sizeof(uint2) + 512 : 0);
+  return 3 * ((size_t)g.n[0] * g.n[1] * g.nzw * 4 + 256) + 2048 + (use_big_list(g) ? 3 * n_tris * sizeof(uint2) + 512 : 0);
 }
 
 int build_grid_sign_plane(Arena& ws, hipStream_t st, const DeviceMesh& mesh, const GridParams& g,
                           const uint32_t** d_inside_plane) {
   const size_t words = (size_t)g.n[0] * g.n[1] * g.nzw;
-  uint32_t* px = ws.take<uint32_t>(words);
-  uint32_t* py = ws.take<uint32_t>(words);
-  uint32_t* pz = ws.take<uint32_t>(words);
-  if (!px || !py || !pz) {
+  // the three planes and the work-list counter in ONE block: one memset instead of four launches (a launch costs the host ~8 us
+  // and this sequence sits in front of the build's on the calling thread)
+  const size_t wpad = (words + 63) / 64 * 64;                  // planes 256-byte aligned
+  uint32_t* block = ws.take<uint32_t>(3 * wpad + 16);
+  if (!block) {
     set_error("internal: sign workspace too small");
     return M2S_ERR_HIP_INTERNAL;
   }
+  uint32_t *px = block, *py = block + wpad, *pz = block + 2 * wpad;
   *d_inside_plane = pz;
   if (words == 0) return 0;
-  M2S_HIP_CHECK(hipMemsetAsync(px, 0, words * 4, st));
-  M2S_HIP_CHECK(hipMemsetAsync(py, 0, words * 4, st));
-  M2S_HIP_CHECK(hipMemsetAsync(pz, 0, words * 4, st));
+  M2S_HIP_CHECK(hipMemsetAsync(block, 0, (3 * wpad + 16) * 4, st));
   const unsigned B = 256;
   if (mesh.n_tris) {
     BigList list{nullptr, nullptr};
     if (use_big_list(g)) {
-      list.counter = ws.take<unsigned long long>(8);
+      list.counter = reinterpret_cast<unsigned long long*>(block + 3 * wpad);
       list.items = ws.take<uint2>(3 * (size_t)mesh.n_tris);
-      if (!list.counter || !list.items) {
+      if (!list.items) {
         set_error("internal: sign workspace too small");
         return M2S_ERR_HIP_INTERNAL;
       }
-      M2S_HIP_CHECK(hipMemsetAsync(list.counter, 0, 8, st));
     }
     hipLaunchKernelGGL(k_ray_mark, dim3((mesh.n_tris + B - 1) / B), dim3(B), 0, st, mesh, g, px, py, pz, list);
     if (list.items) hipLaunchKernelGGL(k_ray_mark_big, dim3(2048), dim3(B), 0, st, mesh, g, px, py, pz, list);
