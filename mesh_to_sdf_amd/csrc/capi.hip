@@ -285,9 +285,9 @@ static std::vector<std::pair<uint32_t, uint32_t>> slab_chunks(const GridParams& 
 static int stats_begin(Arena& ws, hipStream_t stream, DeviceMesh* mesh, unsigned long long** d_stats) {
   *d_stats = nullptr;
   if (!getenv("M2S_STATS")) return 0;
-  *d_stats = ws.take<unsigned long long>(72);
+  *d_stats = ws.take<unsigned long long>(80);
   if (!*d_stats) return fail(M2S_ERR_HIP, "internal: workspace");
-  unsigned long long init[72] = {0};
+  unsigned long long init[80] = {0};
   init[7] = (unsigned long long)atoi(getenv("M2S_STATS"));
   M2S_HIP_CHECK(hipMemcpyAsync(*d_stats, init, sizeof(init), hipMemcpyHostToDevice, stream));
   M2S_HIP_CHECK(hipStreamSynchronize(stream));
@@ -296,12 +296,13 @@ static int stats_begin(Arena& ws, hipStream_t stream, DeviceMesh* mesh, unsigned
 }
 static int stats_end(hipStream_t stream, const unsigned long long* d_stats) {
   if (!d_stats) return 0;
-  unsigned long long h[72];
+  unsigned long long h[80];
   M2S_HIP_CHECK(hipMemcpyAsync(h, d_stats, sizeof(h), hipMemcpyDeviceToHost, stream));
   M2S_HIP_CHECK(hipStreamSynchronize(stream));
   const double w = h[3] ? (double)h[3] : 1.0;
   fprintf(stderr, "[m2s stats] packets %llu: per packet node tests %.1f, leaf pre-tests %.1f, exact triangle tests %.1f; node tests that pruned %.1f (by the slab term alone %.1f, by a sphere test %.1f)\n",
           h[3], h[0] / w, h[1] / w, h[2] / w, h[4] / w, h[5] / w, h[6] / w);
+  fprintf(stderr, "[m2s stats]   longest packet: %llu node tests, %llu exact triangle tests (the launch cannot end before its chain does)\n", h[72], h[73]);
   // grid path: by distance of the packet's first voxel to its seed triangle, in cells: [0,1) [1,2) [2,4) ... [64,inf)
   for (int bk = 0; bk < 8; ++bk) {
     const unsigned long long* q = h + 8 + 8 * bk;

@@ -289,7 +289,37 @@ struct CutList {
   uint32_t log, ny, nz;    // bricks per block per axis = 2^log; blocks along y and z
   uint32_t bx_off;         // grid: this launch covers a piece of the slab the seed lattice and the lists were built for,
                            // starting bx_off bricks into it along x (a multiple of 2^log)
+  const float4* centres;   // generic queries: (centre, radius) of every packet's bounding box (k_qpacket_bounds); one list per packet
 };
+
+// Generic queries: the sorted queries [first, first + cnt) of packet k (table of launch_query_distance / k_qcells).
+__device__ __forceinline__ bool query_packet_range(const uint32_t* __restrict__ table, uint32_t packet, uint32_t n_q,
+                                                   uint32_t* first, uint32_t* cnt) {
+  uint32_t f = packet * 64u, c = 64u;
+  if (table != nullptr) {
+    const uint32_t count = table[0];
+    if (packet >= count) return false;
+    if (table[1] == 0u) {
+      f = table[2u + packet];
+      c = (packet + 1u < count ? table[3u + packet] : n_q) - f;
+    }
+  }
+  if (f >= n_q) return false;
+  *first = f;
+  *cnt = min(c, n_q - f);
+  return true;
+}
+// Cell of the generic path's seed lattice that holds x (k_qlattice).
+__device__ __forceinline__ uint32_t query_lattice_cell(const GridParams& L, float x, float y, float z) {
+  const float q0[3] = {x, y, z};
+  uint32_t cell[3];
+  for (int k = 0; k < 3; ++k) {
+    float f = (q0[k] - L.first[k]) / L.size[k] + 0.5f;
+    f = (f == f) ? fminf(fmaxf(f, 0.0f), (float)(L.n[k] - 1)) : 0.0f;
+    cell[k] = min((uint32_t)f, L.n[k] - 1);
+  }
+  return (cell[0] * L.n[1] + cell[1]) * L.n[2] + cell[2];
+}
 
 // ---- k_packet -------------------------------------------------------------------------------
 // `seed_in` (one TriRec slot per 2^seed_shift bricks per axis, may be null) replaces the greedy descent:
@@ -321,11 +351,15 @@ __global__ __launch_bounds__(256) void k_packet(DeviceMesh mesh, GridParams g, c
     out_index = ((size_t)vox.x * g.n[1] + vox.y) * g.n[2] + vox.z - (size_t)g.out_off;
     store = vox.in_range;
   } else {
-    const uint32_t i = min(packet * 64u + lane, n_q - 1);
+    // generic queries: `plane` carries the packet table of launch_query_distance (k_qcells): [0] packets, [1] mode, [2 + k] the
+    // first sorted query of packet k.  mode 1 (more packets than the launch has waves): 64 consecutive queries per packet.
+    uint32_t first, cnt;
+    if (!query_packet_range(plane, packet, n_q, &first, &cnt)) return;
+    const uint32_t i = first + min((uint32_t)lane, cnt - 1u);
     const float4 q = qsorted[i];
     p = mk3(q.x, q.y, q.z);
     out_index = perm[i];
-    store = packet * 64u + lane < n_q;
+    store = (uint32_t)lane < cnt;
   }
 
   Best<MODE> best;
@@ -340,8 +374,9 @@ __global__ __launch_bounds__(256) void k_packet(DeviceMesh mesh, GridParams g, c
     // evaluation, so that the ~1 us of the miss passes under its 120 instructions instead of in front of the walk.
     const uint32_t* cl = nullptr;
     uint32_t n_ranges = 1;
-    if (GRID && cut.lists != nullptr) {
-      const uint32_t cb = __builtin_amdgcn_readfirstlane((((vox.bx + cut.bx_off) >> cut.log) * cut.ny + (vox.by >> cut.log)) * cut.nz + (vox.bz >> cut.log));
+    if (cut.lists != nullptr) {
+      const uint32_t cb = GRID ? __builtin_amdgcn_readfirstlane((((vox.bx + cut.bx_off) >> cut.log) * cut.ny + (vox.by >> cut.log)) * cut.nz + (vox.bz >> cut.log))
+                               : packet;
       cl = cut.lists + (size_t)cb * CUT_WORDS;
       n_ranges = cl[0] + cl[CUT_WORDS - 1];   // the last word is always 0 (k_cut): it only pulls the second line in
     }
@@ -350,16 +385,14 @@ __global__ __launch_bounds__(256) void k_packet(DeviceMesh mesh, GridParams g, c
       uint32_t sidx = packet;
       if (GRID) {  // 2^seed_shift bricks per axis share one seed point
         sidx = (((vox.bx + cut.bx_off) >> seed_shift) * seed_ny + (vox.by >> seed_shift)) * seed_nz + (vox.bz >> seed_shift);
-      } else {     // generic queries: the lattice cell that holds the packet's first point
+      } else {     // generic queries: the lattice cell that holds the packet's centre (its first point without the packet boxes)
         const GridParams L = *seed_lattice;
-        const float q0[3] = {__shfl(p.x, 0), __shfl(p.y, 0), __shfl(p.z, 0)};
-        uint32_t cell[3];
-        for (int k = 0; k < 3; ++k) {
-          float f = (q0[k] - L.first[k]) / L.size[k] + 0.5f;
-          f = (f == f) ? fminf(fmaxf(f, 0.0f), (float)(L.n[k] - 1)) : 0.0f;
-          cell[k] = min((uint32_t)f, L.n[k] - 1);
+        float q0[3] = {__shfl(p.x, 0), __shfl(p.y, 0), __shfl(p.z, 0)};
+        if (cut.centres != nullptr) {      // the same cell k_cut<false> took this packet's seed from
+          const float4 c = cut.centres[packet];
+          q0[0] = c.x; q0[1] = c.y; q0[2] = c.z;
         }
-        sidx = __builtin_amdgcn_readfirstlane((cell[0] * L.n[1] + cell[1]) * L.n[2] + cell[2]);
+        sidx = __builtin_amdgcn_readfirstlane(query_lattice_cell(L, q0[0], q0[1], q0[2]));
       }
       // one seed per packet: wave-uniform, so the 96-byte record comes through scalar loads
       const uint32_t slot = __builtin_amdgcn_readfirstlane(min(seed_in[sidx], mesh.n_tris - 1));
@@ -466,6 +499,8 @@ __global__ __launch_bounds__(256) void k_packet(DeviceMesh mesh, GridParams g, c
     atomicAdd(&mesh.stats[4], (unsigned long long)st_pruned);
     atomicAdd(&mesh.stats[5], (unsigned long long)st_slab);
     atomicAdd(&mesh.stats[6], (unsigned long long)st_sphere);
+    atomicMax(&mesh.stats[72], (unsigned long long)st_box);
+    atomicMax(&mesh.stats[73], (unsigned long long)st_leaf);
     unsigned long long* q = mesh.stats + 8 + 8 * st_band;
     atomicAdd(&q[0], (unsigned long long)st_box);
     atomicAdd(&q[1], (unsigned long long)st_ext);
@@ -744,6 +779,82 @@ __global__ __launch_bounds__(256) void k_jfa_pass(GridParams g0, const GridParam
   if (ids_out) ids_out[i] = best;
 }
 
+// ---- k_lane_q: the lane walk for generic queries ---------------------------------------------
+// One sorted query per lane, every lane on its own through the tree (as k_lane) and, for the best-of-three-rays sign, through the
+// box tree along each axis.  For SPARSE query sets: a packet of 64 of 100 000 queries in the benchmark box is 44 cells of the 512^3
+// grid wide, the wave-uniform walk pays for the union of what its lanes need (800 node tests and 340 exact evaluations per packet
+// on average, 4 300 and 2 200 for the worst one) and, with fewer packets than the GPU has wave slots, the launch lasts as long as
+// that one wave's chain of dependent loads: 3.2 ms for 100 000 queries, 2.7 ms for 1 M.  A lane alone needs ~60 node tests.
+template <int AXIS>
+__device__ __forceinline__ uint32_t stab_count_lane(const DeviceMesh& mesh, f3 p) {
+  uint32_t count = 0, node = 0;
+  while (node < mesh.n_nodes) {
+    const NodeRec nr = mesh.nodes[node];
+    if (!ray_meets_box<AXIS>(p, mk3(nr.mnx, nr.mny, nr.mnz), mk3(nr.mxx, nr.mxy, nr.mxz))) { node = nr.skip; continue; }
+    if (nr.tri >= 0) {
+      const uint32_t cnt = (nr.skip - node + 1u) >> 1;
+      for (uint32_t k = 0; k < cnt; ++k) {
+        const TriRec& tr = mesh.tris[(uint32_t)nr.tri + k];
+        const f3 a = mk3(tr.ax, tr.ay, tr.az), b = mk3(tr.bx, tr.by, tr.bz), c = mk3(tr.cx, tr.cy, tr.cz);
+        f3 mn, mx;
+        triangle_bounding_box(a, b, c, &mn, &mx);     // the candidate rule is per triangle: ITS padded box
+        float t;
+        const bool h = ray_meets_box<AXIS>(p, mn, mx) && ray_triangle_aligned<AXIS>(p, a, b, c, &t);
+        count += h ? 1u : 0u;
+      }
+      node = nr.skip;
+    } else {
+      node = node + 1;
+    }
+  }
+  return count;
+}
+template <int MODE, int SIGN>
+__global__ __launch_bounds__(256) void k_lane_q(DeviceMesh mesh, const float4* __restrict__ qsorted, const uint32_t* __restrict__ perm,
+                                                uint32_t n_q, float* __restrict__ out, int* __restrict__ err,
+                                                const uint32_t* __restrict__ seed_in, const GridParams* __restrict__ seed_lattice) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_q) return;
+  const float4 q = qsorted[i];
+  const f3 p = mk3(q.x, q.y, q.z);
+  Best<MODE> best;
+  if (mesh.n_nodes) {
+    const float scale = fmaxf(mesh_scale(mesh), fmaxf(fabsf(p.x), fmaxf(fabsf(p.y), fabsf(p.z))));
+    const float slack = 4.0e-6f * scale + (MODE == MODE_NORMAL_FOLD ? 2.5e-6f : 0.0f);
+    uint32_t slot = 0;
+    if (seed_in != nullptr) slot = min(seed_in[query_lattice_cell(*seed_lattice, p.x, p.y, p.z)], mesh.n_tris - 1);
+    eval_triangle<MODE>(best, p, mesh.tris[slot]);
+    float thr = prune_bound(best.d2, slack);
+    constexpr uint32_t NB = (uint32_t)sizeof(NodeExt);
+    const uint32_t end = mesh.n_nodes * NB;
+    const char* ext_bytes = reinterpret_cast<const char*>(mesh.ext);
+    uint32_t off = 0;                                  // per lane
+    while (off < end) {
+      const NodeExt nr = *reinterpret_cast<const NodeExt*>(ext_bytes + off);
+      if (ext_dist2(p, nr) > thr) { off = nr.skip; continue; }
+      if (nr.tri >= 0) {
+        const uint32_t cnt = (nr.skip - off + NB) / (2u * NB);
+        for (uint32_t k = 0; k < cnt; ++k) {
+          if (!(planes_dist2(p, mesh.planes[nr.tri + k]) > thr)) {
+            eval_triangle<MODE>(best, p, mesh.tris[nr.tri + k]);
+            thr = prune_bound(best.d2, slack);
+          }
+        }
+        off = nr.skip;
+      } else {
+        off += NB;
+      }
+    }
+  }
+  bool negate = false;
+  if (MODE == MODE_UNSIGNED && SIGN == SIGN_RAYS3) {
+    const uint32_t cx = stab_count_lane<0>(mesh, p), cy = stab_count_lane<1>(mesh, p), cz = stab_count_lane<2>(mesh, p);
+    negate = ((cx & 1u) + (cy & 1u) + (cz & 1u)) > 1u;                 // bvh.rs:131-141, rtree_bvh.rs:161-171
+  }
+  if (MODE == MODE_NORMAL_FOLD && best.nan) atomicOr(err, ERRF_NAN);
+  out[perm[i]] = finish<MODE>(best, negate);
+}
+
 // ---- k_cut: one wave per 4 x 4 x 4 bricks, lane = brick, one cut list per brick (see CutList) ---------------
 // The 64 bricks of a wave are neighbours, so they visit nearly the same top of the tree: the wave walks it ONCE, like
 // k_packet does (wave-uniform position, node records through scalar loads, a subtree left when no lane keeps it), one
@@ -767,24 +878,39 @@ __global__ __launch_bounds__(256) void k_jfa_pass(GridParams g0, const GridParam
 // Earlier versions (512^3 x blob-100k / the 64-layer slab of an 8-GPU rank; lists per block of 2 x 2 x 2 bricks, sphere
 // test): one lane per block, per-lane record fetches: 0.27 / 0.24 ms; eight lanes per block: 0.40 / 0.15 ms; one wave per
 // eight blocks with scalar record loads: 0.22 / 0.07 ms.
+// GRID = false (generic queries): "brick" = packet of sorted queries, lane = packet, 64 consecutive packets (neighbours in
+// the Morton order) per wave; centre and radius from `centres` (k_qpacket_bounds), the seed from the lattice cell of the
+// centre (as k_packet<false> does), `nbx` = the number of wave slots the packet walk was launched with.
+template <bool GRID>
 __global__ __launch_bounds__(64) void k_cut(DeviceMesh mesh, GridParams g, const uint32_t* __restrict__ seeds, uint32_t seed_shift,
                                             uint32_t seed_ny, uint32_t seed_nz, uint32_t nbx, uint32_t nby, uint32_t nbz,
-                                            uint32_t* __restrict__ lists, float emit_near, float emit_far, uint32_t budget, uint32_t wave_cap) {
+                                            uint32_t* __restrict__ lists, float emit_near, float emit_far, uint32_t budget, uint32_t wave_cap,
+                                            const float4* __restrict__ centres, const uint32_t* __restrict__ table,
+                                            const GridParams* __restrict__ seed_lattice) {
   const uint32_t nsy = (nby + 3u) >> 2, nsz = (nbz + 3u) >> 2;
   const uint32_t sb = blockIdx.x;                            // 4 x 4 x 4 bricks
   const uint32_t sz = sb % nsz, sy = (sb / nsz) % nsy, sx = sb / (nsz * nsy);
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t bk[3] = {4u * sx + (lane >> 4), 4u * sy + ((lane >> 2) & 3u), 4u * sz + (lane & 3u)};
-  const bool in_grid = bk[0] < nbx && bk[1] < nby && bk[2] < nbz;
-  // first cell of the brick in the grid (a brick never straddles two chunks of an interleaved slab: capi.hip checks)
-  const uint32_t cell0[3] = {slab_x(g, bk[0] << g.bl[0]), bk[1] << g.bl[1], bk[2] << g.bl[2]};
+  const uint32_t pk = blockIdx.x * 64u + lane;               // !GRID: this lane's packet
+  bool in_grid = bk[0] < nbx && bk[1] < nby && bk[2] < nbz;
   float r = 0.0f, qq[3];
-  for (int k = 0; k < 3; ++k) {
-    const float hb = 0.5f * (float)((1u << g.bl[k]) - 1u) * fabsf(g.size[k]);   // half extent between voxel centres
-    r = __builtin_fmaf(hb, hb, r);
-    qq[k] = g.first[k] + ((float)cell0[k] + 0.5f * (float)((1u << g.bl[k]) - 1u)) * g.size[k];
+  if (GRID) {
+    // first cell of the brick in the grid (a brick never straddles two chunks of an interleaved slab: capi.hip checks)
+    const uint32_t cell0[3] = {slab_x(g, bk[0] << g.bl[0]), bk[1] << g.bl[1], bk[2] << g.bl[2]};
+    for (int k = 0; k < 3; ++k) {
+      const float hb = 0.5f * (float)((1u << g.bl[k]) - 1u) * fabsf(g.size[k]);   // half extent between voxel centres
+      r = __builtin_fmaf(hb, hb, r);
+      qq[k] = g.first[k] + ((float)cell0[k] + 0.5f * (float)((1u << g.bl[k]) - 1u)) * g.size[k];
+    }
+    r = sqrtf(r) * 1.0001f;
+  } else {
+    in_grid = pk < nbx && pk < table[0];
+    const float4 c = centres[in_grid ? pk : 0u];
+    qq[0] = c.x; qq[1] = c.y; qq[2] = c.z;
+    r = c.w;                                                 // already rounded up; NaN / inf (non-finite queries): nothing is dropped
+    if (!(r < 3.0e37f)) r = __builtin_inff();
   }
-  r = sqrtf(r) * 1.0001f;
   const f3 q = mk3(qq[0], qq[1], qq[2]);
   const float scale = fmaxf(mesh_scale(mesh), fmaxf(fabsf(q.x), fmaxf(fabsf(q.y), fabsf(q.z))) + r);
   const float abs_margin = 6.4e-5f * scale + 4.0e-5f;        // the packet walk's own slack is <= 4e-6 * scale + 2.5e-6
@@ -792,7 +918,9 @@ __global__ __launch_bounds__(64) void k_cut(DeviceMesh mesh, GridParams g, const
   f3 e = mk3(0.0f, 0.0f, 0.0f);
   float grad_c0 = __builtin_inff(), grad_c1 = 0.0f;          // gradient test: drop if L * (1 - 1e-4) - grad_c0 > grad_c1 * |n - e|
   if (in_grid) {
-    const uint32_t slot = min(seeds[((bk[0] >> seed_shift) * seed_ny + (bk[1] >> seed_shift)) * seed_nz + (bk[2] >> seed_shift)], mesh.n_tris - 1);
+    const uint32_t sidx = GRID ? ((bk[0] >> seed_shift) * seed_ny + (bk[1] >> seed_shift)) * seed_nz + (bk[2] >> seed_shift)
+                               : query_lattice_cell(*seed_lattice, q.x, q.y, q.z);
+    const uint32_t slot = min(seeds[sidx], mesh.n_tris - 1);
     const TriRec& t = mesh.tris[slot];
     const f3 a = mk3(t.ax, t.ay, t.az), bq = mk3(t.bx, t.by, t.bz), c = mk3(t.cx, t.cy, t.cz);
     const TriEdges ed = {mk3(t.abx, t.aby, t.abz), mk3(t.acx, t.acy, t.acz), mk3(t.bcx, t.bcy, t.bcz)};
@@ -814,7 +942,7 @@ __global__ __launch_bounds__(64) void k_cut(DeviceMesh mesh, GridParams g, const
 
   constexpr uint32_t NB = (uint32_t)sizeof(NodeExt);
   const uint32_t end = mesh.n_nodes * NB;
-  uint32_t* out = lists + ((size_t)(in_grid ? (bk[0] * nby + bk[1]) * nbz + bk[2] : 0u)) * CUT_WORDS;
+  uint32_t* out = lists + ((size_t)(in_grid ? (GRID ? (bk[0] * nby + bk[1]) * nbz + bk[2] : pk) : 0u)) * CUT_WORDS;
   uint32_t n = 0, last_start = 0, last_end = 0, resume = 0, opened = 0;   // per lane
   uint32_t off = 0, steps = 0;                                // wave-uniform
   while (off < end) {
@@ -992,17 +1120,20 @@ __global__ __launch_bounds__(256) void k_qbounds_final(const int* __restrict__ p
     for (int k = 0; k < 3; ++k) { lo[k] = min(lo[k], partial[6 * j + k]); hi[k] = max(hi[k], partial[6 * j + 3 + k]); }
   qb_block_reduce(lo, hi, b);
 }
-__device__ __forceinline__ uint64_t expand21q(uint32_t v) {
-  uint64_t x = v & 0x1fffffu;
-  x = (x | x << 32) & 0x1f00000000ffffull;
-  x = (x | x << 16) & 0x1f0000ff0000ffull;
-  x = (x | x << 8) & 0x100f00f00f00f00full;
-  x = (x | x << 4) & 0x10c30c30c30c30c3ull;
-  x = (x | x << 2) & 0x1249249249249249ull;
+// 30-bit Morton key of a query in the query bounding box (10 bits per axis: 1024^3 cells — far finer than a packet of 64 of
+// any realistic query count, and a 32-bit key sorts in four radix passes instead of the eight of the 63-bit key used before:
+// 0.83 -> 0.45 ms for 10 M queries).  Queries of one cell keep their input order among themselves.
+constexpr int QKEY_BITS = 30;
+__device__ __forceinline__ uint32_t expand10q(uint32_t v) {
+  uint32_t x = v & 0x3ffu;
+  x = (x | x << 16) & 0x030000ffu;
+  x = (x | x << 8) & 0x0300f00fu;
+  x = (x | x << 4) & 0x030c30c3u;
+  x = (x | x << 2) & 0x09249249u;
   return x;
 }
 __global__ __launch_bounds__(256) void k_qkeys(const float* __restrict__ q, uint32_t n_q, const int* __restrict__ b,
-                                               uint64_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+                                               uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_q) return;
   uint32_t c[3];
@@ -1010,9 +1141,9 @@ __global__ __launch_bounds__(256) void k_qkeys(const float* __restrict__ q, uint
     const float lo = unordf(b[k]), hi = unordf(b[3 + k]);
     float u = (q[3 * (size_t)i + k] - lo) / (hi - lo);
     u = (u == u) ? fminf(fmaxf(u, 0.0f), 1.0f) : 0.0f;
-    c[k] = min((uint32_t)(u * 2097152.0f), 2097151u);
+    c[k] = min((uint32_t)(u * 1024.0f), 1023u);
   }
-  keys[i] = (expand21q(c[0]) << 2) | (expand21q(c[1]) << 1) | expand21q(c[2]);
+  keys[i] = (expand10q(c[0]) << 2) | (expand10q(c[1]) << 1) | expand10q(c[2]);
   vals[i] = i;
 }
 // Seed lattice for generic queries: QL^3 cells over the query bounding box (description kept on the device).
@@ -1040,11 +1171,81 @@ __global__ __launch_bounds__(256) void k_qgather(const float* __restrict__ q, co
   sorted[i] = make_float4(q[3 * s], q[3 * s + 1], q[3 * s + 2], 0.0f);
 }
 
+// Packets of the generic path.  64 CONSECUTIVE queries of the Morton order are a loose group (the run straddles cell
+// boundaries of every level: bounding radius 1.6 x that of a cube holding 64 uniform points, r^2 2.9 x) and the wave-uniform
+// walk pays for the union of what its 64 lanes need.  The packets are therefore the LEAVES OF THE BUCKET K-D TREE over the
+// keys, capacity 64: the largest key-prefix cells holding at most 64 queries — aligned boxes of aspect <= 2, 46 queries on
+// average for uniform points (1.38 x the packets, radius 0.88, r^2 0.78 of that cube's).  No tree is built: with
+// w[j] = common prefix length of keys j and j + 64, query i sits in an over-full cell of prefix length b iff some window
+// j in [i - 64, i] has w[j] >= b, so its leaf has prefix length m(i) + 1, m(i) = max of w over those windows, the same for
+// every query of the leaf; i starts a packet iff it differs from i - 1 within that prefix.  More than 64 queries with
+// identical keys (m = QKEY_BITS) are cut at multiples of 64.
+__global__ __launch_bounds__(256) void k_qcells(const uint32_t* __restrict__ keys, uint32_t n, uint8_t* __restrict__ head) {
+  __shared__ uint32_t sk[256 + 128];   // keys[base - 64, base + 320)
+  __shared__ int sw[256 + 64];         // w[j], j in [base - 64, base + 256)
+  const long long base = (long long)blockIdx.x * 256;
+  for (uint32_t t = threadIdx.x; t < 384u; t += 256u) {
+    const long long idx = base - 64 + t;
+    sk[t] = (idx >= 0 && idx < (long long)n) ? keys[idx] : 0u;
+  }
+  __syncthreads();
+  for (uint32_t t = threadIdx.x; t < 320u; t += 256u) {
+    const long long j = base - 64 + t;
+    const uint32_t x = sk[t] ^ sk[t + 64];
+    sw[t] = (j >= 0 && j + 64 < (long long)n) ? (x == 0u ? QKEY_BITS : __clz((int)x) - (32 - QKEY_BITS)) : -1;
+  }
+  __syncthreads();
+  const long long i = base + threadIdx.x;
+  if (i >= (long long)n) return;
+  int m = -1;
+  for (uint32_t t = 0; t <= 64u; ++t) m = max(m, sw[threadIdx.x + t]);
+  const uint32_t plen = (uint32_t)min(m + 1, QKEY_BITS);
+  const uint32_t key = sk[threadIdx.x + 64], prev = sk[threadIdx.x + 63];
+  bool h = i == 0 || (plen != 0u && ((key ^ prev) >> ((uint32_t)QKEY_BITS - plen)) != 0u);
+  if (m >= QKEY_BITS) h |= (i & 63) == 0;                   // more than 64 queries in one cell of the finest level
+  head[i] = h ? 1 : 0;
+}
+__global__ void k_qtable_mode(uint32_t* __restrict__ table, uint32_t n, uint32_t launched) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const bool over = table[0] > launched;                    // cannot be ruled out (63 levels of 1 + 64 splits): consecutive packets then
+  table[1] = over ? 1u : 0u;
+  if (over) table[0] = (n + 63u) / 64u;
+}
+
+// (centre, radius) of the bounding box of every packet's queries: one wave per packet.  The radius is rounded up; a packet
+// with a non-finite coordinate gets radius inf (its cut list then keeps the whole tree).
+__global__ __launch_bounds__(256) void k_qpacket_bounds(const float4* __restrict__ sorted, const uint32_t* __restrict__ table,
+                                                        uint32_t n_q, uint32_t launched, float4* __restrict__ centres) {
+  const uint32_t packet = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+  if (packet >= launched) return;
+  uint32_t first, cnt;
+  if (!query_packet_range(table, packet, n_q, &first, &cnt)) return;
+  const float4 v = sorted[first + min(lane, cnt - 1u)];
+  float lo[3] = {v.x, v.y, v.z}, hi[3] = {v.x, v.y, v.z};
+  bool bad = !(fabsf(v.x) < 3.0e37f) | !(fabsf(v.y) < 3.0e37f) | !(fabsf(v.z) < 3.0e37f);
+  for (int o = 32; o >= 1; o >>= 1)
+    for (int k = 0; k < 3; ++k) {
+      lo[k] = fminf(lo[k], __shfl_xor(lo[k], o));
+      hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], o));
+    }
+  bad = __ballot(bad) != 0ull;
+  if (lane != 0u) return;
+  float c[3], r2 = 0.0f;
+  for (int k = 0; k < 3; ++k) {
+    c[k] = 0.5f * lo[k] + 0.5f * hi[k];
+    const float h = fmaxf(hi[k] - c[k], c[k] - lo[k]);
+    r2 = __builtin_fmaf(h, h, r2);
+  }
+  float r = sqrtf(r2) * 1.0001f + 1.0e-30f;
+  if (bad) { c[0] = c[1] = c[2] = 0.0f; r = __builtin_inff(); }
+  centres[packet] = make_float4(c[0], c[1], c[2], r);
+}
+
 template <bool GRID, int MODE, int SIGN>
 void launch_packet(hipStream_t st, const DeviceMesh& mesh, const GridParams& g, const float4* qs, const uint32_t* perm,
                    uint32_t n_q, const uint32_t* plane, float* out, int* err, uint32_t n_packets,
                    const uint32_t* seed_in = nullptr, uint32_t seed_shift = 0, uint32_t seed_ny = 0,
-                   uint32_t seed_nz = 0, const GridParams* seed_lattice = nullptr, CutList cut = {nullptr, 0, 0, 0, 0},
+                   uint32_t seed_nz = 0, const GridParams* seed_lattice = nullptr, CutList cut = {nullptr, 0, 0, 0, 0, nullptr},
                    const PeerOut* peers_in = nullptr) {
   PeerOut peers{};
   if (peers_in) peers = *peers_in;
@@ -1212,7 +1413,7 @@ int prepare_grid_walk(Arena& ws, hipStream_t st, const DeviceMesh& mesh, const G
   const double surface_bricks = 6.0 * pow((double)packets, 2.0 / 3.0);
   const bool lane_walk = !brute && mesh.n_tris && (lane_env >= 0 ? lane_env == 1 : (double)mesh.n_tris > 60.0 * surface_bricks);   // measured crossover: 40 per brick favours the packet walk, 65 the lane walk
   // cut lists: the top of the tree is walked once per block of 2^log bricks per axis (k_cut)
-  CutList cut = {nullptr, 0, 0, 0, 0};
+  CutList cut = {nullptr, 0, 0, 0, 0, nullptr};
   // k_cut costs about 0.25 us per brick plus a latency floor of ~0.1 ms; measured crossover (blob-100k / blob-6k,
   // tools/exp_cutmin.py): 192^3 = 110 592 packets loses 0.1-0.2 ms with the lists, 256^3 = 262 144 packets breaks even or
   // gains, 512^3 gains 1.3 ms.  Read per call: the tests lower it to cover small grids.
@@ -1237,8 +1438,9 @@ int prepare_grid_walk(Arena& ws, hipStream_t st, const DeviceMesh& mesh, const G
     uint32_t* lists = ws.take<uint32_t>(bricks * CUT_WORDS);
     if (!lists) { set_error("internal: cut-list workspace too small"); return M2S_ERR_HIP_INTERNAL; }
     const size_t waves = (size_t)bricks_along(nbx, 2) * bricks_along(nby, 2) * bricks_along(nbz, 2);
-    hipLaunchKernelGGL(k_cut, dim3((unsigned)waves), dim3(64), 0, st, mesh, g, seed1, sh1, s1ny, s1nz, nbx, nby, nbz, lists, emit_near, emit_far, budget, wave_cap);
-    cut = {lists, 0, nby, nbz, 0};
+    hipLaunchKernelGGL(k_cut<true>, dim3((unsigned)waves), dim3(64), 0, st, mesh, g, seed1, sh1, s1ny, s1nz, nbx, nby, nbz, lists, emit_near, emit_far, budget, wave_cap,
+                       (const float4*)nullptr, (const uint32_t*)nullptr, (const GridParams*)nullptr);
+    cut = {lists, 0, nby, nbz, 0, nullptr};
   }
   plan->seeds = seed1; plan->seed_shift = sh1; plan->seed_ny = s1ny; plan->seed_nz = s1nz;
   plan->cut_lists = cut.lists; plan->cut_log = cut.log; plan->cut_ny = cut.ny; plan->cut_nz = cut.nz;
@@ -1288,7 +1490,7 @@ int launch_grid_walk(hipStream_t st, const DeviceMesh& mesh, const GridParams& g
   const bool brute = algorithm == 1;
   const uint32_t* seed1 = plan.seeds;
   const uint32_t sh1 = plan.seed_shift, s1ny = plan.seed_ny, s1nz = plan.seed_nz;
-  const CutList cut = {plan.cut_lists, plan.cut_log, plan.cut_ny, plan.cut_nz, bx_off};
+  const CutList cut = {plan.cut_lists, plan.cut_log, plan.cut_ny, plan.cut_nz, bx_off, nullptr};
   if (plan.lane_walk) {
     const unsigned blocks = (packets + 3) / 4;
     if (mode == MODE_UNSIGNED && d_inside_plane)
@@ -1330,9 +1532,11 @@ int launch_grid_distance(Arena& ws, hipStream_t st, const DeviceMesh& mesh, cons
 
 size_t query_workspace_bytes(size_t n_q) {
   size_t n = n_q ? n_q : 1, tmp = 0;
-  (void)rocprim::radix_sort_pairs(nullptr, tmp, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr,
-                            n, 0, 64, (hipStream_t)0);
-  return n * (8 + 8 + 4 + 4 + 16) + tmp + 16 * 256 + (size_t)64 * 64 * 64 * 44 + 8192 + 24 * 1024 + 256;
+  (void)rocprim::radix_sort_pairs(nullptr, tmp, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr,
+                            n, 0, 30, (hipStream_t)0);
+  size_t sel = 0;
+  (void)rocprim::select(nullptr, sel, rocprim::counting_iterator<uint32_t>(0), (uint8_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, n, (hipStream_t)0);
+  return n * (8 + 8 + 4 + 4 + 16 + 1 + 4) + (n / 32 + 64) * (16 + 4 * CUT_WORDS) + tmp + sel + 21 * 256 + (size_t)64 * 64 * 64 * 44 + 8192 + 24 * 1024 + 256;
 }
 
 int launch_query_distance(Arena& ws, hipStream_t st, const DeviceMesh& mesh, const float* d_queries, size_t n_q,
@@ -1352,13 +1556,13 @@ int launch_query_distance(Arena& ws, hipStream_t st, const DeviceMesh& mesh, con
   }
   // Morton order
   int* qb = ws.take<int>(8 + 6 * QB_BLOCKS);
-  uint64_t* keys = ws.take<uint64_t>(n_q);
-  uint64_t* keys2 = ws.take<uint64_t>(n_q);
+  uint32_t* keys = ws.take<uint32_t>(n_q);
+  uint32_t* keys2 = ws.take<uint32_t>(n_q);
   uint32_t* vals = ws.take<uint32_t>(n_q);
   uint32_t* perm = ws.take<uint32_t>(n_q);
   float4* sorted = ws.take<float4>(n_q);
   size_t tmp_bytes = 0;
-  (void)rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys, keys2, vals, perm, n_q, 0, 64, st);
+  (void)rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys, keys2, vals, perm, n_q, 0, QKEY_BITS, st);
   void* tmp = ws.take<char>(tmp_bytes ? tmp_bytes : 1);
   if (!qb || !keys || !keys2 || !vals || !perm || !sorted || !tmp) {
     set_error("internal: query workspace too small");
@@ -1369,8 +1573,34 @@ int launch_query_distance(Arena& ws, hipStream_t st, const DeviceMesh& mesh, con
   hipLaunchKernelGGL(k_qbounds, dim3(qblocks), dim3(B), 0, st, d_queries, nq, qb + 8);
   hipLaunchKernelGGL(k_qbounds_final, dim3(1), dim3(B), 0, st, qb + 8, qblocks, qb);
   hipLaunchKernelGGL(k_qkeys, dim3(nb), dim3(B), 0, st, d_queries, nq, qb, keys, vals);
-  M2S_HIP_CHECK(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, keys2, vals, perm, n_q, 0, 63, st));
+  M2S_HIP_CHECK(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, keys2, vals, perm, n_q, 0, QKEY_BITS, st));
   hipLaunchKernelGGL(k_qgather, dim3(nb), dim3(B), 0, st, d_queries, perm, nq, sorted);
+  // Sparse query sets take the lane walk (k_lane_q).  Measured crossover, uniform queries in the extended box (lane / packet walk,
+  // RtreeBvh): blob-100k 100 k queries 1.36 / 3.65 ms, 1 M 2.70 / 3.45, 3 M 5.00 / 4.38, 10 M 12.3 / 6.7 (crossover ~2 M);
+  // blob-1M 1 M 6.3 / 12.8 ms, 10 M 26.4 / 22.4 (~7 M).  Below it the packet walk lasts as long as its worst packet's chain of
+  // dependent loads (2.7 ms), above it the lane walk's divergence costs more than the packets' union.  n* ~ 3500 T^0.55 fits both.
+  static const int lane_env = getenv("M2S_LANE_WALK") ? atoi(getenv("M2S_LANE_WALK")) : -1;   // -1 auto, 0 never, 1 always
+  const double lane_coeff = getenv("M2S_QUERY_LANE_COEFF") ? atof(getenv("M2S_QUERY_LANE_COEFF")) : 3500.0;
+  const bool lane_walk = mesh.n_tris && sign_src != SIGN_XRAY_ALL &&
+                         (lane_env >= 0 ? lane_env == 1 : (double)n_q < lane_coeff * pow((double)mesh.n_tris, 0.55));
+  // packets = leaves of the bucket k-d tree over the sorted keys (k_qcells); the launch has room for twice the consecutive
+  // count, and k_qtable_mode falls back to consecutive packets should there be more
+  const uint32_t* table = nullptr;
+  uint32_t launched = packets;
+  static const bool bucket_packets = !(getenv("M2S_QUERY_CELLS") && atoi(getenv("M2S_QUERY_CELLS")) == 0);
+  if (bucket_packets && !lane_walk) {
+    launched = nq / 32u + 64u;
+    uint8_t* head = ws.take<uint8_t>(n_q);
+    uint32_t* tb = ws.take<uint32_t>(n_q + 2);               // [0] count, [1] mode, then one start per head (at most n_q)
+    size_t sel_bytes = 0;
+    (void)rocprim::select(nullptr, sel_bytes, rocprim::counting_iterator<uint32_t>(0), head, tb + 2, tb, n_q, st);
+    void* sel_tmp = ws.take<char>(sel_bytes ? sel_bytes : 1);
+    if (!head || !tb || !sel_tmp) { set_error("internal: query workspace too small"); return M2S_ERR_HIP_INTERNAL; }
+    hipLaunchKernelGGL(k_qcells, dim3(nb), dim3(B), 0, st, keys2, nq, head);
+    M2S_HIP_CHECK(rocprim::select(sel_tmp, sel_bytes, rocprim::counting_iterator<uint32_t>(0), head, tb + 2, tb, n_q, st));
+    hipLaunchKernelGGL(k_qtable_mode, dim3(1), dim3(1), 0, st, tb, nq, launched);
+    table = tb;
+  }
   // seeds: jump flooding over a QL^3 lattice on the query bounding box (as for the grid path)
   const uint32_t* seeds = nullptr;
   const GridParams* d_lat = nullptr;
@@ -1397,10 +1627,37 @@ int launch_query_distance(Arena& ws, hipStream_t st, const DeviceMesh& mesh, con
     seeds = ids;
     d_lat = lat;
   }
-  if (mode == MODE_UNSIGNED && sign_src == SIGN_RAYS3) launch_packet<false, MODE_UNSIGNED, SIGN_RAYS3>(st, mesh, g, sorted, perm, nq, nullptr, d_out, d_err, packets, seeds, 0, 0, 0, d_lat);
-  else if (mode == MODE_UNSIGNED) launch_packet<false, MODE_UNSIGNED, SIGN_NONE>(st, mesh, g, sorted, perm, nq, nullptr, d_out, d_err, packets, seeds, 0, 0, 0, d_lat);
-  else if (mode == MODE_NORMAL_FOLD) launch_packet<false, MODE_NORMAL_FOLD, SIGN_NONE>(st, mesh, g, sorted, perm, nq, nullptr, d_out, d_err, packets, seeds, 0, 0, 0, d_lat);
-  else launch_packet<false, MODE_NEAREST_NORMAL, SIGN_NONE>(st, mesh, g, sorted, perm, nq, nullptr, d_out, d_err, packets, seeds, 0, 0, 0, d_lat);
+  // cut lists, one per packet (k_cut<false>): the top of the tree is walked once per 64 neighbouring packets
+  CutList cut = {nullptr, 0, 0, 0, 0, nullptr};
+  const uint32_t qcut_min = getenv("M2S_QUERY_CUT_MIN") ? (uint32_t)atoi(getenv("M2S_QUERY_CUT_MIN")) : 20000u;
+  static const int cut_env = getenv("M2S_CUT") ? atoi(getenv("M2S_CUT")) : 1;
+  if (table != nullptr && seeds != nullptr && cut_env > 0 && packets >= qcut_min) {
+    float4* centres = ws.take<float4>(launched);
+    uint32_t* lists = ws.take<uint32_t>((size_t)launched * CUT_WORDS);
+    if (!centres || !lists) { set_error("internal: query workspace too small"); return M2S_ERR_HIP_INTERNAL; }
+    const float emit_near = getenv("M2S_CUT_NEAR") ? (float)atof(getenv("M2S_CUT_NEAR")) : 2.0f;
+    const float emit_far = getenv("M2S_CUT_FAR") ? (float)atof(getenv("M2S_CUT_FAR")) : 1.0f / 16.0f;
+    uint32_t depth = 1;
+    while ((1ull << depth) < (unsigned long long)mesh.n_tris + 1ull) ++depth;
+    const uint32_t wave_cap = getenv("M2S_CUT_WAVE_CAP") ? (uint32_t)atoi(getenv("M2S_CUT_WAVE_CAP")) : std::max(120u, 20u * depth);
+    hipLaunchKernelGGL(k_qpacket_bounds, dim3((launched + 3) / 4), dim3(256), 0, st, sorted, table, nq, launched, centres);
+    hipLaunchKernelGGL(k_cut<false>, dim3((launched + 63) / 64), dim3(64), 0, st, mesh, g, seeds, 0u, 0u, 0u, launched, 1u, 1u, lists,
+                       emit_near, emit_far, 100000u, wave_cap, (const float4*)centres, table, d_lat);
+    cut = {lists, 0, 0, 0, 0, centres};
+  }
+  if (lane_walk) {
+    const unsigned lb = (nq + 255u) / 256u;
+    if (mode == MODE_UNSIGNED && sign_src == SIGN_RAYS3) hipLaunchKernelGGL((k_lane_q<MODE_UNSIGNED, SIGN_RAYS3>), dim3(lb), dim3(256), 0, st, mesh, (const float4*)sorted, (const uint32_t*)perm, nq, d_out, d_err, seeds, d_lat);
+    else if (mode == MODE_UNSIGNED) hipLaunchKernelGGL((k_lane_q<MODE_UNSIGNED, SIGN_NONE>), dim3(lb), dim3(256), 0, st, mesh, (const float4*)sorted, (const uint32_t*)perm, nq, d_out, d_err, seeds, d_lat);
+    else if (mode == MODE_NORMAL_FOLD) hipLaunchKernelGGL((k_lane_q<MODE_NORMAL_FOLD, SIGN_NONE>), dim3(lb), dim3(256), 0, st, mesh, (const float4*)sorted, (const uint32_t*)perm, nq, d_out, d_err, seeds, d_lat);
+    else hipLaunchKernelGGL((k_lane_q<MODE_NEAREST_NORMAL, SIGN_NONE>), dim3(lb), dim3(256), 0, st, mesh, (const float4*)sorted, (const uint32_t*)perm, nq, d_out, d_err, seeds, d_lat);
+    M2S_HIP_CHECK(hipGetLastError());
+    return 0;
+  }
+  if (mode == MODE_UNSIGNED && sign_src == SIGN_RAYS3) launch_packet<false, MODE_UNSIGNED, SIGN_RAYS3>(st, mesh, g, sorted, perm, nq, table, d_out, d_err, launched, seeds, 0, 0, 0, d_lat, cut);
+  else if (mode == MODE_UNSIGNED) launch_packet<false, MODE_UNSIGNED, SIGN_NONE>(st, mesh, g, sorted, perm, nq, table, d_out, d_err, launched, seeds, 0, 0, 0, d_lat, cut);
+  else if (mode == MODE_NORMAL_FOLD) launch_packet<false, MODE_NORMAL_FOLD, SIGN_NONE>(st, mesh, g, sorted, perm, nq, table, d_out, d_err, launched, seeds, 0, 0, 0, d_lat, cut);
+  else launch_packet<false, MODE_NEAREST_NORMAL, SIGN_NONE>(st, mesh, g, sorted, perm, nq, table, d_out, d_err, launched, seeds, 0, 0, 0, d_lat, cut);
   M2S_HIP_CHECK(hipGetLastError());
   return 0;
 }
