@@ -618,6 +618,28 @@ __global__ __launch_bounds__(256) void k_push_cells(const float* __restrict__ sr
   }
 }
 
+// Per-lane greedy descent (towards the child box nearer to p) and evaluation of the leaf it ends in: a second starting candidate for
+// the lane walks.  Their lattice seed is only as good as the lattice is fine — one point per 4^3 voxels of a 16^3 grid is 64 seeds
+// for the whole box — and a lane that starts with a loose bound walks long: the launch lasts as long as its slowest lane.
+template <int MODE>
+__device__ __forceinline__ void greedy_leaf(const DeviceMesh& mesh, f3 p, Best<MODE>& best) {
+  uint32_t n = 0;
+  NodeRec nr = mesh.nodes[0];
+  while (nr.tri < 0) {
+    const uint32_t l = n + 1;
+    const NodeRec nl = mesh.nodes[l];
+    const uint32_t r = nl.skip;
+    const NodeRec nrr = mesh.nodes[r];
+    const float dl = box_dist2(p, nl.mnx, nl.mny, nl.mnz, nl.mxx, nl.mxy, nl.mxz);
+    const float dr = box_dist2(p, nrr.mnx, nrr.mny, nrr.mnz, nrr.mxx, nrr.mxy, nrr.mxz);
+    const bool go_left = dl <= dr;
+    n = go_left ? l : r;
+    nr = go_left ? nl : nrr;
+  }
+  const uint32_t cnt = (nr.skip - n + 1u) >> 1;
+  for (uint32_t k = 0; k < cnt; ++k) eval_triangle<MODE>(best, p, mesh.tris[(uint32_t)nr.tri + k]);
+}
+
 // ---- k_lane ---------------------------------------------------------------------------------
 // One VOXEL per lane, every lane walking the tree on its own (per-lane offsets, records by vector gathers).
 // For the opposite regime of k_packet: when the triangles are much smaller than the voxels (a 1 M-triangle
@@ -629,7 +651,7 @@ template <int MODE, int SIGN>
 __global__ __launch_bounds__(256) void k_lane(DeviceMesh mesh, GridParams g, const uint32_t* __restrict__ plane,
                                               float* __restrict__ out, int* __restrict__ err, uint32_t n_packets,
                                               const uint32_t* __restrict__ seed_in, uint32_t seed_shift, uint32_t seed_ny, uint32_t seed_nz,
-                                              uint32_t bx_off, PeerOut peers) {
+                                              uint32_t bx_off, PeerOut peers, bool greedy) {
   const int lane = threadIdx.x & 63;
   const uint32_t packet = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (packet >= n_packets) return;
@@ -646,13 +668,16 @@ __global__ __launch_bounds__(256) void k_lane(DeviceMesh mesh, GridParams g, con
     if (seed_in != nullptr)
       slot = min(seed_in[(((vox.bx + bx_off) >> seed_shift) * seed_ny + (vox.by >> seed_shift)) * seed_nz + (vox.bz >> seed_shift)], mesh.n_tris - 1);
     eval_triangle<MODE>(best, p, mesh.tris[slot]);
+    if (greedy) greedy_leaf<MODE>(mesh, p, best);
     float thr = prune_bound(best.d2, slack);
     constexpr uint32_t NB = (uint32_t)sizeof(NodeExt);
     const uint32_t end = mesh.n_nodes * NB;
     const char* ext_bytes = reinterpret_cast<const char*>(mesh.ext);
     uint32_t off = 0;                                  // per lane
+    uint32_t st_nodes = 0, st_exact = 0;               // M2S_STATS
     while (off < end) {
       const NodeExt nr = *reinterpret_cast<const NodeExt*>(ext_bytes + off);
+      ++st_nodes;
       if (ext_dist2(p, nr) > thr) { off = nr.skip; continue; }
       if (nr.tri >= 0) {
         const uint32_t cnt = (nr.skip - off + NB) / (2u * NB);
@@ -660,12 +685,20 @@ __global__ __launch_bounds__(256) void k_lane(DeviceMesh mesh, GridParams g, con
           if (!(planes_dist2(p, mesh.planes[nr.tri + k]) > thr)) {
             eval_triangle<MODE>(best, p, mesh.tris[nr.tri + k]);
             thr = prune_bound(best.d2, slack);
+            ++st_exact;
           }
         }
         off = nr.skip;
       } else {
         off += NB;
       }
+    }
+    if (mesh.stats != nullptr) {                       // per lane: the lane walk's unit is the lane
+      atomicAdd(&mesh.stats[0], (unsigned long long)st_nodes);
+      atomicAdd(&mesh.stats[2], (unsigned long long)st_exact);
+      atomicAdd(&mesh.stats[3], 1ull);
+      atomicMax(&mesh.stats[72], (unsigned long long)st_nodes);
+      atomicMax(&mesh.stats[73], (unsigned long long)st_exact);
     }
   }
   bool negate = false;
@@ -812,7 +845,7 @@ __device__ __forceinline__ uint32_t stab_count_lane(const DeviceMesh& mesh, f3 p
 template <int MODE, int SIGN>
 __global__ __launch_bounds__(256) void k_lane_q(DeviceMesh mesh, const float4* __restrict__ qsorted, const uint32_t* __restrict__ perm,
                                                 uint32_t n_q, float* __restrict__ out, int* __restrict__ err,
-                                                const uint32_t* __restrict__ seed_in, const GridParams* __restrict__ seed_lattice) {
+                                                const uint32_t* __restrict__ seed_in, const GridParams* __restrict__ seed_lattice, bool greedy) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_q) return;
   const float4 q = qsorted[i];
@@ -824,13 +857,16 @@ __global__ __launch_bounds__(256) void k_lane_q(DeviceMesh mesh, const float4* _
     uint32_t slot = 0;
     if (seed_in != nullptr) slot = min(seed_in[query_lattice_cell(*seed_lattice, p.x, p.y, p.z)], mesh.n_tris - 1);
     eval_triangle<MODE>(best, p, mesh.tris[slot]);
+    if (greedy) greedy_leaf<MODE>(mesh, p, best);
     float thr = prune_bound(best.d2, slack);
     constexpr uint32_t NB = (uint32_t)sizeof(NodeExt);
     const uint32_t end = mesh.n_nodes * NB;
     const char* ext_bytes = reinterpret_cast<const char*>(mesh.ext);
     uint32_t off = 0;                                  // per lane
+    uint32_t st_nodes = 0, st_exact = 0;               // M2S_STATS
     while (off < end) {
       const NodeExt nr = *reinterpret_cast<const NodeExt*>(ext_bytes + off);
+      ++st_nodes;
       if (ext_dist2(p, nr) > thr) { off = nr.skip; continue; }
       if (nr.tri >= 0) {
         const uint32_t cnt = (nr.skip - off + NB) / (2u * NB);
@@ -838,12 +874,20 @@ __global__ __launch_bounds__(256) void k_lane_q(DeviceMesh mesh, const float4* _
           if (!(planes_dist2(p, mesh.planes[nr.tri + k]) > thr)) {
             eval_triangle<MODE>(best, p, mesh.tris[nr.tri + k]);
             thr = prune_bound(best.d2, slack);
+            ++st_exact;
           }
         }
         off = nr.skip;
       } else {
         off += NB;
       }
+    }
+    if (mesh.stats != nullptr) {                       // per lane: the lane walk's unit is the lane
+      atomicAdd(&mesh.stats[0], (unsigned long long)st_nodes);
+      atomicAdd(&mesh.stats[2], (unsigned long long)st_exact);
+      atomicAdd(&mesh.stats[3], 1ull);
+      atomicMax(&mesh.stats[72], (unsigned long long)st_nodes);
+      atomicMax(&mesh.stats[73], (unsigned long long)st_exact);
     }
   }
   bool negate = false;
@@ -1493,12 +1537,13 @@ int launch_grid_walk(hipStream_t st, const DeviceMesh& mesh, const GridParams& g
   const CutList cut = {plan.cut_lists, plan.cut_log, plan.cut_ny, plan.cut_nz, bx_off, nullptr};
   if (plan.lane_walk) {
     const unsigned blocks = (packets + 3) / 4;
+    const bool lane_greedy = getenv("M2S_LANE_GREEDY") ? atoi(getenv("M2S_LANE_GREEDY")) != 0 : true;
     if (mode == MODE_UNSIGNED && d_inside_plane)
-      hipLaunchKernelGGL((k_lane<MODE_UNSIGNED, SIGN_GRID_PLANE>), dim3(blocks), dim3(256), 0, st, mesh, g, d_inside_plane, d_out, d_err, packets, seed1, sh1, s1ny, s1nz, bx_off, pz);
+      hipLaunchKernelGGL((k_lane<MODE_UNSIGNED, SIGN_GRID_PLANE>), dim3(blocks), dim3(256), 0, st, mesh, g, d_inside_plane, d_out, d_err, packets, seed1, sh1, s1ny, s1nz, bx_off, pz, lane_greedy);
     else if (mode == MODE_UNSIGNED)
-      hipLaunchKernelGGL((k_lane<MODE_UNSIGNED, SIGN_NONE>), dim3(blocks), dim3(256), 0, st, mesh, g, nullptr, d_out, d_err, packets, seed1, sh1, s1ny, s1nz, bx_off, pz);
+      hipLaunchKernelGGL((k_lane<MODE_UNSIGNED, SIGN_NONE>), dim3(blocks), dim3(256), 0, st, mesh, g, nullptr, d_out, d_err, packets, seed1, sh1, s1ny, s1nz, bx_off, pz, lane_greedy);
     else
-      hipLaunchKernelGGL((k_lane<MODE_NORMAL_FOLD, SIGN_NONE>), dim3(blocks), dim3(256), 0, st, mesh, g, nullptr, d_out, d_err, packets, seed1, sh1, s1ny, s1nz, bx_off, pz);
+      hipLaunchKernelGGL((k_lane<MODE_NORMAL_FOLD, SIGN_NONE>), dim3(blocks), dim3(256), 0, st, mesh, g, nullptr, d_out, d_err, packets, seed1, sh1, s1ny, s1nz, bx_off, pz, lane_greedy);
     M2S_HIP_CHECK(hipGetLastError());
     return 0;
   }
@@ -1647,10 +1692,11 @@ int launch_query_distance(Arena& ws, hipStream_t st, const DeviceMesh& mesh, con
   }
   if (lane_walk) {
     const unsigned lb = (nq + 255u) / 256u;
-    if (mode == MODE_UNSIGNED && sign_src == SIGN_RAYS3) hipLaunchKernelGGL((k_lane_q<MODE_UNSIGNED, SIGN_RAYS3>), dim3(lb), dim3(256), 0, st, mesh, (const float4*)sorted, (const uint32_t*)perm, nq, d_out, d_err, seeds, d_lat);
-    else if (mode == MODE_UNSIGNED) hipLaunchKernelGGL((k_lane_q<MODE_UNSIGNED, SIGN_NONE>), dim3(lb), dim3(256), 0, st, mesh, (const float4*)sorted, (const uint32_t*)perm, nq, d_out, d_err, seeds, d_lat);
-    else if (mode == MODE_NORMAL_FOLD) hipLaunchKernelGGL((k_lane_q<MODE_NORMAL_FOLD, SIGN_NONE>), dim3(lb), dim3(256), 0, st, mesh, (const float4*)sorted, (const uint32_t*)perm, nq, d_out, d_err, seeds, d_lat);
-    else hipLaunchKernelGGL((k_lane_q<MODE_NEAREST_NORMAL, SIGN_NONE>), dim3(lb), dim3(256), 0, st, mesh, (const float4*)sorted, (const uint32_t*)perm, nq, d_out, d_err, seeds, d_lat);
+    const bool lane_greedy = getenv("M2S_LANE_GREEDY") ? atoi(getenv("M2S_LANE_GREEDY")) != 0 : true;
+    if (mode == MODE_UNSIGNED && sign_src == SIGN_RAYS3) hipLaunchKernelGGL((k_lane_q<MODE_UNSIGNED, SIGN_RAYS3>), dim3(lb), dim3(256), 0, st, mesh, (const float4*)sorted, (const uint32_t*)perm, nq, d_out, d_err, seeds, d_lat, lane_greedy);
+    else if (mode == MODE_UNSIGNED) hipLaunchKernelGGL((k_lane_q<MODE_UNSIGNED, SIGN_NONE>), dim3(lb), dim3(256), 0, st, mesh, (const float4*)sorted, (const uint32_t*)perm, nq, d_out, d_err, seeds, d_lat, lane_greedy);
+    else if (mode == MODE_NORMAL_FOLD) hipLaunchKernelGGL((k_lane_q<MODE_NORMAL_FOLD, SIGN_NONE>), dim3(lb), dim3(256), 0, st, mesh, (const float4*)sorted, (const uint32_t*)perm, nq, d_out, d_err, seeds, d_lat, lane_greedy);
+    else hipLaunchKernelGGL((k_lane_q<MODE_NEAREST_NORMAL, SIGN_NONE>), dim3(lb), dim3(256), 0, st, mesh, (const float4*)sorted, (const uint32_t*)perm, nq, d_out, d_err, seeds, d_lat, lane_greedy);
     M2S_HIP_CHECK(hipGetLastError());
     return 0;
   }

@@ -81,6 +81,8 @@ def named(name):
         return sheet(251, 201)
     if name == "blob-6k":
         return blob(60, 51)
+    if name == "blob-11k":      # the size of the reference's criterion mesh (assets/knight.glb, 11 184 triangles)
+        return blob(80, 71)
     raise KeyError(name)
 
 
