@@ -31,6 +31,12 @@
  * Limits (validated, M2S_ERR_BAD_ARG): n_vertices < 2^31, n_indices < 3 * 2^31, at most 2^25 triangles per mesh
  * (32-bit byte offsets into the 96-byte triangle records), n_queries < 2^32 - 64 per call, every cell_count < 2^31
  * and every product of two cell counts < 2^32 (grid lines per face are counted in 32 bits).
+ *
+ * Non-finite QUERY coordinates (m2s_generate_sdf): with None / Bvh and SignMethod::Raycast the result is +f32::MAX, as in the
+ * reference (every distance is NaN and f32::min drops it, default.rs:47; no ray hits); with SignMethod::Normal the call returns
+ * M2S_ERR_NAN where the reference panics (lib.rs:257).  Rtree / RtreeBvh: the reference measures the distance to whichever
+ * triangle rstar's nearest_neighbor returns for a NaN / inf point — unspecified by that crate — so the value for such a query
+ * is unspecified here too (+f32::MAX for RtreeBvh today); the other queries of the call are unaffected.
  */
 #ifndef M2S_H
 #define M2S_H

@@ -1453,7 +1453,7 @@ int prepare_grid_walk(Arena& ws, hipStream_t st, const DeviceMesh& mesh, const G
   }
   // Walk flavour: bricks that each meet MANY triangles (triangles much smaller than voxels) are better served by
   // independent per-lane walks.  Estimate: triangles per surface brick ~ T / (6 * bricks^(2/3)).
-  static const int lane_env = getenv("M2S_LANE_WALK") ? atoi(getenv("M2S_LANE_WALK")) : -1;   // -1 auto, 0 never, 1 always
+  const int lane_env = getenv("M2S_LANE_WALK") ? atoi(getenv("M2S_LANE_WALK")) : -1;   // -1 auto, 0 never, 1 always (read per call: the tests switch it)
   const double surface_bricks = 6.0 * pow((double)packets, 2.0 / 3.0);
   const bool lane_walk = !brute && mesh.n_tris && (lane_env >= 0 ? lane_env == 1 : (double)mesh.n_tris > 60.0 * surface_bricks);   // measured crossover: 40 per brick favours the packet walk, 65 the lane walk
   // cut lists: the top of the tree is walked once per block of 2^log bricks per axis (k_cut)
@@ -1624,7 +1624,7 @@ int launch_query_distance(Arena& ws, hipStream_t st, const DeviceMesh& mesh, con
   // RtreeBvh): blob-100k 100 k queries 1.36 / 3.65 ms, 1 M 2.70 / 3.45, 3 M 5.00 / 4.38, 10 M 12.3 / 6.7 (crossover ~2 M);
   // blob-1M 1 M 6.3 / 12.8 ms, 10 M 26.4 / 22.4 (~7 M).  Below it the packet walk lasts as long as its worst packet's chain of
   // dependent loads (2.7 ms), above it the lane walk's divergence costs more than the packets' union.  n* ~ 3500 T^0.55 fits both.
-  static const int lane_env = getenv("M2S_LANE_WALK") ? atoi(getenv("M2S_LANE_WALK")) : -1;   // -1 auto, 0 never, 1 always
+  const int lane_env = getenv("M2S_LANE_WALK") ? atoi(getenv("M2S_LANE_WALK")) : -1;   // -1 auto, 0 never, 1 always (read per call: the tests switch it)
   const double lane_coeff = getenv("M2S_QUERY_LANE_COEFF") ? atof(getenv("M2S_QUERY_LANE_COEFF")) : 3500.0;
   const bool lane_walk = mesh.n_tris && sign_src != SIGN_XRAY_ALL &&
                          (lane_env >= 0 ? lane_env == 1 : (double)n_q < lane_coeff * pow((double)mesh.n_tris, 0.55));
@@ -1632,9 +1632,10 @@ int launch_query_distance(Arena& ws, hipStream_t st, const DeviceMesh& mesh, con
   // count, and k_qtable_mode falls back to consecutive packets should there be more
   const uint32_t* table = nullptr;
   uint32_t launched = packets;
-  static const bool bucket_packets = !(getenv("M2S_QUERY_CELLS") && atoi(getenv("M2S_QUERY_CELLS")) == 0);
+  const bool bucket_packets = !(getenv("M2S_QUERY_CELLS") && atoi(getenv("M2S_QUERY_CELLS")) == 0);
   if (bucket_packets && !lane_walk) {
     launched = nq / 32u + 64u;
+    if (getenv("M2S_QUERY_LAUNCH_TIGHT") && atoi(getenv("M2S_QUERY_LAUNCH_TIGHT")) != 0) launched = packets + 1u;   // test hook: forces the consecutive-packet fallback
     uint8_t* head = ws.take<uint8_t>(n_q);
     uint32_t* tb = ws.take<uint32_t>(n_q + 2);               // [0] count, [1] mode, then one start per head (at most n_q)
     size_t sel_bytes = 0;

@@ -18,19 +18,29 @@ F = np.float32
 TOL = 1e-5  # north_star tolerance (absolute, f32 distances); signs must match exactly
 
 
-@pytest.fixture(autouse=True, params=["default", "cut lists on every grid"])
+@pytest.fixture(autouse=True, params=["default", "cut lists on every grid", "lane walks"])
 def cut_lists_mode(request):
-    """The cut lists (k_cut) are used from 100 000 packets per launch upwards; the second run of every test lowers that
-    to 8 packets, so that the nasty small inputs below (degenerate, non-finite, huge, anisotropic, sliced) meet them too."""
+    """The cut lists (k_cut) are used from 100 000 packets per launch upwards and the packet walk of generic queries from a
+    few million queries; the second run of every test lowers the thresholds and forces the packet walks, so that the nasty
+    small inputs below (degenerate, non-finite, huge, anisotropic, sliced, duplicated) meet packets and cut lists too; the third
+    run forces the lane walks (k_lane, k_lane_q) on everything that is small enough for them to be quick."""
     import os
 
-    forced = request.param != "default"
-    if forced and "full_size" in request.node.name:
+    mode = request.param
+    big = any(t in request.node.name for t in ("full_size", "10M", "512", "1024", "config", "256"))
+    if mode != "default" and "full_size" in request.node.name:
         pytest.skip("large enough to use the cut lists anyway")
-    if forced:
+    if mode == "lane walks" and big:
+        pytest.skip("the lane walk is not meant for this size")
+    if mode == "cut lists on every grid":
         os.environ["M2S_CUT_MIN_PACKETS"] = "8"
+        os.environ["M2S_QUERY_CUT_MIN"] = "1"
+        os.environ["M2S_LANE_WALK"] = "0"
+    elif mode == "lane walks":
+        os.environ["M2S_LANE_WALK"] = "1"
     yield
-    os.environ.pop("M2S_CUT_MIN_PACKETS", None)
+    for k in ("M2S_CUT_MIN_PACKETS", "M2S_QUERY_CUT_MIN", "M2S_LANE_WALK"):
+        os.environ.pop(k, None)
 
 
 def bits(a):
@@ -138,6 +148,61 @@ def test_generic_blob100k_rtreebvh():
     assert_bit_equal(got, want, "blob-100k RtreeBvh")
     got = generate_sdf(v, Topology.TriangleList(idx), q, AccelerationMethod.Rtree)
     assert_bit_equal(got, orc.generate_sdf(v, idx, q, accel=2, fast=True), "blob-100k Rtree")
+
+
+def test_generic_duplicate_and_clustered_queries():
+    """Packets of the generic path are prefix cells of the 30-bit Morton keys (k_qcells): more than 64 queries in one cell of the
+    finest level (identical points; a tight cluster beside far outliers that stretch the query box) are cut by position."""
+    v, idx = meshes.blob(60, 31)
+    lo, hi = meshes.extended_bbox(v, 0.1)
+    rng = np.random.default_rng(7)
+    q = meshes.uniform_queries(lo, hi, 3000)
+    same = np.repeat(q[:3], [700, 65, 129], axis=0)                                   # identical points
+    cluster = (q[10] + rng.uniform(-1e-5, 1e-5, (5000, 3))).astype(F)                # one finest-level cell, distinct points
+    far = np.array([[50.0, -40.0, 30.0], [-60.0, 55.0, -45.0]], F)                     # stretch the box: everything else shares few cells
+    allq = np.concatenate([same, q, cluster, far, q[:500]]).astype(F)
+    for name, am, accel, sign in ACCELS[2:]:
+        got = generate_sdf(v, Topology.TriangleList(idx), allq, am)
+        assert_bit_equal(got, orc.generate_sdf(v, idx, allq, accel=accel, sign=sign, fast=True), name)
+    for n in (1, 2, 63, 64, 65, 129):                                                 # tiny sets: one packet, a window that does not exist
+        got = generate_sdf(v, Topology.TriangleList(idx), allq[:n], AccelerationMethod.RtreeBvh)
+        assert_bit_equal(got, orc.generate_sdf(v, idx, allq[:n], accel=3, fast=True), f"{n} queries")
+
+
+def test_generic_nonfinite_queries_raycast():
+    """A NaN / inf query coordinate: every distance is NaN and f32::min drops it (default.rs:47), no ray hits (geo.rs:203) — the
+    reference returns +f32::MAX for it in the Raycast modes; the packets, their boxes and cut lists must survive such a member."""
+    v, idx = meshes.blob(60, 31)
+    q = meshes.uniform_queries(*meshes.extended_bbox(v, 0.1), 20_000)
+    q[5] = [np.nan, 0.1, 0.2]
+    q[6000] = [0.3, np.inf, 0.1]
+    q[12345] = [0.2, 0.2, -np.inf]
+    q[19999] = [np.nan, np.nan, np.nan]
+    bad = [5, 6000, 12345, 19999]
+    got = generate_sdf(v, Topology.TriangleList(idx), q, AccelerationMethod.Bvh(SignMethod.Raycast))
+    assert_bit_equal(got, orc.generate_sdf(v, idx, q, accel=1, sign=0), "Bvh(Raycast)")
+    assert (got[bad] == np.finfo(F).max).all()
+    # RtreeBvh: the reference measures the distance to whichever triangle rstar returns for a NaN / inf point (unspecified; include/m2s.h):
+    # only the finite queries are compared
+    got = generate_sdf(v, Topology.TriangleList(idx), q, AccelerationMethod.RtreeBvh)
+    want = orc.generate_sdf(v, idx, q, accel=3, fast=True)
+    assert_bit_equal(np.delete(got, bad), np.delete(want, bad), "RtreeBvh, finite queries")
+
+
+def test_generic_consecutive_packet_fallback():
+    """More bucket cells than the launch has waves (M2S_QUERY_LAUNCH_TIGHT forces it): k_qtable_mode switches to 64 consecutive
+    queries per packet on the device; same bits."""
+    import os
+
+    v, idx = meshes.blob(60, 31)
+    q = meshes.uniform_queries(*meshes.extended_bbox(v, 0.1), 50_000)
+    want = orc.generate_sdf(v, idx, q, accel=3, fast=True)
+    os.environ["M2S_QUERY_LAUNCH_TIGHT"] = "1"
+    try:
+        got = generate_sdf(v, Topology.TriangleList(idx), q, AccelerationMethod.RtreeBvh)
+    finally:
+        os.environ.pop("M2S_QUERY_LAUNCH_TIGHT", None)
+    assert_bit_equal(got, want, "consecutive-packet fallback")
 
 
 def test_generic_large_coordinates():
