@@ -208,7 +208,19 @@ enum m2s_partition { M2S_PART_AUTO = 0, M2S_PART_CONTIGUOUS = 1, M2S_PART_INTERL
 int m2s_generate_grid_sdf_multi(const float* vertices, size_t n_vertices, const void* indices, size_t n_indices,
                                 int index_bytes, int topology, const m2s_grid* grid, int sign_method, float* const* outs,
                                 const m2s_multi_opts* opts);
-/* x-slab [*x_begin, *x_end) of shard `k` out of `n` for a grid with `nx` layers (sizes differ by at most one layer). */
+/* generate_sdf over several GPUs (lib.rs:291-300 is still the one signature a caller has).  Shard k computes the contiguous query
+ * range m2s_slab_bounds(n_queries, n, k): every query depends only on the mesh.  mem_kind / devices / exchange / timings /
+ * wall_ms / exchange_used as for the grid call; partition and peer_mode are ignored.
+ *   M2S_MEM_HOST    outs[0] = the caller's array of n_queries floats; every device returns its range over its own PCIe link.
+ *   M2S_MEM_DEVICE  vertices, indices and queries lie on devices[0]; outs[k] = n_queries floats on devices[k]; on return EVERY
+ *                   buffer holds all distances (M2S_XCHG_PEER: each shard copies its finished range into the other buffers itself
+ *                   over xGMI and the other devices read the inputs where they lie; M2S_XCHG_RCCL: inputs replicated by peer
+ *                   copies, ranges gathered by ncclAllGather / ncclBroadcast; M2S_XCHG_NONE: buffer k holds range k only).
+ * *n_out (optional): n_queries, or 0 for RTREE_BVH on a mesh without triangles, as m2s_generate_sdf. */
+int m2s_generate_sdf_multi(const float* vertices, size_t n_vertices, const void* indices, size_t n_indices, int index_bytes,
+                           int topology, const float* queries, size_t n_queries, int accel, int sign_method, float* const* outs,
+                           size_t* n_out, const m2s_multi_opts* opts);
+/* Contiguous range [x_begin, x_end) of shard k out of n over nx units (x-layers, queries): sizes differ by at most one. */
 void m2s_slab_bounds(uint64_t nx, int n, int k, uint64_t* x_begin, uint64_t* x_end);
 /* The balanced partition: shard k takes the chunks k and n + k of 2n (m2s_opts.x_begin / x_end / x_period) when the grid allows
  * it — returns 1 — else its contiguous slab with *x_period = 0 — returns 0. */

@@ -146,6 +146,7 @@ EXPORTS = [
     "m2s_gltf_instances",
     "m2s_gltf_close",
     "m2s_generate_grid_sdf_multi",
+    "m2s_generate_sdf_multi",
     "m2s_slab_bounds",
     "m2s_interleaved_slab",
     "m2s_shared_alloc",
@@ -252,6 +253,9 @@ def lib():
         L.m2s_generate_grid_sdf_multi.restype = C.c_int
         L.m2s_generate_grid_sdf_multi.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_int,
                                                   C.POINTER(M2SGrid), C.c_int, C.POINTER(C.c_void_p), C.POINTER(M2SMultiOpts)]
+        L.m2s_generate_sdf_multi.restype = C.c_int
+        L.m2s_generate_sdf_multi.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_size_t,
+                                             C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(M2SMultiOpts)]
         L.m2s_slab_bounds.restype = None
         L.m2s_slab_bounds.argtypes = [C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.m2s_interleaved_slab.restype = C.c_int

@@ -407,6 +407,61 @@ def generate_grid_sdf_multi(vertices, indices: Topology, grid: Grid, sign_method
     return result
 
 
+def generate_sdf_multi(vertices, indices: Topology, query_points, acceleration_method: AccelerationMethod = None, *,
+                       devices: Sequence[int] = None, outs=None, exchange: Exchange = Exchange.Auto, algorithm: int = 0,
+                       info: dict = None):
+    """generate_sdf over several GPUs from this one process (m2s_generate_sdf_multi): shard k computes a contiguous range of the
+    queries.  numpy in -> one numpy array out; torch CUDA tensors in (on devices[0]) -> a list of CUDA tensors, one per entry of
+    `devices`, each holding ALL distances on return.  `devices` may repeat a device."""
+    am = acceleration_method if acceleration_method is not None else AccelerationMethod.RtreeBvh
+    a = _Args(vertices, indices, query_points)
+    L = _lib.lib()
+    if devices is None:
+        devices = list(range(L.m2s_device_count()))
+    devices = [int(d) for d in devices]
+    n = len(devices)
+    mo = _lib.M2SMultiOpts()
+    mo.struct_size = C.sizeof(_lib.M2SMultiOpts)
+    mo.n_devices = n
+    dev_arr = (C.c_int32 * max(n, 1))(*devices)
+    mo.devices = C.cast(dev_arr, C.POINTER(C.c_int32))
+    mo.exchange = int(exchange)
+    mo.algorithm = int(algorithm)
+    tims = (M2STimings * max(n, 1))()
+    mo.timings = C.cast(tims, C.POINTER(M2STimings))
+    wall, used = C.c_float(0.0), C.c_int32(-1)
+    mo.wall_ms = C.pointer(wall)
+    mo.exchange_used = C.pointer(used)
+    if a.device:
+        mo.mem_kind = _lib.MEM_DEVICE
+        dev0 = a.dev.index if a.dev.index is not None else a.torch.cuda.current_device()
+        assert n == 0 or devices[0] == dev0, "mesh and queries must live on devices[0]"
+        if outs is None:
+            outs = [a.torch.empty(a.n_q, dtype=a.torch.float32, device=f"cuda:{d}") for d in devices]
+        assert len(outs) == n and all(o.is_cuda and o.dtype == a.torch.float32 and o.numel() == a.n_q and o.is_contiguous() for o in outs)
+        a.torch.cuda.synchronize(a.dev)      # the library uses streams of its own: inputs must be complete
+        ptrs = (C.c_void_p * max(n, 1))(*[(o.data_ptr() if a.n_q else None) for o in outs])
+    else:
+        mo.mem_kind = _lib.MEM_HOST
+        if outs is None:
+            outs = np.empty(a.n_q, np.float32)
+        assert outs.dtype == np.float32 and outs.size == a.n_q and outs.flags["C_CONTIGUOUS"]
+        ptrs = (C.c_void_p * 1)(outs.ctypes.data if a.n_q else None)
+    n_out = C.c_size_t(0)
+    rc = L.m2s_generate_sdf_multi(a.p_verts, a.n_verts, a.p_idx, a.n_idx, a.index_bytes, a.topology, a.p_q, a.n_q, int(am.kind),
+                                  int(am.sign), C.cast(ptrs, C.POINTER(C.c_void_p)), C.byref(n_out), C.byref(mo))
+    if rc != _lib.M2S_OK:
+        _raise(rc)
+    if info is not None:
+        info["wall_ms"] = float(wall.value)
+        info["exchange"] = Exchange(used.value).name if used.value >= 0 else None
+        info["timings"] = [tims[k] for k in range(n)]
+        info["_keep"] = tims
+    if a.device:
+        return [o[: n_out.value] for o in outs]
+    return outs[: n_out.value]
+
+
 class SharedGrid:
     """A whole-grid device buffer other PROCESSES can map (m2s_shared_alloc / m2s_ipc_*): the one-process-per-GPU form of
     the peer exchange.  `tensor` views it as a torch CUDA tensor; `handle` is the 64-byte token to send to the other ranks;

@@ -159,6 +159,64 @@ bool enable_peer_access(const std::vector<int>& devices) {
   return true;
 }
 
+// The part of a multi-device call that does not depend on what is computed: shards -> (device, lane), memory kind, exchange.
+struct MultiPlan {
+  int n = 0;
+  std::vector<int> devices, lanes, distinct;
+  int mem_kind = M2S_MEM_HOST, exchange = M2S_XCHG_NONE, peer_mode = M2S_PEER_PUSH;
+};
+int plan_multi(const m2s_multi_opts* opts, float* const* outs, bool empty, MultiPlan* mp) {
+  if (!outs) return fail(M2S_ERR_BAD_ARG, "outs is NULL");
+  if (opts && opts->struct_size != 0 && opts->struct_size < M2S_MULTI_OPTS_V1_SIZE) return fail(M2S_ERR_BAD_ARG, "m2s_multi_opts.struct_size too small");
+  const int visible = m2s_device_count();
+  if (visible <= 0) return fail(M2S_ERR_HIP, "no HIP device available: the MI355X kernels cannot run (there is no CPU fallback)");
+  int n = opts ? opts->n_devices : 0;
+  if (n == 0) n = visible;
+  if (n < 0 || n > M2S_MAX_PEERS + 1) return fail(M2S_ERR_BAD_ARG, "n_devices %d outside [1, %d]", n, M2S_MAX_PEERS + 1);
+  mp->n = n;
+  mp->devices.assign((size_t)n, 0);
+  mp->lanes.assign((size_t)n, 0);
+  for (int k = 0; k < n; ++k) {
+    mp->devices[k] = (opts && opts->devices) ? opts->devices[k] : k;
+    if (mp->devices[k] < 0 || mp->devices[k] >= visible) return fail(M2S_ERR_BAD_ARG, "devices[%d] = %d, but %d device(s) are visible", k, mp->devices[k], visible);
+    int lane = 0;
+    for (int j = 0; j < k; ++j) lane += mp->devices[j] == mp->devices[k];   // shards that share a device get contexts of their own
+    if (lane >= M2S_MAX_LANES) return fail(M2S_ERR_BAD_ARG, "more than %d shards on device %d", M2S_MAX_LANES, mp->devices[k]);
+    mp->lanes[k] = lane;
+  }
+  mp->mem_kind = opts ? opts->mem_kind : M2S_MEM_HOST;
+  if (mp->mem_kind != M2S_MEM_HOST && mp->mem_kind != M2S_MEM_DEVICE) return fail(M2S_ERR_BAD_ARG, "bad mem_kind");
+  int exchange = opts ? opts->exchange : M2S_XCHG_AUTO;
+  if (exchange < M2S_XCHG_AUTO || exchange > M2S_XCHG_NONE) return fail(M2S_ERR_BAD_ARG, "bad exchange");
+  mp->peer_mode = opts ? opts->peer_mode : M2S_PEER_PUSH;
+  if (mp->peer_mode < M2S_PEER_PUSH || mp->peer_mode > M2S_PEER_TRAIL) return fail(M2S_ERR_BAD_ARG, "bad peer_mode");
+  for (int k = 0; k < (mp->mem_kind == M2S_MEM_HOST ? 1 : n); ++k)
+    if (!outs[k] && !empty) return fail(M2S_ERR_BAD_ARG, "outs[%d] is NULL", k);
+  for (int d : mp->devices) { bool seen = false; for (int e : mp->distinct) seen |= e == d; if (!seen) mp->distinct.push_back(d); }
+  // (an explicit RCCL request is honoured even for one shard: a 1-rank in-place all-gather, which is how the RCCL
+  // path is exercised on a 1-GPU box)
+  if (mp->mem_kind == M2S_MEM_HOST || (n == 1 && exchange != M2S_XCHG_RCCL)) exchange = M2S_XCHG_NONE;
+  else if (exchange == M2S_XCHG_AUTO || exchange == M2S_XCHG_PEER) {
+    const bool ok = enable_peer_access(mp->distinct);
+    if (!ok && exchange == M2S_XCHG_PEER) return fail(M2S_ERR_HIP, "peer access between the listed devices is not available");
+    exchange = ok ? M2S_XCHG_PEER : M2S_XCHG_RCCL;
+  }
+  if (exchange == M2S_XCHG_RCCL && mp->distinct.size() != mp->devices.size())
+    return fail(M2S_ERR_BAD_ARG, "the RCCL exchange needs distinct devices (one communicator rank per device)");
+  mp->exchange = exchange;
+  if (opts && opts->exchange_used) *opts->exchange_used = exchange;
+  return 0;
+}
+
+// A replica of a device-resident array of devices[0] on another device (no peer access: RCCL exchange).
+int replicate(int dst_device, int src_device, const void* src, size_t bytes, void** staged) {
+  *staged = nullptr;
+  if (!bytes) return 0;
+  if (hipSetDevice(dst_device) != hipSuccess || hipMalloc(staged, bytes + 256) != hipSuccess) return fail(M2S_ERR_HIP, "replica: hipMalloc failed on device %d", dst_device);
+  if (hipMemcpyPeer(*staged, dst_device, src, src_device, bytes) != hipSuccess) return fail(M2S_ERR_HIP, "replica: hipMemcpyPeer failed");
+  return 0;
+}
+
 }  // namespace
 }  // namespace m2s
 
@@ -180,48 +238,16 @@ int m2s_generate_grid_sdf_multi(const float* vertices, size_t n_vertices, const 
   clear_error();
   const auto t0 = std::chrono::steady_clock::now();
   if (!grid) return fail(M2S_ERR_BAD_ARG, "grid is NULL");
-  if (!outs) return fail(M2S_ERR_BAD_ARG, "outs is NULL");
   if (opts && opts->struct_size != 0 && opts->struct_size < M2S_MULTI_OPTS_V1_SIZE) return fail(M2S_ERR_BAD_ARG, "m2s_multi_opts.struct_size too small");
   int partition = (opts && opts->struct_size >= sizeof(m2s_multi_opts)) ? opts->partition : M2S_PART_AUTO;
   if (partition < M2S_PART_AUTO || partition > M2S_PART_INTERLEAVED) return fail(M2S_ERR_BAD_ARG, "bad partition");
-  const int visible = m2s_device_count();
-  if (visible <= 0) return fail(M2S_ERR_HIP, "no HIP device available: the MI355X kernels cannot run (there is no CPU fallback)");
-  int n = opts ? opts->n_devices : 0;
-  if (n == 0) n = visible;
-  if (n < 0 || n > M2S_MAX_PEERS + 1) return fail(M2S_ERR_BAD_ARG, "n_devices %d outside [1, %d]", n, M2S_MAX_PEERS + 1);
-  std::vector<int> devices((size_t)n), lanes((size_t)n);
-  for (int k = 0; k < n; ++k) {
-    devices[k] = (opts && opts->devices) ? opts->devices[k] : k;
-    if (devices[k] < 0 || devices[k] >= visible) return fail(M2S_ERR_BAD_ARG, "devices[%d] = %d, but %d device(s) are visible", k, devices[k], visible);
-    int lane = 0;
-    for (int j = 0; j < k; ++j) lane += devices[j] == devices[k];   // shards that share a device get contexts of their own
-    if (lane >= M2S_MAX_LANES) return fail(M2S_ERR_BAD_ARG, "more than %d shards on device %d", M2S_MAX_LANES, devices[k]);
-    lanes[k] = lane;
-  }
-  const int mem_kind = opts ? opts->mem_kind : M2S_MEM_HOST;
-  if (mem_kind != M2S_MEM_HOST && mem_kind != M2S_MEM_DEVICE) return fail(M2S_ERR_BAD_ARG, "bad mem_kind");
-  int exchange = opts ? opts->exchange : M2S_XCHG_AUTO;
-  if (exchange < M2S_XCHG_AUTO || exchange > M2S_XCHG_NONE) return fail(M2S_ERR_BAD_ARG, "bad exchange");
-  const int peer_mode = opts ? opts->peer_mode : M2S_PEER_PUSH;
-  if (peer_mode < M2S_PEER_PUSH || peer_mode > M2S_PEER_TRAIL) return fail(M2S_ERR_BAD_ARG, "bad peer_mode");
   const uint64_t nx = grid->cell_count[0], row = grid->cell_count[1] * grid->cell_count[2];
   const bool empty = nx == 0 || row == 0;
-  for (int k = 0; k < (mem_kind == M2S_MEM_HOST ? 1 : n); ++k)
-    if (!outs[k] && !empty) return fail(M2S_ERR_BAD_ARG, "outs[%d] is NULL", k);
-
-  std::vector<int> distinct;
-  for (int d : devices) { bool seen = false; for (int e : distinct) seen |= e == d; if (!seen) distinct.push_back(d); }
-  // (an explicit RCCL request is honoured even for one shard: a 1-rank in-place all-gather, which is how the RCCL
-  // path is exercised on a 1-GPU box)
-  if (mem_kind == M2S_MEM_HOST || (n == 1 && exchange != M2S_XCHG_RCCL)) exchange = M2S_XCHG_NONE;
-  else if (exchange == M2S_XCHG_AUTO || exchange == M2S_XCHG_PEER) {
-    const bool ok = enable_peer_access(distinct);
-    if (!ok && exchange == M2S_XCHG_PEER) return fail(M2S_ERR_HIP, "peer access between the listed devices is not available");
-    exchange = ok ? M2S_XCHG_PEER : M2S_XCHG_RCCL;
-  }
-  if (exchange == M2S_XCHG_RCCL && distinct.size() != devices.size())
-    return fail(M2S_ERR_BAD_ARG, "the RCCL exchange needs distinct devices (one communicator rank per device)");
-  if (opts && opts->exchange_used) *opts->exchange_used = exchange;
+  MultiPlan mp;
+  if (const int prc = plan_multi(opts, outs, empty, &mp)) return prc;
+  const int n = mp.n, mem_kind = mp.mem_kind, exchange = mp.exchange, peer_mode = mp.peer_mode;
+  const std::vector<int>& devices = mp.devices;
+  const std::vector<int>& lanes = mp.lanes;
 
   // the mesh lives on devices[0] in device mode: the other devices read it through a staging copy of their own
   const size_t vbytes = n_vertices * 12, ibytes = indices ? n_indices * (size_t)index_bytes : 0;
@@ -296,6 +322,87 @@ int m2s_generate_grid_sdf_multi(const float* vertices, size_t n_vertices, const 
     const int rc = rccl_gather(devices, outs, xb, xe, row, period, nx);
     if (rc) return rc;
   }
+  if (opts && opts->wall_ms) *opts->wall_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  return M2S_OK;
+}
+
+// generate_sdf over several GPUs: shard k takes the contiguous query range [q0_k, q1_k) (sizes differ by at most one; every query
+// depends only on the replicated mesh).  Host memory: every device returns its range into the caller's array over its own PCIe
+// link.  Device memory: mesh and queries lie on devices[0]; with peer access the other devices read them where they lie and every
+// shard copies its finished range into all other buffers itself (xGMI is point-to-point: n - 1 links in parallel); without it the
+// inputs are replicated by peer copies and the ranges are gathered by RCCL (one in-place all-gather, or one broadcast per range
+// when the count does not divide).
+int m2s_generate_sdf_multi(const float* vertices, size_t n_vertices, const void* indices, size_t n_indices, int index_bytes,
+                           int topology, const float* queries, size_t n_queries, int accel, int sign_method, float* const* outs,
+                           size_t* n_out, const m2s_multi_opts* opts) {
+  clear_error();
+  const auto t0 = std::chrono::steady_clock::now();
+  if (n_out) *n_out = 0;
+  if (n_queries && !queries) return fail(M2S_ERR_BAD_ARG, "queries is NULL");
+  MultiPlan mp;
+  if (const int prc = plan_multi(opts, outs, n_queries == 0, &mp)) return prc;
+  const int n = mp.n;
+  const std::vector<int>& devices = mp.devices;
+  std::vector<uint64_t> qb((size_t)n), qe((size_t)n);
+  for (int k = 0; k < n; ++k) m2s_slab_bounds((uint64_t)n_queries, n, k, &qb[k], &qe[k]);
+  const size_t vbytes = n_vertices * 12, ibytes = indices ? n_indices * (size_t)index_bytes : 0;
+
+  std::vector<int> rcs((size_t)n, 0);
+  std::vector<size_t> written((size_t)n, 0);
+  std::vector<std::string> errs((size_t)n);
+  auto shard = [&](int k) {
+    const size_t count = (size_t)(qe[k] - qb[k]);
+    if (count == 0) { rcs[k] = 0; return; }       // more shards than queries
+    m2s_opts o{};
+    o.struct_size = sizeof(m2s_opts);
+    o.device = devices[k];
+    o.lane = mp.lanes[k];
+    o.mem_kind = mp.mem_kind;
+    o.algorithm = opts ? opts->algorithm : 0;
+    o.synchronous = 1;
+    o.timings = (opts && opts->timings) ? &opts->timings[k] : nullptr;
+    const float* v = vertices;
+    const void* ix = indices;
+    const float* q = queries + 3 * (size_t)qb[k];
+    void *sv = nullptr, *si = nullptr, *sq = nullptr;
+    int rc = 0;
+    if (mp.mem_kind == M2S_MEM_DEVICE && devices[k] != devices[0] && mp.exchange != M2S_XCHG_PEER) {
+      rc = replicate(devices[k], devices[0], vertices, vbytes, &sv);
+      if (!rc) rc = replicate(devices[k], devices[0], indices, ibytes, &si);
+      if (!rc) rc = replicate(devices[k], devices[0], q, count * 12, &sq);
+      if (sv) v = (const float*)sv;
+      if (si) ix = si;
+      if (sq) q = (const float*)sq;
+    }
+    float* out = (mp.mem_kind == M2S_MEM_HOST ? outs[0] : outs[k]) + qb[k];
+    if (!rc) rc = m2s_generate_sdf(v, n_vertices, ix, n_indices, index_bytes, topology, q, count, accel, sign_method, out, &written[k], &o);
+    if (rc) errs[k] = m2s_last_error();
+    if (!rc && mp.exchange == M2S_XCHG_PEER && written[k]) {
+      // the call was synchronous: the range is complete in outs[k]; hand it to every other buffer (skip aliases of this one)
+      for (int j = 0; j < n && !rc; ++j) {
+        if (j == k || outs[j] == outs[k]) continue;
+        if (hipMemcpyPeer(outs[j] + qb[k], devices[j], out, devices[k], count * 4) != hipSuccess) rc = fail(M2S_ERR_HIP, "peer copy of the result range failed");
+      }
+      if (rc) errs[k] = m2s_last_error();
+    }
+    for (void* p : {sv, si, sq}) if (p) (void)hipFree(p);
+    rcs[k] = rc;
+  };
+  if (n == 1) shard(0);
+  else {
+    std::vector<std::thread> th;
+    for (int k = 0; k < n; ++k) th.emplace_back(shard, k);
+    for (auto& t : th) t.join();
+  }
+  for (int k = 0; k < n; ++k)
+    if (rcs[k]) return fail(rcs[k], "shard %d (device %d): %s", k, devices[k], errs[k].c_str());
+  size_t total = 0;
+  for (int k = 0; k < n; ++k) total += written[k];   // n_queries, or 0: RTREE_BVH on a mesh without triangles (every shard agrees)
+  if (mp.exchange == M2S_XCHG_RCCL && total) {
+    const int rc = rccl_gather(devices, outs, qb, qe, 1, 0, (uint64_t)n_queries);
+    if (rc) return rc;
+  }
+  if (n_out) *n_out = total;
   if (opts && opts->wall_ms) *opts->wall_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
   return M2S_OK;
 }

@@ -85,6 +85,17 @@ int main(int argc, char** argv) {
     m2s_slab_bounds(3, 3, 1, &a, &b);
     CHECK(rc == M2S_OK && memcmp(cells, cells3, sizeof(cells)) == 0 && used == M2S_XCHG_NONE && a == 1 && b == 2,
           "m2s_generate_grid_sdf_multi over {0,0,0} == single call");
+    /* generate_sdf over the same three shards: two queries, so one shard has nothing to do */
+    {
+      const float qs[6] = {0.25f, 0.25f, 1.0f, 0.25f, 0.25f, -2.0f};
+      float one[2] = {0, 0}, multi[2] = {0, 0};
+      size_t n1 = 0, n3 = 0;
+      float* qouts[1] = {multi};
+      rc = m2s_generate_sdf(vertices, 3, indices, 3, 4, M2S_TRIANGLE_LIST, qs, 2, M2S_ACCEL_RTREE_BVH, M2S_SIGN_RAYCAST, one, &n1, NULL);
+      CHECK(rc == M2S_OK && n1 == 2, "m2s_generate_sdf");
+      rc = m2s_generate_sdf_multi(vertices, 3, indices, 3, 4, M2S_TRIANGLE_LIST, qs, 2, M2S_ACCEL_RTREE_BVH, M2S_SIGN_RAYCAST, qouts, &n3, &mo);
+      CHECK(rc == M2S_OK && n3 == 2 && memcmp(one, multi, sizeof(one)) == 0, "m2s_generate_sdf_multi over {0,0,0} == single call");
+    }
     /* a version-0.1 caller's options (struct_size = M2S_OPTS_V1_SIZE) still work */
     m2s_opts o1;
     memset(&o1, 0, sizeof(o1));

@@ -11,8 +11,8 @@ import sys
 import numpy as np
 import pytest
 
-from mesh_to_sdf_amd import (Exchange, Grid, Partition, PeerMode, SignMethod, Topology, generate_grid_sdf, generate_grid_sdf_multi,
-                             interleaved_slab, meshes, slab_bounds)
+from mesh_to_sdf_amd import (AccelerationMethod, Exchange, Grid, Partition, PeerMode, SignMethod, Topology, generate_grid_sdf,
+                             generate_grid_sdf_multi, generate_sdf, generate_sdf_multi, interleaved_slab, meshes, slab_bounds)
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -197,6 +197,69 @@ def test_multi_exchange_none_leaves_other_slabs_alone():
         assert bool((o[mask] == -7.0).all())
 
 
+# ---- generate_sdf over several shards (m2s_generate_sdf_multi) ------------------------------------------------------
+QUERY_METHODS = [AccelerationMethod.RtreeBvh, AccelerationMethod.Rtree, AccelerationMethod.Bvh(SignMethod.Normal), AccelerationMethod.None_(SignMethod.Raycast)]
+
+
+@pytest.mark.parametrize("devices", [[0], [0, 0], [0, 0, 0]])
+def test_queries_multi_host_result_equals_single_call(devices):
+    v, idx = meshes.named("blob-6k")
+    q = meshes.uniform_queries(*meshes.extended_bbox(v, 0.1), 50_001)      # does not divide
+    for am in QUERY_METHODS:
+        want = generate_sdf(v, Topology.TriangleList(idx), q, am)
+        info = {}
+        got = generate_sdf_multi(v, Topology.TriangleList(idx), q, am, devices=devices, info=info)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), am
+        assert info["exchange"] == "Nothing"
+        assert [int(t.n_units) for t in info["timings"]] == [b - a for a, b in (slab_bounds(len(q), len(devices), k) for k in range(len(devices)))]
+
+
+@pytest.mark.parametrize("exchange", [Exchange.Peer, Exchange.Nothing])
+def test_queries_multi_device_resident_three_shards_one_gpu(exchange):
+    import torch
+
+    v, idx = meshes.named("blob-6k")
+    q = meshes.uniform_queries(*meshes.extended_bbox(v, 0.1), 40_003)
+    dv, di = _device_inputs(v, idx)
+    dq = torch.as_tensor(q, device="cuda:0")
+    want = generate_sdf(dv, Topology.TriangleList(di), dq, AccelerationMethod.RtreeBvh)
+    outs = [torch.full_like(want, -7.0) for _ in range(3)]
+    info = {}
+    got = generate_sdf_multi(dv, Topology.TriangleList(di), dq, AccelerationMethod.RtreeBvh, devices=[0, 0, 0], outs=outs, exchange=exchange, info=info)
+    assert info["exchange"] == exchange.name
+    for k, o in enumerate(got):
+        a, b = slab_bounds(len(q), 3, k)
+        if exchange == Exchange.Peer:          # EVERY buffer holds all distances
+            assert torch.equal(o.view(torch.int32), want.view(torch.int32)), f"buffer {k}"
+        else:                                  # buffer k holds range k only
+            assert torch.equal(o[a:b].view(torch.int32), want[a:b].view(torch.int32))
+            mask = torch.ones(len(q), dtype=torch.bool, device="cuda:0")
+            mask[a:b] = False
+            assert bool((o[mask] == -7.0).all())
+
+
+def test_queries_multi_rccl_one_rank_and_edge_cases():
+    import torch
+
+    from mesh_to_sdf_amd import M2SPanic
+
+    v, idx = meshes.named("blob-6k")
+    q = meshes.uniform_queries(*meshes.extended_bbox(v, 0.1), 10_000)
+    dv, di = _device_inputs(v, idx)
+    dq = torch.as_tensor(q, device="cuda:0")
+    want = generate_sdf(dv, Topology.TriangleList(di), dq, AccelerationMethod.RtreeBvh)
+    info = {}
+    outs = generate_sdf_multi(dv, Topology.TriangleList(di), dq, AccelerationMethod.RtreeBvh, devices=[0], exchange=Exchange.Rccl, info=info)
+    assert info["exchange"] == "Rccl" and torch.equal(outs[0].view(torch.int32), want.view(torch.int32))
+    # more shards than queries; no queries at all; RtreeBvh on a mesh without triangles returns nothing (rtree_bvh.rs:104-106)
+    few = generate_sdf_multi(v, Topology.TriangleList(idx), q[:2], AccelerationMethod.RtreeBvh, devices=[0, 0, 0])
+    assert np.array_equal(few.view(np.uint32), generate_sdf(v, Topology.TriangleList(idx), q[:2], AccelerationMethod.RtreeBvh).view(np.uint32))
+    assert generate_sdf_multi(v, Topology.TriangleList(idx), q[:0], AccelerationMethod.RtreeBvh, devices=[0, 0]).size == 0
+    assert generate_sdf_multi(v, Topology.TriangleList(idx[:0]), q[:100], AccelerationMethod.RtreeBvh, devices=[0, 0]).size == 0
+    with pytest.raises(M2SPanic):
+        generate_sdf_multi(v, Topology.TriangleList(idx), q, AccelerationMethod.RtreeBvh, devices=[0, 99])
+
+
 def test_multi_real_peers_when_the_box_has_them():
     import torch
 
@@ -212,6 +275,12 @@ def test_multi_real_peers_when_the_box_has_them():
             assert torch.equal(o.cpu().view(torch.int32), want.cpu().view(torch.int32)), (exchange, mode)
     host = generate_grid_sdf_multi(v, Topology.TriangleList(idx), g, SignMethod.Raycast, devices=list(range(n)))
     assert np.array_equal(host.view(np.uint32), want.cpu().numpy().view(np.uint32))
+    q = meshes.uniform_queries(*meshes.extended_bbox(v, 0.1), 300_007)
+    dq = torch.as_tensor(q, device="cuda:0")
+    wq = generate_sdf(dv, Topology.TriangleList(di), dq, AccelerationMethod.RtreeBvh)
+    for exchange in (Exchange.Peer, Exchange.Rccl):
+        for o in generate_sdf_multi(dv, Topology.TriangleList(di), dq, AccelerationMethod.RtreeBvh, devices=list(range(n)), exchange=exchange):
+            assert torch.equal(o.cpu().view(torch.int32), wq.cpu().view(torch.int32)), exchange
 
 
 def test_multi_errors():
