@@ -208,9 +208,21 @@ static bool side_stream_wanted(bool synchronous_call) {
   // asynchronous calls are the pieces of a caller who overlaps them on streams of its own: leave the hardware queues to those
   return overlap && synchronous_call;
 }
+// Side work (seed passes, sign planes) runs BESIDE the build on streams of the LOWEST priority: the build is a chain of ~30 small,
+// latency-bound kernels on the caller's stream and is what the cut lists wait for; the wide flooding passes should take the CUs it leaves.
+static int create_side_stream(hipStream_t* s) {
+  int lo = 0, hi = 0;
+  static const bool prio = !(getenv("M2S_SIDE_PRIORITY") && atoi(getenv("M2S_SIDE_PRIORITY")) == 0);
+  if (prio && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo != hi) {   // lo = numerically greatest = lowest priority
+    if (hipStreamCreateWithPriority(s, hipStreamNonBlocking, lo) == hipSuccess) return 0;
+    (void)hipGetLastError();
+  }
+  M2S_HIP_CHECK(hipStreamCreateWithFlags(s, hipStreamNonBlocking));
+  return 0;
+}
 static int ensure_side_stream(DeviceState& st) {
   if (!st.side_stream) {
-    M2S_HIP_CHECK(hipStreamCreateWithFlags(&st.side_stream, hipStreamNonBlocking));
+    if (const int rc = create_side_stream(&st.side_stream)) return rc;
     M2S_HIP_CHECK(hipEventCreateWithFlags(&st.fork_ev, hipEventDisableTiming));
   }
   return 0;
@@ -959,7 +971,7 @@ int m2s_generate_grid_sdf(const float* vertices, size_t n_vertices, const void* 
       // commutative, so the input order serves as well as the sorted one): a third stream builds them beside the rest of
       // the build and the seed passes.  After the build they were the last thing the walk of a thin slab waited for
       // (8-GPU rank: 0.09 ms of its 2.0 ms step).
-      if (!st->side_stream2) M2S_HIP_CHECK(hipStreamCreateWithFlags(&st->side_stream2, hipStreamNonBlocking));
+      if (!st->side_stream2) { if (const int prc = create_side_stream(&st->side_stream2)) return prc; }
       M2S_HIP_CHECK(hipStreamWaitEvent(st->side_stream2, st->seeds_fork, 0));
       M2S_HIP_CHECK(hipEventRecord(st->ev[5], st->side_stream2));
       DeviceMesh rm{};
