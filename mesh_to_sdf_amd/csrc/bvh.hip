@@ -153,6 +153,7 @@ __global__ __launch_bounds__(256) void k_scene_reduce(int* __restrict__ scene, u
       if (f == f && fabsf(f) < 3.0e38f) s = fmaxf(s, fabsf(f));
     }
     scene[6] = __float_as_int(s);
+    scene[7] = 0;                          // number of treelet roots (k_treelet_roots counts into it)
   }
 }
 
@@ -234,8 +235,11 @@ __global__ __launch_bounds__(256) void k_seg_level0(const Box* __restrict__ boxe
 }
 // Builds levels l+1, l+2, l+3 of the segment tree from level l in one launch: thread j owns entry j of
 // level l+3 = the union of (up to) 8 entries of level l, and writes the intermediate entries on the way.
+// LEAVES: level l is level 0 and does not exist yet — its entries are the leaf boxes in sorted order (boxes[order[k]]), written here too.
+template <bool LEAVES>
 __global__ __launch_bounds__(256) void k_seg_level3(Box* __restrict__ seg, uint32_t off0, uint32_t n0, uint32_t off1,
-                                                    uint32_t n1, uint32_t off2, uint32_t n2, uint32_t off3, uint32_t n3) {
+                                                    uint32_t n1, uint32_t off2, uint32_t n2, uint32_t off3, uint32_t n3,
+                                                    const Box* __restrict__ boxes, const uint32_t* __restrict__ order) {
   const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;   // index at level l+3 (or the deepest level present)
   Box b1[4];
   bool have1[4];
@@ -243,8 +247,14 @@ __global__ __launch_bounds__(256) void k_seg_level3(Box* __restrict__ seg, uint3
     const uint32_t i1 = 4 * j + a;          // entry at level l+1
     have1[a] = i1 < n1;
     if (!have1[a]) continue;
-    Box b = seg[off0 + 2 * i1];
-    if (2 * i1 + 1 < n0) b = box_union(b, seg[off0 + 2 * i1 + 1]);
+    Box b, c;
+    if (LEAVES) { b = boxes[order[2 * i1]]; seg[off0 + 2 * i1] = b; }
+    else b = seg[off0 + 2 * i1];
+    if (2 * i1 + 1 < n0) {
+      if (LEAVES) { c = boxes[order[2 * i1 + 1]]; seg[off0 + 2 * i1 + 1] = c; }
+      else c = seg[off0 + 2 * i1 + 1];
+      b = box_union(b, c);
+    }
     b1[a] = b;
     seg[off1 + i1] = b;
   }
@@ -750,7 +760,6 @@ int build_device_mesh(Arena& ws, hipStream_t st, const float* d_verts, size_t n_
   if (n > 2 && treelets && !getenv("M2S_KEYS_FILE")) {
     // treelet pass: the nodes of at most TREELET_MAX triangles are rebuilt by sweep splits, then the hierarchy is derived again
     int2* roots = reinterpret_cast<int2*>(child);   // child[] is not used by the kernels below and is rewritten by the second k_karras
-    M2S_HIP_CHECK(hipMemsetAsync(scene + 7, 0, sizeof(int), st));
     hipLaunchKernelGGL(k_treelet_roots, dim3(cdiv(n_tris - 1, B)), dim3(B), 0, st, n, range, parent, roots, scene + 7);
     hipLaunchKernelGGL(k_treelet, dim3((unsigned)((n_tris + 2) / 3)), dim3(TREELET_MAX), 0, st, roots, scene + 7, boxes, keys2, order);
     hipLaunchKernelGGL(k_karras, dim3(cdiv(n_tris - 1, B)), dim3(B), 0, st, keys2, n, range, child, parent);
@@ -769,14 +778,18 @@ int build_device_mesh(Arena& ws, hipStream_t st, const float* d_verts, size_t n_
       cnt = (cnt + 1) / 2;
     }
   }
-  hipLaunchKernelGGL(k_seg_level0, dim3(cdiv(n_tris, B)), dim3(B), 0, st, boxes, order, n, seg);
+  if (lv.levels == 1) hipLaunchKernelGGL(k_seg_level0, dim3(cdiv(n_tris, B)), dim3(B), 0, st, boxes, order, n, seg);   // a single triangle
   for (int l = 0; l + 1 < lv.levels; l += 3) {
     const uint32_t n1 = lv.cnt[l + 1];
     const uint32_t n2 = l + 2 < lv.levels ? lv.cnt[l + 2] : 0, n3 = l + 3 < lv.levels ? lv.cnt[l + 3] : 0;
     const uint32_t o2 = l + 2 < lv.levels ? lv.off[l + 2] : 0, o3 = l + 3 < lv.levels ? lv.off[l + 3] : 0;
     const uint32_t threads = (n1 + 3) / 4;
-    hipLaunchKernelGGL(k_seg_level3, dim3(cdiv(threads, B)), dim3(B), 0, st, seg, lv.off[l], lv.cnt[l], lv.off[l + 1], n1, o2,
-                       n2, o3, n3);
+    if (l == 0)   // the leaf level is gathered by the launch that consumes it
+      hipLaunchKernelGGL(k_seg_level3<true>, dim3(cdiv(threads, B)), dim3(B), 0, st, seg, lv.off[l], lv.cnt[l], lv.off[l + 1], n1, o2,
+                         n2, o3, n3, (const Box*)boxes, (const uint32_t*)order);
+    else
+      hipLaunchKernelGGL(k_seg_level3<false>, dim3(cdiv(threads, B)), dim3(B), 0, st, seg, lv.off[l], lv.cnt[l], lv.off[l + 1], n1, o2,
+                         n2, o3, n3, (const Box*)nullptr, (const uint32_t*)nullptr);
   }
   hipLaunchKernelGGL(k_emit, dim3(cdiv(2 * n_tris - 1, B)), dim3(B), 0, st, n, range, parent, seg, lv, order, raw,
                      nodes, tris, slot_first, cen, planes, leaf_max, slot_of);
