@@ -982,6 +982,7 @@ __global__ __launch_bounds__(64) void k_cut(DeviceMesh mesh, GridParams g, const
       grad_c1 = r * 1.001f;
     }
   }
+  const float grad_c1sq = grad_c1 * grad_c1 * 1.000001f;     // the test compares squares (no root per node): rounded up
   const float emit_radius = fmaxf(emit_near * r, R * emit_far);
 
   constexpr uint32_t NB = (uint32_t)sizeof(NodeExt);
@@ -998,8 +999,9 @@ __global__ __launch_bounds__(64) void k_cut(DeviceMesh mesh, GridParams g, const
     const float vx = q.x - nr.cx, vy = q.y - nr.cy, vz = q.z - nr.cz;
     const float t = __builtin_fmaf(nr.nz, vz, __builtin_fmaf(nr.ny, vy, nr.nx * vx));
     const float v2 = __builtin_fmaf(vz, vz, __builtin_fmaf(vy, vy, vx * vx));
-    const float l2 = __builtin_fmaf(-1.0e-6f, v2, __builtin_fmaf(-t, t, v2));
-    const float ell = __builtin_amdgcn_sqrtf(fmaxf(l2, 0.0f));
+    const float l2 = fmaxf(__builtin_fmaf(-1.0e-6f, v2, __builtin_fmaf(-t, t, v2)), 0.0f);
+    const float inv_ell = __builtin_amdgcn_rsqf(l2);                  // one transcendental for ell and 1 / ell (inf at l2 = 0: guarded below)
+    const float ell = l2 > 0.0f ? l2 * inv_ell : 0.0f;
     const float lat = fmaxf(ell - nr.R, 0.0f);
     const float dt = t - nr.mid;
     const float ax = copysignf(fmaxf(fabsf(dt) - nr.half, 0.0f), dt);
@@ -1012,12 +1014,13 @@ __global__ __launch_bounds__(64) void k_cut(DeviceMesh mesh, GridParams g, const
       const float ne_s = __builtin_fmaf(nr.nz, e.z, __builtin_fmaf(nr.ny, e.y, nr.nx * e.x));            // n_s . e
       const float ve = __builtin_fmaf(vz, e.z, __builtin_fmaf(vy, e.y, vx * e.x));                       // (q - c0) . e
       const float le = ve - t * ne_s;                                                                    // l . e
-      const float lat_dir = lat > 0.0f ? lat * __builtin_amdgcn_rcpf(ell) : 0.0f;
+      const float lat_dir = lat > 0.0f ? lat * inv_ell : 0.0f;       // lat > 0 means ell > R >= 0
       const float num = __builtin_fmaf(ax, ne_s, lat_dir * le);                                          // (q - c) . e
-      const float cosne = fminf(num * __builtin_amdgcn_rsqf(L2), 1.0f);                                  // n . e (NaN / inf if L == 0: kept)
-      const float nme = __builtin_amdgcn_sqrtf(fmaxf(2.0f - 2.0f * cosne, 0.0f) + 2.0e-5f);              // >= |n - e|
-      const float L = L2 * __builtin_amdgcn_rsqf(L2);
-      const bool drop = __builtin_fmaf(L, 0.9999f, -grad_c0) > grad_c1 * nme;                            // false on NaN
+      const float inv_L = __builtin_amdgcn_rsqf(L2);
+      const float cosne = fminf(num * inv_L, 1.0f);                                                      // n . e (NaN / inf if L == 0: kept)
+      const float nme2 = fmaxf(2.0f - 2.0f * cosne, 0.0f) + 2.0e-5f;                                     // >= |n - e|^2
+      const float A = __builtin_fmaf(L2 * inv_L, 0.9999f, -grad_c0);                                     // L (1 - 1e-4) - c0
+      const bool drop = (A > 0.0f) & (A * A > grad_c1sq * nme2);                                         // A > c1 |n - e| without the root; false on NaN
       keep = keep & !drop;
     }
     const unsigned long long bal = __ballot(keep);
