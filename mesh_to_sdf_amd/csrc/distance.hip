@@ -618,6 +618,125 @@ __global__ __launch_bounds__(256) void k_push_cells(const float* __restrict__ sr
   }
 }
 
+// ---- the lane walk's tree traversal -------------------------------------------------------------------------
+// walk_range: the pre-order records [off, limit) of the oriented-bound tree, one lane on its own, at most max_steps node tests.
+// ANY slot may start a range: every slot holds a valid record (k_emit / k_node_ext write one per node, the descendants of a
+// collapsed leaf included), a range that starts inside a subtree simply meets that subtree's nodes without their ancestors'
+// pruning, and every leaf of the range is either met or skipped with a pruned ancestor that lies in the range itself.
+template <int MODE>
+__device__ __forceinline__ void walk_range(const DeviceMesh& mesh, f3 p, float slack, Best<MODE>& best, float& thr, uint32_t& off,
+                                           uint32_t limit, uint32_t max_steps, uint32_t& st_nodes, uint32_t& st_exact) {
+  constexpr uint32_t NB = (uint32_t)sizeof(NodeExt);
+  const char* ext_bytes = reinterpret_cast<const char*>(mesh.ext);
+  for (uint32_t s = 0; s < max_steps && off < limit; ++s) {
+    const NodeExt nr = *reinterpret_cast<const NodeExt*>(ext_bytes + off);
+    ++st_nodes;
+    if (ext_dist2(p, nr) > thr) { off = nr.skip; continue; }
+    if (nr.tri >= 0) {
+      const uint32_t cnt = (nr.skip - off + NB) / (2u * NB);
+      for (uint32_t k = 0; k < cnt; ++k) {
+        if (!(planes_dist2(p, mesh.planes[nr.tri + k]) > thr)) {
+          eval_triangle<MODE>(best, p, mesh.tris[nr.tri + k]);
+          thr = prune_bound(best.d2, slack);
+          ++st_exact;
+        }
+      }
+      off = nr.skip;
+    } else {
+      off += NB;
+    }
+  }
+}
+// lane_tree_walk: every lane walks the whole tree for its own point — ROUND node tests at a time — and lanes that run out of work
+// take over a share of their neighbours'.  A lane near the centre of curvature of a dimple meets hundreds of tied triangles (1 300
+// node tests against 160 for the average lane of a 16^3 grid) and a small launch lasts as long as its longest chain of dependent
+// loads; the wave as a whole has 64 x 160 tests to do.  After every round the unfinished ranges are published in LDS and ALL lanes
+// are dealt out over them again (range k goes to the lanes with lane % K == k, cut into equal pieces): a lane then walks a piece of
+// another lane's range for that lane's point, starting from that lane's current bound, and folds what it finds into the owner's
+// slot with LDS atomic minima.  Any slot can start a range (walk_range).  Same triangles or more, same arithmetic per triangle:
+// bit-identical.
+struct LaneShare {
+  unsigned long long key[64];   // MODE_NEAREST_NORMAL: (d2 bits, index, !positive): the lexicographic minimum rtree.rs:118-123 asks for
+  uint32_t a[64], b[64];        // d2 bits (and d2pos bits for the Normal fold); non-negative floats order like their bit patterns
+  uint32_t flag[64];            // Normal fold: a NaN distance was met
+  uint32_t rng[64][3];          // unfinished ranges of this round: first, end, owner
+  float4 pt[64];                // every lane's point and slack
+};
+template <int MODE>
+__device__ __forceinline__ void lane_tree_walk(const DeviceMesh& mesh, f3 p, float slack, Best<MODE>& best, bool valid,
+                                               uint32_t& st_nodes, uint32_t& st_exact, LaneShare& sh) {
+  constexpr uint32_t NB = (uint32_t)sizeof(NodeExt);
+  constexpr uint32_t ROUND = 64;
+  const uint32_t end = mesh.n_nodes * NB;
+  const uint32_t lane = threadIdx.x & 63u;
+  auto key_of = [](const Best<MODE>& x) {
+    return ((unsigned long long)__float_as_uint(x.d2) << 32) | ((unsigned long long)(x.idx & 0x7fffffffu) << 1) | (x.pos ? 0ull : 1ull);
+  };
+  sh.pt[lane] = make_float4(p.x, p.y, p.z, slack);
+  sh.a[lane] = __float_as_uint(best.d2);
+  sh.b[lane] = __float_as_uint(best.d2pos);
+  sh.flag[lane] = best.nan ? 1u : 0u;
+  if (MODE == MODE_NEAREST_NORMAL) sh.key[lane] = key_of(best);
+  uint32_t owner = lane, off = valid ? 0u : end, limit = end;
+  f3 tp = p;
+  float tsl = slack;
+  Best<MODE> b = best;
+  float thr = prune_bound(b.d2, tsl);
+  for (;;) {
+    walk_range<MODE>(mesh, tp, tsl, b, thr, off, limit, ROUND, st_nodes, st_exact);
+    const unsigned long long unf = __ballot(off < limit);
+    if (unf == ~0ull) continue;                             // nobody is idle
+    // fold what this lane has found into its owner's slot
+    if (MODE == MODE_NEAREST_NORMAL) atomicMin(&sh.key[owner], key_of(b));
+    else {
+      atomicMin(&sh.a[owner], __float_as_uint(b.d2));
+      if (MODE == MODE_NORMAL_FOLD) { atomicMin(&sh.b[owner], __float_as_uint(b.d2pos)); if (b.nan) atomicOr(&sh.flag[owner], 1u); }
+    }
+    if (unf == 0ull) break;
+    const uint32_t K = (uint32_t)__popcll(unf);
+    if (off < limit) {
+      const uint32_t r = (uint32_t)__popcll(unf & ((1ull << lane) - 1ull));
+      sh.rng[r][0] = off; sh.rng[r][1] = limit; sh.rng[r][2] = owner;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const uint32_t k = lane % K, idx = lane / K, helpers = (64u - k + K - 1u) / K;
+    const uint32_t so = sh.rng[k][0], se = sh.rng[k][1], sowner = sh.rng[k][2];
+    const uint32_t records = (se - so) / NB, piece = (records + helpers - 1u) / helpers;
+    off = min(se, so + idx * piece * NB);
+    limit = min(se, off + piece * NB);
+    owner = sowner;
+    const float4 q = sh.pt[owner];
+    tp = mk3(q.x, q.y, q.z);
+    tsl = q.w;
+    // start from the owner's current result: the tightest bound anybody has for that point
+    b = Best<MODE>();
+    if (MODE == MODE_NEAREST_NORMAL) {
+      const unsigned long long kk = sh.key[owner];
+      b.d2 = __uint_as_float((uint32_t)(kk >> 32)); b.idx = (uint32_t)(kk >> 1) & 0x7fffffffu; b.pos = (kk & 1ull) == 0ull;
+      if (b.idx == 0x7fffffffu) b.idx = 0xffffffffu;        // "none yet" survives the 31-bit trip
+    } else {
+      b.d2 = __uint_as_float(sh.a[owner]);
+      if (MODE == MODE_NORMAL_FOLD) b.d2pos = __uint_as_float(sh.b[owner]);
+    }
+    thr = prune_bound(b.d2, tsl);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();                        // the ranges are read: the next round may overwrite them
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  if (MODE == MODE_NEAREST_NORMAL) {
+    const unsigned long long kk = sh.key[lane];
+    best.d2 = __uint_as_float((uint32_t)(kk >> 32)); best.idx = (uint32_t)(kk >> 1) & 0x7fffffffu; best.pos = (kk & 1ull) == 0ull;
+  } else {
+    best.d2 = __uint_as_float(sh.a[lane]);
+    if (MODE == MODE_NORMAL_FOLD) { best.d2pos = __uint_as_float(sh.b[lane]); best.nan = sh.flag[lane] != 0u; }
+  }
+}
+
 // Per-lane greedy descent (towards the child box nearer to p) and evaluation of the leaf it ends in: a second starting candidate for
 // the lane walks.  Their lattice seed is only as good as the lattice is fine — one point per 4^3 voxels of a 16^3 grid is 64 seeds
 // for the whole box — and a lane that starts with a loose bound walks long: the launch lasts as long as its slowest lane.
@@ -659,6 +778,7 @@ __global__ __launch_bounds__(256) void k_lane(DeviceMesh mesh, GridParams g, con
   if (!vox.brick_in_grid) return;
   const f3 p = grid_point(g, vox);
   const size_t out_index = ((size_t)vox.x * g.n[1] + vox.y) * g.n[2] + vox.z - (size_t)g.out_off;
+  const bool LANE_VALID = vox.in_range;                // lanes beyond the grid's edge hold a clamped copy: nothing to walk for them
 
   Best<MODE> best;
   if (mesh.n_nodes) {
@@ -669,31 +789,10 @@ __global__ __launch_bounds__(256) void k_lane(DeviceMesh mesh, GridParams g, con
       slot = min(seed_in[(((vox.bx + bx_off) >> seed_shift) * seed_ny + (vox.by >> seed_shift)) * seed_nz + (vox.bz >> seed_shift)], mesh.n_tris - 1);
     eval_triangle<MODE>(best, p, mesh.tris[slot]);
     if (greedy) greedy_leaf<MODE>(mesh, p, best);
-    float thr = prune_bound(best.d2, slack);
-    constexpr uint32_t NB = (uint32_t)sizeof(NodeExt);
-    const uint32_t end = mesh.n_nodes * NB;
-    const char* ext_bytes = reinterpret_cast<const char*>(mesh.ext);
-    uint32_t off = 0;                                  // per lane
     uint32_t st_nodes = 0, st_exact = 0;               // M2S_STATS
-    while (off < end) {
-      const NodeExt nr = *reinterpret_cast<const NodeExt*>(ext_bytes + off);
-      ++st_nodes;
-      if (ext_dist2(p, nr) > thr) { off = nr.skip; continue; }
-      if (nr.tri >= 0) {
-        const uint32_t cnt = (nr.skip - off + NB) / (2u * NB);
-        for (uint32_t k = 0; k < cnt; ++k) {
-          if (!(planes_dist2(p, mesh.planes[nr.tri + k]) > thr)) {
-            eval_triangle<MODE>(best, p, mesh.tris[nr.tri + k]);
-            thr = prune_bound(best.d2, slack);
-            ++st_exact;
-          }
-        }
-        off = nr.skip;
-      } else {
-        off += NB;
-      }
-    }
-    if (mesh.stats != nullptr) {                       // per lane: the lane walk's unit is the lane
+    __shared__ LaneShare lane_share[4];                // one per wave of the workgroup
+    lane_tree_walk<MODE>(mesh, p, slack, best, LANE_VALID, st_nodes, st_exact, lane_share[threadIdx.x >> 6]);
+    if (mesh.stats != nullptr && LANE_VALID) {         // per lane: the lane walk's unit is the lane
       atomicAdd(&mesh.stats[0], (unsigned long long)st_nodes);
       atomicAdd(&mesh.stats[2], (unsigned long long)st_exact);
       atomicAdd(&mesh.stats[3], 1ull);
@@ -846,8 +945,9 @@ template <int MODE, int SIGN>
 __global__ __launch_bounds__(256) void k_lane_q(DeviceMesh mesh, const float4* __restrict__ qsorted, const uint32_t* __restrict__ perm,
                                                 uint32_t n_q, float* __restrict__ out, int* __restrict__ err,
                                                 const uint32_t* __restrict__ seed_in, const GridParams* __restrict__ seed_lattice, bool greedy) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_q) return;
+  const uint32_t i_raw = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool LANE_VALID = i_raw < n_q;                 // the last wave's spare lanes stay: the wave-cooperative tail of the walk needs all 64
+  const uint32_t i = min(i_raw, n_q - 1u);
   const float4 q = qsorted[i];
   const f3 p = mk3(q.x, q.y, q.z);
   Best<MODE> best;
@@ -858,31 +958,10 @@ __global__ __launch_bounds__(256) void k_lane_q(DeviceMesh mesh, const float4* _
     if (seed_in != nullptr) slot = min(seed_in[query_lattice_cell(*seed_lattice, p.x, p.y, p.z)], mesh.n_tris - 1);
     eval_triangle<MODE>(best, p, mesh.tris[slot]);
     if (greedy) greedy_leaf<MODE>(mesh, p, best);
-    float thr = prune_bound(best.d2, slack);
-    constexpr uint32_t NB = (uint32_t)sizeof(NodeExt);
-    const uint32_t end = mesh.n_nodes * NB;
-    const char* ext_bytes = reinterpret_cast<const char*>(mesh.ext);
-    uint32_t off = 0;                                  // per lane
     uint32_t st_nodes = 0, st_exact = 0;               // M2S_STATS
-    while (off < end) {
-      const NodeExt nr = *reinterpret_cast<const NodeExt*>(ext_bytes + off);
-      ++st_nodes;
-      if (ext_dist2(p, nr) > thr) { off = nr.skip; continue; }
-      if (nr.tri >= 0) {
-        const uint32_t cnt = (nr.skip - off + NB) / (2u * NB);
-        for (uint32_t k = 0; k < cnt; ++k) {
-          if (!(planes_dist2(p, mesh.planes[nr.tri + k]) > thr)) {
-            eval_triangle<MODE>(best, p, mesh.tris[nr.tri + k]);
-            thr = prune_bound(best.d2, slack);
-            ++st_exact;
-          }
-        }
-        off = nr.skip;
-      } else {
-        off += NB;
-      }
-    }
-    if (mesh.stats != nullptr) {                       // per lane: the lane walk's unit is the lane
+    __shared__ LaneShare lane_share[4];                // one per wave of the workgroup
+    lane_tree_walk<MODE>(mesh, p, slack, best, LANE_VALID, st_nodes, st_exact, lane_share[threadIdx.x >> 6]);
+    if (mesh.stats != nullptr && LANE_VALID) {         // per lane: the lane walk's unit is the lane
       atomicAdd(&mesh.stats[0], (unsigned long long)st_nodes);
       atomicAdd(&mesh.stats[2], (unsigned long long)st_exact);
       atomicAdd(&mesh.stats[3], 1ull);
@@ -895,6 +974,7 @@ __global__ __launch_bounds__(256) void k_lane_q(DeviceMesh mesh, const float4* _
     const uint32_t cx = stab_count_lane<0>(mesh, p), cy = stab_count_lane<1>(mesh, p), cz = stab_count_lane<2>(mesh, p);
     negate = ((cx & 1u) + (cy & 1u) + (cz & 1u)) > 1u;                 // bvh.rs:131-141, rtree_bvh.rs:161-171
   }
+  if (!LANE_VALID) return;
   if (MODE == MODE_NORMAL_FOLD && best.nan) atomicOr(err, ERRF_NAN);
   out[perm[i]] = finish<MODE>(best, negate);
 }
@@ -1457,8 +1537,12 @@ int prepare_grid_walk(Arena& ws, hipStream_t st, const DeviceMesh& mesh, const G
   // Walk flavour: bricks that each meet MANY triangles (triangles much smaller than voxels) are better served by
   // independent per-lane walks.  Estimate: triangles per surface brick ~ T / (6 * bricks^(2/3)).
   const int lane_env = getenv("M2S_LANE_WALK") ? atoi(getenv("M2S_LANE_WALK")) : -1;   // -1 auto, 0 never, 1 always (read per call: the tests switch it)
-  const double surface_bricks = 6.0 * pow((double)packets, 2.0 / 3.0);
-  const bool lane_walk = !brute && mesh.n_tris && (lane_env >= 0 ? lane_env == 1 : (double)mesh.n_tris > 60.0 * surface_bricks);   // measured crossover: 40 per brick favours the packet walk, 65 the lane walk
+  // measured crossover with the work-sharing lane walk (lane / packet walk, whole call, Raycast): blob-11k 32^3 0.77 / 0.86 ms, 48^3
+  // 0.80 / 0.71; blob-100k 64^3 1.71 / 2.85, 96^3 2.19 / 2.12; blob-1M 128^3 8.8 / 12.1, 256^3 32.7 / 14.3: the lane walk wins while
+  // there are more than ~8 triangles per brick
+  const double real_bricks = (double)bricks_along(g.xe - g.xb, g.bl[0]) * bricks_along(g.n[1], g.bl[1]) * bricks_along(g.n[2], g.bl[2]);
+  const double lane_ratio = getenv("M2S_LANE_RATIO") ? atof(getenv("M2S_LANE_RATIO")) : 8.0;
+  const bool lane_walk = !brute && mesh.n_tris && (lane_env >= 0 ? lane_env == 1 : (double)mesh.n_tris > lane_ratio * real_bricks);
   // cut lists: the top of the tree is walked once per block of 2^log bricks per axis (k_cut)
   CutList cut = {nullptr, 0, 0, 0, 0, nullptr};
   // k_cut costs about 0.25 us per brick plus a latency floor of ~0.1 ms; measured crossover (blob-100k / blob-6k,
