@@ -49,7 +49,7 @@ extern "C" {
 #endif
 
 #define M2S_VERSION_MAJOR 0
-#define M2S_VERSION_MINOR 2
+#define M2S_VERSION_MINOR 3   /* 0.3: + m2s_generate_sdf_multi (additive; 0.2 callers are unaffected) */
 
 /* Return codes.  The reference panics where this ABI returns a negative code; the Rust shim
  * turns a negative code back into panic!(m2s_last_error()). */
