@@ -6,7 +6,7 @@ d = np.load("tests/golden/suzanne.npz")
 v, idx = d["vertices"].astype(np.float32), d["indices"].astype(np.uint32)
 lo, hi = meshes.extended_bbox(v, 0.1)
 dv, di = torch.as_tensor(v, device="cuda"), torch.as_tensor(idx.astype(np.int64), device="cuda").to(torch.int32)
-for n in (256, 512):
+for n in ([int(a) for a in sys.argv[1:]] or [256, 512]):
     g = Grid.from_bounding_box(lo, hi, [n] * 3)
     out = torch.empty(n ** 3, device="cuda")
     for sign in (SignMethod.Raycast, SignMethod.Normal):
