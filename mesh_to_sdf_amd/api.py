@@ -585,6 +585,18 @@ class Mesh:
             _raise(rc)
         return out[: n_out.value]
 
+    def debug_digest(self):
+        """FNV-1a digests of the resident arrays (test hook `m2s_debug_mesh_digest`): triangle records, pre-test planes, box nodes,
+        oriented bounds, centroids, slot table, scene words, triangle count."""
+        L = _lib.lib()
+        L.m2s_debug_mesh_digest.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+        L.m2s_debug_mesh_digest.restype = C.c_int
+        out = (C.c_uint64 * 8)()
+        rc = L.m2s_debug_mesh_digest(self._h, out)
+        if rc != _lib.M2S_OK:
+            _raise(rc)
+        return [int(x) for x in out]
+
     def drain_timings(self) -> M2STimings:
         t = M2STimings()
         rc = _lib.lib().m2s_mesh_drain_timings(self._h, C.byref(t))

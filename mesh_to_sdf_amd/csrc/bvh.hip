@@ -58,7 +58,8 @@ __global__ __launch_bounds__(256) void k_tri_setup(const float* __restrict__ ver
                                                    const void* __restrict__ indices, int index_bytes, int topology,
                                                    uint32_t n_tris, TriRec* __restrict__ raw, Box* __restrict__ boxes,
                                                    float4* __restrict__ cen_raw,
-                                                   int* __restrict__ scene /*6 final + 6 per block*/, int* __restrict__ err) {
+                                                   int* __restrict__ scene /*final values, then 6 per block from part_base on*/, int part_base,
+                                                   int* __restrict__ err) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   int lo[3] = {INT32_MAX, INT32_MAX, INT32_MAX}, hi[3] = {INT32_MIN, INT32_MIN, INT32_MIN};
   if (t < n_tris) {
@@ -113,7 +114,7 @@ __global__ __launch_bounds__(256) void k_tri_setup(const float* __restrict__ ver
     const int k = threadIdx.x;
     int v = part[k][0];
     for (int w = 1; w < 4; ++w) v = k < 3 ? min(v, part[k][w]) : max(v, part[k][w]);
-    scene[6 + blockIdx.x * 6 + k] = v;   // partials live behind the 6 final values
+    scene[part_base + blockIdx.x * 6 + k] = v;   // partials live behind the final values
   }
 }
 
@@ -295,6 +296,15 @@ __device__ __forceinline__ Box seg_query(const Box* __restrict__ seg, const SegL
   return acc;
 }
 
+// Slab [lo, hi] along n in the (mid, half) form the walk tests with one op less: max(|t - mid| - half, 0).
+// half is rounded up over both one-sided widths, so the stored slab contains [lo, hi].
+__device__ __forceinline__ void set_slab(NodeExt& x, float lo, float hi) {
+  const float mid = 0.5f * lo + 0.5f * hi;
+  const float w = fmaxf(hi - mid, mid - lo);
+  x.mid = mid;
+  x.half = w + fabsf(w) * 2.4e-7f;   // >= the exact widths: each subtraction above is off by <= 1/2 ulp(w)
+}
+
 // One thread per node (internal 0..n-2, leaves n-1..2n-2): pre-order slot, box, skip link,
 // and for leaves the sorted triangle record.
 __global__ __launch_bounds__(256) void k_emit(int n, const int2* __restrict__ range, const int* __restrict__ parent,
@@ -302,7 +312,8 @@ __global__ __launch_bounds__(256) void k_emit(int n, const int2* __restrict__ ra
                                               const uint32_t* __restrict__ order, const TriRec* __restrict__ raw,
                                               NodeRec* __restrict__ nodes, TriRec* __restrict__ tris,
                                               uint32_t* __restrict__ slot_first, float4* __restrict__ cen,
-                                              TriPlanes* __restrict__ planes, uint32_t leaf_max, uint32_t* __restrict__ slot_of) {
+                                              TriPlanes* __restrict__ planes, uint32_t leaf_max, uint32_t* __restrict__ slot_of,
+                                              int* __restrict__ err) {
   const int id = blockIdx.x * blockDim.x + threadIdx.x;
   if (id >= 2 * n - 1) return;
   const bool leaf = id >= n - 1;
@@ -311,13 +322,15 @@ __global__ __launch_bounds__(256) void k_emit(int n, const int2* __restrict__ ra
   else { int2 r = range[id]; first = r.x; last = r.y; }
   // number of left turns on the root -> node path
   int lefts = 0, cur = id;
-  while (true) {
+  for (int guard = 0;; ++guard) {
     const int p = parent[cur];
     if (p == INT32_MIN) break;          // root marker
     if (p >= 0) { ++lefts; cur = p; }   // cur is a left child of p
     else cur = -p - 2;                  // right child
+    if (guard > 256) { atomicOr(err, ERRF_BUILD_TIMEOUT); return; }   // a radix tree over 64 + 32 key bits is at most 96 deep: only garbage keys get here
   }
   const uint32_t slot = 2u * (uint32_t)first + (uint32_t)lefts;
+  if (slot >= 2u * (uint32_t)n - 1u || last < first || last >= n) { atomicOr(err, ERRF_BUILD_TIMEOUT); return; }   // never with sorted keys
   const uint32_t cnt = (uint32_t)(last - first + 1);
   Box b = leaf ? seg[first] : seg_query(seg, lv, first, last);
   NodeRec nr;
@@ -390,24 +403,24 @@ __device__ __forceinline__ float wave_max(float v) {
 // Pass 2: extent along it and lateral radius about the AABB centre.  All roundings go outwards.
 constexpr uint32_t EXT_THREAD_BELOW = 16;   // subtrees up to this many triangles: one THREAD per node
 
-// Slab [lo, hi] along n in the (mid, half) form the walk tests with one op less: max(|t - mid| - half, 0).
-// half is rounded up over both one-sided widths, so the stored slab contains [lo, hi].
-__device__ __forceinline__ void set_slab(NodeExt& x, float lo, float hi) {
-  const float mid = 0.5f * lo + 0.5f * hi;
-  const float w = fmaxf(hi - mid, mid - lo);
-  x.mid = mid;
-  x.half = w + fabsf(w) * 2.4e-7f;   // >= the exact widths: each subtraction above is off by <= 1/2 ulp(w)
-}
-
 // Serial version of the same computation for small subtrees (most nodes: half of them are leaves).
 __device__ __forceinline__ void node_ext_thread(const NodeRec& nr, uint32_t slot, uint32_t cnt, const uint32_t* __restrict__ slot_first,
                                                 const TriRec* __restrict__ tris, NodeExt* __restrict__ ext) {
   const uint32_t first = slot_first[slot];
+  // Both loops fetch FOUR triangles before they use the first: the records were written by the kernel before (L2 misses), and a
+  // loop that loads, waits and adds per triangle is a chain of up to 2 x 16 memory round trips — most of this kernel's 41 us for
+  // 100 k triangles.  The sums still run in the order i = 0, 1, 2, ... (a triangle past the count is skipped, not added as zero).
   float sx = 0.0f, sy = 0.0f, sz = 0.0f;
-  for (uint32_t i = 0; i < cnt; ++i) {
-    const TriRec& t = tris[first + i];
-    const f3 n = cross3(mk3(t.abx, t.aby, t.abz), mk3(t.acx, t.acy, t.acz));
-    if (fabsf(n.x) < 3.0e38f && fabsf(n.y) < 3.0e38f && fabsf(n.z) < 3.0e38f) { sx += n.x; sy += n.y; sz += n.z; }
+  for (uint32_t i0 = 0; i0 < cnt; i0 += 4) {
+    f3 nn[4];
+    for (uint32_t u = 0; u < 4; ++u) {
+      const TriRec& t = tris[first + min(i0 + u, cnt - 1u)];
+      nn[u] = cross3(mk3(t.abx, t.aby, t.abz), mk3(t.acx, t.acy, t.acz));
+    }
+    for (uint32_t u = 0; u < 4; ++u) {
+      const f3 n = nn[u];
+      if (i0 + u < cnt && fabsf(n.x) < 3.0e38f && fabsf(n.y) < 3.0e38f && fabsf(n.z) < 3.0e38f) { sx += n.x; sy += n.y; sz += n.z; }
+    }
   }
   const float len = sqrtf(sx * sx + sy * sy + sz * sz);
   float nx = 1.0f, ny = 0.0f, nz = 0.0f;
@@ -418,18 +431,24 @@ __device__ __forceinline__ void node_ext_thread(const NodeRec& nr, uint32_t slot
   if (!(fabsf(cz) < 3.0e38f)) cz = 0.0f;
   const float inf = __builtin_inff();
   float dlo = inf, dhi = -inf, r2 = 0.0f, w2max = 0.0f;
-  for (uint32_t i = 0; i < cnt; ++i) {
-    const TriRec& t = tris[first + i];
-    const float vx[3] = {t.ax, t.bx, t.cx}, vy[3] = {t.ay, t.by, t.cy}, vz[3] = {t.az, t.bz, t.cz};
-    for (int k = 0; k < 3; ++k) {
-      const float wx = vx[k] - cx, wy = vy[k] - cy, wz = vz[k] - cz;
-      const float tt = nx * wx + ny * wy + nz * wz;
-      const float w2 = wx * wx + wy * wy + wz * wz;
-      dlo = fminf(dlo, tt);
-      dhi = fmaxf(dhi, tt);
-      r2 = fmaxf(r2, w2 - tt * tt);
-      w2max = fmaxf(w2max, w2);
+  for (uint32_t i0 = 0; i0 < cnt; i0 += 4) {
+    float vx[4][3], vy[4][3], vz[4][3];
+    for (uint32_t u = 0; u < 4; ++u) {                    // a repeated last triangle changes no minimum or maximum
+      const TriRec& t = tris[first + min(i0 + u, cnt - 1u)];
+      vx[u][0] = t.ax; vx[u][1] = t.bx; vx[u][2] = t.cx;
+      vy[u][0] = t.ay; vy[u][1] = t.by; vy[u][2] = t.cy;
+      vz[u][0] = t.az; vz[u][1] = t.bz; vz[u][2] = t.cz;
     }
+    for (uint32_t u = 0; u < 4; ++u)
+      for (int k = 0; k < 3; ++k) {
+        const float wx = vx[u][k] - cx, wy = vy[u][k] - cy, wz = vz[u][k] - cz;
+        const float tt = nx * wx + ny * wy + nz * wz;
+        const float w2 = wx * wx + wy * wy + wz * wz;
+        dlo = fminf(dlo, tt);
+        dhi = fmaxf(dhi, tt);
+        r2 = fmaxf(r2, w2 - tt * tt);
+        w2max = fmaxf(w2max, w2);
+      }
   }
   const float R = sqrtf(fmaxf(r2, 0.0f) + 1.0e-6f * w2max) * 1.00001f + 1.0e-30f;
   const float e = 1.0e-5f * (fabsf(dlo) + fabsf(dhi)) + 2.0e-6f * sqrtf(w2max) + 1.0e-30f;
@@ -550,6 +569,43 @@ __global__ __launch_bounds__(256) void k_treelet_roots(int n, const int2* __rest
   }
   if (is_root) roots[atomicAdd(n_roots, 1)] = make_int2(r.x, cnt);
 }
+// The same list with ONE atomic per block (40 000 device-scope atomics on one word took 151 us for 1 M triangles): the block's
+// roots are counted by ballots, one lane reserves the block's slots.  The order of the list is arbitrary either way.
+__global__ __launch_bounds__(256) void k_treelet_roots_block(int n, const int2* __restrict__ range, const int* __restrict__ parent,
+                                                             int2* __restrict__ roots, int* __restrict__ n_roots) {
+  __shared__ int s_wcnt[4], s_base;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  bool is_root = false;
+  int2 r = make_int2(0, 0);
+  int cnt = 0;
+  if (i < n - 1) {
+    r = range[i];
+    cnt = r.y - r.x + 1;
+    if (cnt <= TREELET_MAX && cnt >= 3) {
+      const int p = parent[i];
+      is_root = p == INT32_MIN;
+      if (!is_root) {
+        const int pi = p >= 0 ? p : -p - 2;
+        const int2 pr = range[pi];
+        is_root = pr.y - pr.x + 1 > TREELET_MAX;
+      }
+    }
+  }
+  const unsigned long long bal = __ballot(is_root);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) s_wcnt[wave] = __popcll(bal);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int total = s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
+    s_base = total ? atomicAdd(n_roots, total) : 0;
+  }
+  __syncthreads();
+  if (is_root) {
+    int off = s_base + (int)__popcll(bal & ((1ull << lane) - 1ull));
+    for (int w = 0; w < wave; ++w) off += s_wcnt[w];
+    roots[off] = make_int2(r.x, cnt);
+  }
+}
 
 __global__ __launch_bounds__(TREELET_MAX) void k_treelet(const int2* __restrict__ roots, const int* __restrict__ n_roots,
                                                 const Box* __restrict__ boxes, uint64_t* __restrict__ keys,
@@ -649,11 +705,470 @@ __global__ __launch_bounds__(TREELET_MAX) void k_treelet(const int2* __restrict_
   }
 }
 
+// The same treelets with the items held BY POSITION IN THE LANES of one wave instead of in LDS arrays that every lane loops over.
+// k_treelet's four loops per level run over the lane's whole segment — O(m^2) LDS reads per level, one LDS round trip per
+// iteration: 62 us for 100 k triangles (every wave waiting on its own chain) and 290 us for 1 M (the LDS pipes saturated).  Here a
+// segment is a run of consecutive lanes, so its reductions are log-step scans bounded by the segment's ends ([s, e) is known to
+// every lane, no head flags): extents of the centres, prefix / suffix boxes in rank order, the best (cost, rank).  The scan steps
+// are DPP moves on the VALU (row_shr / row_shl inside a row of 16 lanes, row_bcast across rows for the prefixes; the suffixes
+// cross rows with two lane reads) — a first version on ds_bpermute throughout was no faster than the loops (47 / 306 us): a lane
+// permute occupies the LDS pipe like the reads it replaced.  The items move to their rank with seven lane permutes per level; only
+// the rank itself is still counted by looking at every other item of the segment (one lane read each, four in flight).  Same
+// splits, same arithmetic for the cost, same tie rules: the same keys and order as k_treelet, bit for bit.
+template <int CTRL, int ROWS>
+__device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, ROWS, 0xf, false); }   // lanes without a source keep v
+template <int CTRL, int ROWS>
+__device__ __forceinline__ float dpp_f(float v) { return __int_as_float(dpp_i<CTRL, ROWS>(__float_as_int(v))); }
+constexpr int DPP_SHR = 0x110, DPP_SHL = 0x100, DPP_BCAST15 = 0x142, DPP_BCAST31 = 0x143, DPP_WAVE_SHL1 = 0x130;
+
+// inclusive scan towards higher lanes over [s, lane]; MIN: fminf, else fmaxf
+template <bool MIN>
+__device__ __forceinline__ float seg_prefix(float v, int lane, int s) {
+#define M2S_STEP(CTRL, ROWS, SRC) { const float t = dpp_f<CTRL, ROWS>(v); const float u = MIN ? fminf(v, t) : fmaxf(v, t); v = (SRC) >= s ? u : v; }
+  M2S_STEP(DPP_SHR + 1, 0xf, lane - 1)
+  M2S_STEP(DPP_SHR + 2, 0xf, lane - 2)
+  M2S_STEP(DPP_SHR + 4, 0xf, lane - 4)
+  M2S_STEP(DPP_SHR + 8, 0xf, lane - 8)
+  M2S_STEP(DPP_BCAST15, 0xa, (lane & ~15) - 1)
+  M2S_STEP(DPP_BCAST31, 0xc, 31)
+#undef M2S_STEP
+  return v;
+}
+// inclusive scan towards lower lanes over [lane, e)
+template <bool MIN>
+__device__ __forceinline__ float seg_suffix(float v, int lane, int e) {
+#define M2S_STEP(CTRL, SRC) { const float t = dpp_f<CTRL, 0xf>(v); const float u = MIN ? fminf(v, t) : fmaxf(v, t); v = (SRC) < e ? u : v; }
+  M2S_STEP(DPP_SHL + 1, lane + 1)
+  M2S_STEP(DPP_SHL + 2, lane + 2)
+  M2S_STEP(DPP_SHL + 4, lane + 4)
+  M2S_STEP(DPP_SHL + 8, lane + 8)
+#undef M2S_STEP
+  {
+    const int src = (lane | 15) + 1;                              // first lane of the next row (rows 0 and 2 take it)
+    const float t = __shfl(v, src & 63), u = MIN ? fminf(v, t) : fmaxf(v, t);
+    v = (!(lane & 16) && src < e) ? u : v;
+  }
+  {
+    const float t = __shfl(v, 32), u = MIN ? fminf(v, t) : fmaxf(v, t);
+    v = (lane < 32 && 32 < e) ? u : v;
+  }
+  return v;
+}
+
+__global__ __launch_bounds__(64) void k_treelet_lanes(const int2* __restrict__ roots, const int* __restrict__ n_roots,
+                                                      const Box* __restrict__ boxes, uint64_t* __restrict__ keys,
+                                                      uint32_t* __restrict__ order) {
+  // a few thousand single-wave blocks take the roots in turn (one block per POSSIBLE root — n / 3 of them, nine in ten with
+  // nothing to do — spent more time being dispatched than the treelets took)
+  const int total = *n_roots, lane = threadIdx.x;
+  for (int r = blockIdx.x; r < total; r += gridDim.x) {
+  const int2 root = roots[r];
+  const int first = root.x, m = root.y;
+  const bool live = lane < m;
+  const uint64_t k_first = keys[first], k_last = keys[first + m - 1];
+  if (k_first == k_last) continue;                                // identical centres: no room below the prefix
+  const int prefix = __clzll((long long)(k_first ^ k_last));      // bits the node's keys share
+  const int room = 64 - prefix;                                   // bits left for the path inside the treelet
+  uint32_t tri = live ? order[first + lane] : 0u;
+  Box b = {0, 0, 0, 0, 0, 0};
+  if (live) b = boxes[tri];
+  int s = lane, e = live ? m : lane + 1;                          // my segment [s, e) of lanes; I am the item at position `lane`
+  if (live) s = 0;
+  uint64_t code = 0;
+  int depth = 0;
+  const float inf = __builtin_inff();
+  for (int level = 0; level < 64; ++level) {
+    const bool open = live && e - s > 1 && depth < room;
+    if (__ballot(open) == 0ull) break;
+    // widest axis of the centres of my segment
+    const float cen[3] = {0.5f * (b.mnx + b.mxx), 0.5f * (b.mny + b.mxy), 0.5f * (b.mnz + b.mxz)};
+    const int tail = e - 1;
+    float ext[3];
+    for (int k = 0; k < 3; ++k) ext[k] = __shfl(seg_prefix<false>(cen[k], lane, s), tail) - __shfl(seg_prefix<true>(cen[k], lane, s), tail);
+    int axis = 2;
+    if (open) axis = (ext[0] >= ext[1] && ext[0] >= ext[2]) ? 0 : (ext[1] >= ext[2] ? 1 : 2);   // NaN extents: comparisons false -> axis 2
+    const int key = ord(axis == 0 ? cen[0] : (axis == 1 ? cen[1] : cen[2]));                    // total order, NaN included
+    // my rank inside my segment along that axis (strict order by (key, position))
+    int rank = lane;
+    {
+      int longest = open ? e - s : 0;
+      for (int o = 32; o > 0; o >>= 1) longest = max(longest, __shfl_xor(longest, o));
+      int cnt = 0;
+      for (int it = 0; it < longest; it += 4) {
+        int oj[4];
+        for (int u = 0; u < 4; ++u) oj[u] = __shfl(key, min(s + it + u, 63));
+        for (int u = 0; u < 4; ++u) {
+          const int j = s + it + u;
+          cnt += (open && j < e && (oj[u] < key || (oj[u] == key && j < lane))) ? 1 : 0;
+        }
+      }
+      if (open) rank = s + cnt;
+    }
+    // every item to the lane of its rank (closed segments stay where they are)
+    {
+      const int dst = rank << 2;
+      b.mnx = __int_as_float(__builtin_amdgcn_ds_permute(dst, __float_as_int(b.mnx)));
+      b.mny = __int_as_float(__builtin_amdgcn_ds_permute(dst, __float_as_int(b.mny)));
+      b.mnz = __int_as_float(__builtin_amdgcn_ds_permute(dst, __float_as_int(b.mnz)));
+      b.mxx = __int_as_float(__builtin_amdgcn_ds_permute(dst, __float_as_int(b.mxx)));
+      b.mxy = __int_as_float(__builtin_amdgcn_ds_permute(dst, __float_as_int(b.mxy)));
+      b.mxz = __int_as_float(__builtin_amdgcn_ds_permute(dst, __float_as_int(b.mxz)));
+      tri = (uint32_t)__builtin_amdgcn_ds_permute(dst, (int)tri);
+    }
+    // the split after me: boxes of the items up to my position and of the rest
+    const float L[6] = {seg_prefix<true>(b.mnx, lane, s), seg_prefix<true>(b.mny, lane, s), seg_prefix<true>(b.mnz, lane, s),
+                        seg_prefix<false>(b.mxx, lane, s), seg_prefix<false>(b.mxy, lane, s), seg_prefix<false>(b.mxz, lane, s)};
+    const float S[6] = {seg_suffix<true>(b.mnx, lane, e), seg_suffix<true>(b.mny, lane, e), seg_suffix<true>(b.mnz, lane, e),
+                        seg_suffix<false>(b.mxx, lane, e), seg_suffix<false>(b.mxy, lane, e), seg_suffix<false>(b.mxz, lane, e)};
+    float Rr[6];
+    for (int k = 0; k < 6; ++k) Rr[k] = dpp_f<DPP_WAVE_SHL1, 0xf>(S[k]);   // S of lane + 1
+    int cost_key = INT32_MAX;
+    {
+      const int n_left = lane - s + 1, n_right = e - lane - 1;
+      float r0 = inf, r1 = inf, r2 = inf, r3 = -inf, r4 = -inf, r5 = -inf;
+      if (n_right > 0) { r0 = Rr[0]; r1 = Rr[1]; r2 = Rr[2]; r3 = Rr[3]; r4 = Rr[4]; r5 = Rr[5]; }
+      const float cost = ((L[3] - L[0]) + (L[4] - L[1]) + (L[5] - L[2])) * (float)n_left + ((r3 - r0) + (r4 - r1) + (r5 - r2)) * (float)n_right;
+      if (open && n_right > 0) cost_key = ord(cost);              // the last rank is not a split
+    }
+    // the best split of my segment: smallest (cost, rank); all INT32_MAX keeps the fallback
+    int bc = (int)((uint32_t)cost_key ^ 0x80000000u), br = lane;   // cost as unsigned order in a signed... compared as uint below
+    {
+#define M2S_STEP(CTRL, ROWS, SRC) { const uint32_t tc = (uint32_t)dpp_i<CTRL, ROWS>(bc); const int tr = dpp_i<CTRL, ROWS>(br); \
+        const bool less = tc < (uint32_t)bc || (tc == (uint32_t)bc && tr < br); const bool ok = (SRC) >= s && less; bc = ok ? (int)tc : bc; br = ok ? tr : br; }
+      M2S_STEP(DPP_SHR + 1, 0xf, lane - 1)
+      M2S_STEP(DPP_SHR + 2, 0xf, lane - 2)
+      M2S_STEP(DPP_SHR + 4, 0xf, lane - 4)
+      M2S_STEP(DPP_SHR + 8, 0xf, lane - 8)
+      M2S_STEP(DPP_BCAST15, 0xa, (lane & ~15) - 1)
+      M2S_STEP(DPP_BCAST31, 0xc, 31)
+#undef M2S_STEP
+    }
+    const uint32_t best_cost = (uint32_t)__shfl(bc, tail);
+    const int best_at = __shfl(br, tail);
+    if (open) {
+      int best_rank = s + (e - s) / 2 - 1;
+      if (best_cost != 0xffffffffu) best_rank = best_at;
+      const bool right = lane > best_rank;
+      code = (code << 1) | (right ? 1ull : 0ull);
+      ++depth;
+      if (right) s = best_rank + 1; else e = best_rank + 1;
+    }
+  }
+  if (live) {
+    // Morton prefix of the node (shared by all its keys), then the path inside the treelet, left aligned (depth <= room)
+    const uint64_t mask = ~0ull << room;
+    const uint64_t path = depth ? code << (room - depth) : 0ull;
+    keys[first + lane] = (k_first & mask) | path;
+    order[first + lane] = tri;
+  }
+  }
+}
+
 __global__ void k_init_scene(int* scene, int* parent, int n_nodes) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < 3) scene[i] = INT32_MAX;
   else if (i < 6) scene[i] = INT32_MIN;
   if (i < n_nodes) parent[i] = INT32_MIN;
+}
+
+
+// ======== round 3: the lean build ====================================================================================
+// The round-2 build was ~45 launch-bound kernels (0.36 ms for 100 k triangles, 1.4 ms for 1 M) on every rank of a multi-GPU
+// run — the part of a rank's step that does not shard.  The lean build keeps the TREE bit for bit and spends fewer, fuller
+// launches on it:
+//   k_tri_setup       also clears the sort's counters and the parent markers          (was + k_init_scene)
+//   k_morton_hist     folds the scene partials itself, writes the keys and all seven digit histograms
+//                                                                                      (was k_scene_reduce + k_morton)
+//   k_sort_pass x 7   own LSD radix sort, 9 bits per pass, one kernel per pass with a decoupled look-back
+//                                                                                      (was rocPRIM: 9 / 22 kernels)
+//   k_seg_build       ten segment-tree levels per block in LDS, the last block to finish adds the top levels
+//                                                                                      (was 6 launches of k_seg_level3)
+// M2S_BUILD=0 selects the round-2 sequence (A/B and tests/test_gpu_build.py, which compares the two trees byte for byte).
+constexpr int SORT_DIGIT = 9, SORT_BINS = 1 << SORT_DIGIT, SORT_PASSES = 7;        // 7 x 9 = the 63 bits of a key
+#ifndef M2S_SORT_KPT
+#define M2S_SORT_KPT 8
+#endif
+constexpr int SORT_THREADS = 512, SORT_KPT = M2S_SORT_KPT, SORT_CHUNK = SORT_THREADS * SORT_KPT;
+constexpr uint32_t SORT_MAX_TILES = 128;
+// The sort's tiles: at most SORT_MAX_TILES of them (all resident at once: a block only ever waits for blocks with lower
+// indices, which the dispatcher started before it), each a whole number of chunks, one block per tile and pass.
+__host__ __device__ inline uint32_t sort_tile_pairs(size_t n) {
+  const size_t chunks = (n + SORT_CHUNK - 1) / SORT_CHUNK;
+  return (uint32_t)((chunks + SORT_MAX_TILES - 1) / SORT_MAX_TILES) * SORT_CHUNK;
+}
+__host__ __device__ inline uint32_t sort_tiles(size_t n) {
+  const uint32_t tp = sort_tile_pairs(n);
+  return tp ? (uint32_t)((n + tp - 1) / tp) : 0u;
+}
+// Words of sort workspace: the seven digit histograms, 16 counters ([0]: k_seg_build's finished blocks), the (tile, digit) words
+// the tiles of a pass publish for each other.
+__host__ __device__ inline size_t sort_aux_words(size_t n) { return (size_t)SORT_PASSES * SORT_BINS + 16 + (size_t)sort_tiles(n) * SORT_BINS; }
+
+// Clears the sort's tables and writes the "no parent yet" markers (what k_init_scene and a memset did).
+__global__ __launch_bounds__(256) void k_clear_aux(uint32_t* __restrict__ aux, size_t words, int* __restrict__ parent, int n_nodes) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t k = i; k < words; k += stride) aux[k] = 0u;
+  for (size_t k = i; k < (size_t)n_nodes; k += stride) parent[k] = INT32_MIN;
+}
+
+// Keys + the seven digit histograms.  One block per sort tile; every block folds the scene partials of k_tri_setup itself.
+__global__ __launch_bounds__(SORT_THREADS) void k_morton_hist(const Box* __restrict__ boxes, uint32_t n_tris, int* __restrict__ scene,
+                                                               uint32_t n_partials, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals,
+                                                               uint32_t* __restrict__ hist, uint32_t tile_pairs) {
+  __shared__ uint32_t s_hist[SORT_PASSES * SORT_BINS];
+  __shared__ int s_part[6][SORT_THREADS / 64];
+  __shared__ int s_scene[6];
+  const uint32_t tid = threadIdx.x;
+  // every block folds the per-block partials of k_tri_setup (scene[8 + 6 b + k]) itself: a few KB out of L2
+  int lo[3] = {INT32_MAX, INT32_MAX, INT32_MAX}, hi[3] = {INT32_MIN, INT32_MIN, INT32_MIN};
+  for (uint32_t b = tid; b < n_partials; b += SORT_THREADS)
+    for (int k = 0; k < 3; ++k) {
+      lo[k] = min(lo[k], scene[8 + b * 6 + k]);
+      hi[k] = max(hi[k], scene[8 + b * 6 + 3 + k]);
+    }
+  for (int k = 0; k < 3; ++k) {
+    int l = lo[k], h = hi[k];
+    for (int off = 32; off > 0; off >>= 1) {
+      l = min(l, __shfl_xor(l, off));
+      h = max(h, __shfl_xor(h, off));
+    }
+    if ((tid & 63u) == 0) { s_part[k][tid >> 6] = l; s_part[3 + k][tid >> 6] = h; }
+  }
+  for (uint32_t i = tid; i < (uint32_t)(SORT_PASSES * SORT_BINS); i += SORT_THREADS) s_hist[i] = 0u;
+  __syncthreads();
+  if (tid < 6) {
+    int v = s_part[tid][0];
+    for (int w = 1; w < SORT_THREADS / 64; ++w) v = tid < 3 ? min(v, s_part[tid][w]) : max(v, s_part[tid][w]);
+    s_scene[tid] = v;
+  }
+  __syncthreads();
+  if (blockIdx.x == 0 && tid == 0) {   // the final values for everybody after the build (k_scene_reduce's outputs)
+    float s = 0.0f;
+    for (int k = 0; k < 6; ++k) {
+      scene[k] = s_scene[k];
+      const float f = unord(s_scene[k]);
+      if (f == f && fabsf(f) < 3.0e38f) s = fmaxf(s, fabsf(f));
+    }
+    scene[6] = __float_as_int(s);
+    scene[7] = 0;
+  }
+  float slo[3], shi[3];
+  for (int k = 0; k < 3; ++k) { slo[k] = unord(s_scene[k]); shi[k] = unord(s_scene[3 + k]); }
+  const uint32_t base = blockIdx.x * tile_pairs, end = min(n_tris, base + tile_pairs);
+  for (uint32_t t = base + tid; t < end; t += SORT_THREADS) {
+    const Box bx = boxes[t];
+    const float c[3] = {0.5f * (bx.mnx + bx.mxx), 0.5f * (bx.mny + bx.mxy), 0.5f * (bx.mnz + bx.mxz)};
+    uint32_t q[3];
+    for (int k = 0; k < 3; ++k) {       // k_morton's arithmetic
+      float u = (c[k] - slo[k]) / (shi[k] - slo[k]);
+      u = (u == u) ? fminf(fmaxf(u, 0.0f), 1.0f) : 0.0f;
+      q[k] = min((uint32_t)(u * 2097152.0f), 2097151u);
+    }
+    const uint64_t key = (expand21(q[0]) << 2) | (expand21(q[1]) << 1) | expand21(q[2]);
+    keys[t] = key;
+    vals[t] = t;
+    for (int p = 0; p < SORT_PASSES; ++p) atomicAdd(&s_hist[p * SORT_BINS + (uint32_t)((key >> (SORT_DIGIT * p)) & (SORT_BINS - 1))], 1u);
+  }
+  __syncthreads();
+  for (uint32_t i = tid; i < (uint32_t)(SORT_PASSES * SORT_BINS); i += SORT_THREADS) {
+    const uint32_t c = s_hist[i];
+    if (c) atomicAdd(&hist[i], c);
+  }
+}
+
+// One pass of the LSD sort: stable scatter of (key, value) by the 9-bit digit at `shift`.  One block per tile, all tiles resident.
+// Order of business, arranged so that nothing waits for anything it does not need (stamped on MI355X, 25 tiles of 4096):
+//   1. the tile's pairs into registers (wave w holds its eighth of the tile: 512 or 1024 consecutive pairs);
+//   2. the tile's digit counts by LDS atomics, PUBLISHED at once (`status`: [31:28] = pass + 1, so that words of earlier passes
+//      read as "not yet"; device-scope accesses — the tiles run on eight XCDs), and the words of the first sixteen earlier tiles
+//      requested right away: they arrive while the tile is ranked.  (Publishing after the ranks made the last tile wait 9 us for
+//      its neighbours: every tile spent 3 us ranking before anybody could see its counts.)
+//   3. ranks: a pair's rank among the pairs of its digit in (wave, round, lane) order — the input order: every pass is stable,
+//      as an LSD sort needs.  Match-any by nine ballots gives every lane its peers; the lowest peer adds the group's size to the
+//      wave's running digit count with ONE returning LDS atomic per round — the eight rounds' atomics are issued back to back
+//      (a wave's LDS operations execute in order) and collected with eight lane reads afterwards: two LDS latencies in all.
+//   4. a thread per digit stacks the waves, adds up the earlier tiles (any word still missing is re-requested, sixteen at a
+//      time), and the digit's start is the scan of the pass's histogram; every pair goes straight to its place.
+// A tile that waits ~1 s for a word gives up and flags ERRF_BUILD_TIMEOUT (a fault elsewhere must not hang the GPU).
+constexpr uint32_t SORT_COUNT_MASK = (1u << 28) - 1u;
+template <int CHUNKS>
+__global__ __launch_bounds__(SORT_THREADS) void k_sort_pass(const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
+                                                             uint64_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, uint32_t n,
+                                                             uint32_t shift, const uint32_t* __restrict__ hist, uint32_t* __restrict__ status,
+                                                             uint32_t gen, uint32_t tile_pairs, int* __restrict__ err, unsigned long long* __restrict__ stamps) {
+  constexpr int R = CHUNKS * SORT_KPT;                       // rounds of 64 pairs per wave
+  __shared__ uint32_t s_cnt[SORT_THREADS / 64][SORT_BINS];
+  __shared__ uint32_t s_hist[SORT_BINS];
+  __shared__ uint32_t s_base[SORT_BINS];
+  __shared__ uint32_t s_wsum[SORT_THREADS / 64];
+  const bool stamp = stamps != nullptr && threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1);
+  unsigned long long* sp = stamps + (blockIdx.x == 0 ? 0 : 8);
+  if (stamp) sp[0] = wall_clock64();
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, tile = blockIdx.x;
+  const uint32_t tile_begin = tile * tile_pairs, tile_end = min(n, tile_begin + tile_pairs);
+  const uint32_t first = tile_begin + wave * (R * 64u) + lane;
+  const uint32_t hist_d = hist[tid];
+  uint64_t key[R];
+  uint32_t val[R], rank[R];
+  for (int j = 0; j < R; ++j) {
+    const uint32_t idx = first + j * 64u;
+    key[j] = idx < tile_end ? keys_in[idx] : ~0ull;
+    val[j] = idx < tile_end ? vals_in[idx] : 0u;
+  }
+  for (uint32_t i = tid; i < (uint32_t)(SORT_THREADS / 64 * SORT_BINS); i += SORT_THREADS) (&s_cnt[0][0])[i] = 0u;
+  s_hist[tid] = 0u;
+  __syncthreads();
+  for (int j = 0; j < R; ++j)
+    if (first + j * 64u < tile_end) atomicAdd(&s_hist[(uint32_t)((key[j] >> shift) & (SORT_BINS - 1))], 1u);
+  __syncthreads();
+  if (stamp) sp[1] = wall_clock64();
+  __hip_atomic_store(status + (size_t)tile * SORT_BINS + tid, (gen << 28) | s_hist[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  uint32_t v[16];                                            // the first sixteen earlier tiles' words, requested before the ranking
+  for (uint32_t k = 0; k < 16u; ++k) v[k] = k < tile ? __hip_atomic_load(status + (size_t)k * SORT_BINS + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (gen << 28);
+  // ranks
+  {
+    uint32_t leader[R], group[R];
+    for (int j = 0; j < R; ++j) {
+      const bool valid = first + j * 64u < tile_end;
+      const uint32_t d = (uint32_t)((key[j] >> shift) & (SORT_BINS - 1));
+      unsigned long long mask = __ballot(valid);
+      for (int b = 0; b < SORT_DIGIT; ++b) {
+        const bool bit = (d >> b) & 1u;
+        const unsigned long long bal = __ballot(bit);
+        mask &= bit ? bal : ~bal;
+      }
+      rank[j] = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));   // peers below me
+      leader[j] = valid ? (uint32_t)(__ffsll((long long)mask) - 1) : lane;
+      group[j] = (uint32_t)__popcll(mask);
+    }
+    uint32_t old[R];
+    for (int j = 0; j < R; ++j) {
+      old[j] = 0u;
+      if (leader[j] == lane && first + j * 64u < tile_end)
+        old[j] = atomicAdd(&s_cnt[wave][(uint32_t)((key[j] >> shift) & (SORT_BINS - 1))], group[j]);
+    }
+    for (int j = 0; j < R; ++j) rank[j] += __shfl(old[j], (int)leader[j]);
+  }
+  __syncthreads();
+  if (stamp) sp[2] = wall_clock64();
+  {
+    // thread = digit: stack the waves, add up the earlier tiles, find the digit's start
+    uint32_t run = 0;
+    for (int w = 0; w < SORT_THREADS / 64; ++w) { const uint32_t c = s_cnt[w][tid]; s_cnt[w][tid] = run; run += c; }
+    uint32_t x = hist_d;
+    for (uint32_t o = 1; o < 64u; o <<= 1) {
+      const uint32_t y = __shfl_up(x, o);
+      if (lane >= o) x += y;
+    }
+    if (lane == 63u) s_wsum[wave] = x;
+    uint32_t before = 0;
+    bool timeout = false;
+    for (uint32_t t0 = 0; t0 < tile; t0 += 16u) {
+      if (t0) for (uint32_t k = 0; k < 16u; ++k) v[k] = t0 + k < tile ? __hip_atomic_load(status + (size_t)(t0 + k) * SORT_BINS + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (gen << 28);
+      for (uint32_t spins = 0;; ++spins) {
+        bool all = true;
+        for (uint32_t k = 0; k < 16u; ++k) all &= (v[k] >> 28) == gen;
+        if (all) break;
+        if (spins > 2000000u) { timeout = true; break; }
+        __builtin_amdgcn_s_sleep(4);
+        for (uint32_t k = 0; k < 16u; ++k)      // everything still missing again, together
+          if ((v[k] >> 28) != gen) v[k] = __hip_atomic_load(status + (size_t)(t0 + k) * SORT_BINS + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      for (uint32_t k = 0; k < 16u; ++k) before += v[k] & SORT_COUNT_MASK;
+    }
+    if (timeout) atomicOr(err, ERRF_BUILD_TIMEOUT);
+    __syncthreads();
+    uint32_t wpre = 0;
+    for (uint32_t w = 0; w < wave; ++w) wpre += s_wsum[w];
+    s_base[tid] = wpre + x - hist_d + before;
+  }
+  __syncthreads();
+  if (stamp) sp[3] = wall_clock64();
+  for (int j = 0; j < R; ++j) {
+    const uint32_t idx = first + j * 64u;
+    if (idx >= tile_end) continue;
+    const uint32_t d = (uint32_t)((key[j] >> shift) & (SORT_BINS - 1));
+    const uint32_t pos = s_base[d] + s_cnt[wave][d] + rank[j];
+    keys_out[pos] = key[j];
+    vals_out[pos] = val[j];
+  }
+  if (stamp) sp[4] = wall_clock64();
+}
+
+// Segment tree of the leaf boxes in two steps inside ONE launch: every block builds the levels 0..SEG_LOCAL of its 512 leaves in
+// LDS, and the block that finishes last (a ticket behind a device-scope fence) adds the levels above from the blocks' tops.
+// Unions are min / max: any order gives the same boxes as k_seg_level3.
+constexpr int SEG_LOCAL = 9;
+__global__ __launch_bounds__(256) void k_seg_build(const Box* __restrict__ boxes, const uint32_t* __restrict__ order, uint32_t n,
+                                                   Box* __restrict__ seg, SegLevels lv, uint32_t* __restrict__ done) {
+  __shared__ Box s[1024], s2[512];
+  __shared__ bool s_last;
+  const uint32_t t = threadIdx.x, leaf0 = blockIdx.x * 512u;
+  for (uint32_t k = t; k < 512u; k += 256u) {
+    const uint32_t i = leaf0 + k;
+    if (i < n) { const Box b = boxes[order[i]]; s[k] = b; seg[i] = b; }
+  }
+  __syncthreads();
+  for (int l = 1; l <= SEG_LOCAL && l < lv.levels; ++l) {
+    const uint32_t m = 512u >> l, gj = (leaf0 >> l) + t;
+    Box u{};
+    const bool have = t < m && gj < lv.cnt[l];
+    if (have) {
+      u = s[2 * t];
+      if (2 * gj + 1 < lv.cnt[l - 1]) u = box_union(u, s[2 * t + 1]);
+    }
+    __syncthreads();
+    if (have) {
+      s[t] = u;
+      if (l < SEG_LOCAL || lv.levels <= SEG_LOCAL + 1) seg[lv.off[l] + gj] = u;
+      else {
+        // the block's top entry is what the last block reads: written through to memory (device scope) and acknowledged before
+        // the block counts itself — no L2 write-back fence (a release fence per block made this kernel 171 us for 1 M triangles)
+        uint32_t* dst = reinterpret_cast<uint32_t*>(seg + lv.off[l] + gj);
+        const float f[6] = {u.mnx, u.mny, u.mnz, u.mxx, u.mxy, u.mxz};
+        for (int k = 0; k < 6; ++k) __hip_atomic_store(dst + k, __float_as_uint(f[k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    __syncthreads();
+  }
+  if (lv.levels <= SEG_LOCAL + 1) return;
+  if (t == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    s_last = __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  auto load_top = [&](uint32_t j) {          // level SEG_LOCAL, written by other blocks: read past this XCD's L2
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(seg + lv.off[SEG_LOCAL] + j);
+    float f[6];
+    for (int k = 0; k < 6; ++k) f[k] = __uint_as_float(__hip_atomic_load(src + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    return Box{f[0], f[1], f[2], f[3], f[4], f[5]};
+  };
+  int l = SEG_LOCAL + 1;
+  for (; l < lv.levels && lv.cnt[l - 1] > 1024u; ++l) {       // too wide for LDS: through memory (meshes above 512 k triangles)
+    for (uint32_t j = t; j < lv.cnt[l]; j += 256u) {
+      Box u = l == SEG_LOCAL + 1 ? load_top(2 * j) : seg[lv.off[l - 1] + 2 * j];
+      if (2 * j + 1 < lv.cnt[l - 1]) u = box_union(u, l == SEG_LOCAL + 1 ? load_top(2 * j + 1) : seg[lv.off[l - 1] + 2 * j + 1]);
+      seg[lv.off[l] + j] = u;
+    }
+    __syncthreads();
+  }
+  if (l >= lv.levels) return;
+  for (uint32_t j = t; j < lv.cnt[l - 1]; j += 256u) s[j] = l == SEG_LOCAL + 1 ? load_top(j) : seg[lv.off[l - 1] + j];
+  __syncthreads();
+  Box* from = s;
+  Box* to = s2;
+  for (; l < lv.levels; ++l) {                                 // the rest in LDS, every level written out as it appears
+    const uint32_t m = lv.cnt[l - 1];
+    for (uint32_t j = t; j < lv.cnt[l]; j += 256u) {
+      Box u = from[2 * j];
+      if (2 * j + 1 < m) u = box_union(u, from[2 * j + 1]);
+      to[j] = u;
+      seg[lv.off[l] + j] = u;
+    }
+    __syncthreads();
+    Box* tmp = from; from = to; to = tmp;
+  }
 }
 
 inline unsigned cdiv(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }
@@ -665,7 +1180,7 @@ size_t bvh_workspace_bytes(size_t n_tris) {
   size_t sort_tmp = 0;
   (void)rocprim::radix_sort_pairs(nullptr, sort_tmp, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr,
                             (uint32_t*)nullptr, n, 0, 64, (hipStream_t)0);
-  size_t b = 0;
+  size_t b = sort_aux_words(n) * 4 + 256;
   b += n * sizeof(TriRec) * 2 + n * 16 + 256 + n * 16 + 256 + n * 4 + 256 + n * sizeof(TriPlanes) + 256 + n * sizeof(Box) * 3 + n * (8 + 4) * 2 + sort_tmp;
   b += n * (sizeof(int2) * 2) + 2 * n * sizeof(int) + 2 * n * sizeof(NodeRec) + 2 * n * (sizeof(NodeExt) + 4);
   return b + 64 * 256 + 4096 + 24 * ((n + 255) / 256) + 256;
@@ -712,27 +1227,62 @@ int build_device_mesh(Arena& ws, hipStream_t st, const float* d_verts, size_t n_
   NodeExt* ext = ws.take<NodeExt>(2 * n_tris);
   uint32_t* slot_first = ws.take<uint32_t>(2 * n_tris);
   int* scene = ws.take<int>(8 + 6 * ((n_tris + 255) / 256));
+  const int build_env = getenv("M2S_BUILD") ? atoi(getenv("M2S_BUILD")) : 1;   // 0 = the round-2 sequence (read per call: the tests switch it)
+  const bool lean = build_env != 0 && !getenv("M2S_KEYS_FILE");
+  unsigned long long* stamps = getenv("M2S_BUILD_STAMPS") ? ws.take<unsigned long long>(64) : nullptr;   // experiment: phase times of one sort pass
+  const size_t aux_words = sort_aux_words(n_tris);
+  const uint32_t sort_nt = sort_tiles(n_tris), sort_tp = sort_tile_pairs(n_tris);
+  uint32_t* aux = ws.take<uint32_t>(aux_words);
+  uint32_t* sort_hist = aux;                                       // [SORT_PASSES][SORT_BINS]
+  uint32_t* aux_counters = aux + SORT_PASSES * SORT_BINS;          // [0]: k_seg_build's finished blocks
+  uint32_t* sort_status = aux_counters + 16;                       // [tiles][SORT_BINS]
   size_t sort_tmp = 0;
   (void)rocprim::radix_sort_pairs(nullptr, sort_tmp, keys, keys2, vals, order, n_tris, 0, 64, st);
   void* tmp = ws.take<char>(sort_tmp ? sort_tmp : 1);
   if (!raw || !tris || !boxes || !seg || !keys || !keys2 || !vals || !order || !range || !child || !parent || !nodes ||
-      !scene || !tmp || !ext || !cen_raw || !slot_of || !slot_first || !cen || !planes) {
+      !scene || !tmp || !ext || !aux || !cen_raw || !slot_of || !slot_first || !cen || !planes) {
     set_error("internal: BVH workspace too small");
     return M2S_ERR_HIP_INTERNAL;
   }
 
   const unsigned B = 256;
   static const uint32_t leaf_max = getenv("M2S_LEAF_MAX") ? std::max(1u, (uint32_t)atoi(getenv("M2S_LEAF_MAX"))) : 2u;
-  hipLaunchKernelGGL(k_init_scene, dim3(cdiv(2 * n_tris, B)), dim3(B), 0, st, scene, parent, 2 * n - 1);
-  hipLaunchKernelGGL(k_tri_setup, dim3(cdiv(n_tris, B)), dim3(B), 0, st, d_verts, (uint32_t)n_verts, d_indices,
-                     index_bytes, topology, (uint32_t)n_tris, raw, boxes, cen_raw, scene, d_err);
-  hipLaunchKernelGGL(k_scene_reduce, dim3(1), dim3(256), 0, st, scene, (uint32_t)cdiv(n_tris, B));
+  if (lean) {
+    hipLaunchKernelGGL(k_tri_setup, dim3(cdiv(n_tris, B)), dim3(B), 0, st, d_verts, (uint32_t)n_verts, d_indices,
+                       index_bytes, topology, (uint32_t)n_tris, raw, boxes, cen_raw, scene, 8, d_err);
+    hipLaunchKernelGGL(k_clear_aux, dim3(std::min(1024u, cdiv(std::max(aux_words, 2 * n_tris), B))), dim3(B), 0, st, aux, aux_words, parent, 2 * n - 1);
+  } else {
+    hipLaunchKernelGGL(k_init_scene, dim3(cdiv(2 * n_tris, B)), dim3(B), 0, st, scene, parent, 2 * n - 1);
+    hipLaunchKernelGGL(k_tri_setup, dim3(cdiv(n_tris, B)), dim3(B), 0, st, d_verts, (uint32_t)n_verts, d_indices,
+                       index_bytes, topology, (uint32_t)n_tris, raw, boxes, cen_raw, scene, 6, d_err);
+    hipLaunchKernelGGL(k_scene_reduce, dim3(1), dim3(256), 0, st, scene, (uint32_t)cdiv(n_tris, B));
+  }
   out->cen_raw = cen_raw;
   out->slot_of = slot_of;
   if (after_setup) {   // the caller's seed passes only need the centroids: they run beside the sort and the hierarchy
     const int rc = (*after_setup)(cen_raw, raw, 0);   // phase 0: mark this point of the stream (an event), launch nothing yet
     if (rc) return rc;
   }
+  if (lean) {
+    hipLaunchKernelGGL(k_morton_hist, dim3(sort_nt), dim3(SORT_THREADS), 0, st, boxes, (uint32_t)n_tris, scene, (uint32_t)cdiv(n_tris, B), keys, vals, sort_hist, sort_tp);
+    uint64_t *ka = keys, *kb = keys2;
+    uint32_t *va = vals, *vb = order;
+    const uint32_t chunks_per_tile = sort_tp / SORT_CHUNK;
+    const bool own_sort = getenv("M2S_SORT") && atoi(getenv("M2S_SORT")) == 1;   // experiment: the own LSD sort below (slower than rocPRIM's merge sort so far)
+    if (chunks_per_tile > 2 || !own_sort) {   // above 128 x 2 x 4096 = 1 M pairs a tile no longer fits the registers of its block: the library sort
+      M2S_HIP_CHECK(rocprim::radix_sort_pairs(tmp, sort_tmp, keys, keys2, vals, order, n_tris, 0, 64, st));
+    } else
+    for (int p = 0; p < SORT_PASSES; ++p) {                          // seven passes: the result lands in (keys2, order)
+      if (chunks_per_tile <= 1)
+        hipLaunchKernelGGL(k_sort_pass<1>, dim3(sort_nt), dim3(SORT_THREADS), 0, st, (const uint64_t*)ka, (const uint32_t*)va, kb, vb, (uint32_t)n_tris,
+                           (uint32_t)(SORT_DIGIT * p), (const uint32_t*)(sort_hist + p * SORT_BINS), sort_status, (uint32_t)(p + 1), sort_tp, d_err, p == 3 ? stamps : nullptr);
+      else
+        hipLaunchKernelGGL(k_sort_pass<2>, dim3(sort_nt), dim3(SORT_THREADS), 0, st, (const uint64_t*)ka, (const uint32_t*)va, kb, vb, (uint32_t)n_tris,
+                           (uint32_t)(SORT_DIGIT * p), (const uint32_t*)(sort_hist + p * SORT_BINS), sort_status, (uint32_t)(p + 1), sort_tp, d_err, p == 3 ? stamps : nullptr);
+      std::swap(ka, kb);
+      std::swap(va, vb);
+    }
+  } else {
   hipLaunchKernelGGL(k_morton, dim3(cdiv(n_tris, B)), dim3(B), 0, st, boxes, (uint32_t)n_tris, scene, keys, vals);
   if (const char* kf = getenv("M2S_KEYS_FILE")) {
     // Experiment knob (tools/exp_tree.py): one 64-bit key per triangle from a file instead of the Morton keys.  The
@@ -747,6 +1297,7 @@ int build_device_mesh(Arena& ws, hipStream_t st, const float* d_verts, size_t n_
     M2S_HIP_CHECK(hipStreamSynchronize(st));
   }
   M2S_HIP_CHECK(rocprim::radix_sort_pairs(tmp, sort_tmp, keys, keys2, vals, order, n_tris, 0, 64, st));
+  }
   if (n > 1) hipLaunchKernelGGL(k_karras, dim3(cdiv(n_tris - 1, B)), dim3(B), 0, st, keys2, n, range, child, parent);
   if (after_setup) {
     // phase 1: `st` now holds ~100 us of work (keys, sort, hierarchy) — the time the host needs to enqueue the side
@@ -760,8 +1311,12 @@ int build_device_mesh(Arena& ws, hipStream_t st, const float* d_verts, size_t n_
   if (n > 2 && treelets && !getenv("M2S_KEYS_FILE")) {
     // treelet pass: the nodes of at most TREELET_MAX triangles are rebuilt by sweep splits, then the hierarchy is derived again
     int2* roots = reinterpret_cast<int2*>(child);   // child[] is not used by the kernels below and is rewritten by the second k_karras
-    hipLaunchKernelGGL(k_treelet_roots, dim3(cdiv(n_tris - 1, B)), dim3(B), 0, st, n, range, parent, roots, scene + 7);
-    hipLaunchKernelGGL(k_treelet, dim3((unsigned)((n_tris + 2) / 3)), dim3(TREELET_MAX), 0, st, roots, scene + 7, boxes, keys2, order);
+    if (lean) hipLaunchKernelGGL(k_treelet_roots_block, dim3(cdiv(n_tris - 1, B)), dim3(B), 0, st, n, range, parent, roots, scene + 7);
+    else hipLaunchKernelGGL(k_treelet_roots, dim3(cdiv(n_tris - 1, B)), dim3(B), 0, st, n, range, parent, roots, scene + 7);
+    if (lean && TREELET_MAX == 64 && !(getenv("M2S_TREELET_LANES") && atoi(getenv("M2S_TREELET_LANES")) == 0))
+      hipLaunchKernelGGL(k_treelet_lanes, dim3((unsigned)std::min<size_t>((n_tris + 2) / 3, 8192)), dim3(64), 0, st, roots, scene + 7, boxes, keys2, order);
+    else
+      hipLaunchKernelGGL(k_treelet, dim3((unsigned)((n_tris + 2) / 3)), dim3(TREELET_MAX), 0, st, roots, scene + 7, boxes, keys2, order);
     hipLaunchKernelGGL(k_karras, dim3(cdiv(n_tris - 1, B)), dim3(B), 0, st, keys2, n, range, child, parent);
   }
 
@@ -778,6 +1333,9 @@ int build_device_mesh(Arena& ws, hipStream_t st, const float* d_verts, size_t n_
       cnt = (cnt + 1) / 2;
     }
   }
+  if (lean) {
+    hipLaunchKernelGGL(k_seg_build, dim3(cdiv(n_tris, 512)), dim3(B), 0, st, (const Box*)boxes, (const uint32_t*)order, (uint32_t)n_tris, seg, lv, aux_counters);
+  } else {
   if (lv.levels == 1) hipLaunchKernelGGL(k_seg_level0, dim3(cdiv(n_tris, B)), dim3(B), 0, st, boxes, order, n, seg);   // a single triangle
   for (int l = 0; l + 1 < lv.levels; l += 3) {
     const uint32_t n1 = lv.cnt[l + 1];
@@ -791,11 +1349,20 @@ int build_device_mesh(Arena& ws, hipStream_t st, const float* d_verts, size_t n_
       hipLaunchKernelGGL(k_seg_level3<false>, dim3(cdiv(threads, B)), dim3(B), 0, st, seg, lv.off[l], lv.cnt[l], lv.off[l + 1], n1, o2,
                          n2, o3, n3, (const Box*)nullptr, (const uint32_t*)nullptr);
   }
+  }
   hipLaunchKernelGGL(k_emit, dim3(cdiv(2 * n_tris - 1, B)), dim3(B), 0, st, n, range, parent, seg, lv, order, raw,
-                     nodes, tris, slot_first, cen, planes, leaf_max, slot_of);
+                     nodes, tris, slot_first, cen, planes, leaf_max, slot_of, d_err);
   hipLaunchKernelGGL(k_node_ext, dim3(cdiv(2 * n_tris - 1, B)), dim3(B), 0, st, nodes, slot_first, tris,
                      (uint32_t)(2 * n_tris - 1), ext);
   M2S_HIP_CHECK(hipGetLastError());
+  if (stamps) {
+    unsigned long long h[16];
+    M2S_HIP_CHECK(hipStreamSynchronize(st));
+    M2S_HIP_CHECK(hipMemcpy(h, stamps, sizeof(h), hipMemcpyDeviceToHost));
+    for (int b = 0; b < 2; ++b)
+      fprintf(stderr, "[m2s build stamps] sort pass 3, %s tile (10 ns units from its start): counts published %llu, ranked %llu, looked back %llu, scattered %llu; first tile started %lld before\n",
+              b ? "last" : "first", h[8 * b + 1] - h[8 * b], h[8 * b + 2] - h[8 * b], h[8 * b + 3] - h[8 * b], h[8 * b + 4] - h[8 * b], (long long)(h[8 * b] - h[0]));
+  }
   out->tris = tris;
   out->cen = cen;
   out->planes = planes;

@@ -277,6 +277,7 @@ int finish_call(const CallCtx& c, DeviceState& st, int* d_err, m2s_timings* t, s
   if (e & ERRF_INDEX_OOB) return fail(M2S_ERR_BAD_ARG, "vertex index out of range (the reference panics indexing `vertices`)");
   if (e & ERRF_NAN) return fail(M2S_ERR_NAN, "NaN distance (lib.rs:257)");
   if (e & ERRF_TRAIL_TIMEOUT) return fail(M2S_ERR_HIP, "the trailing peer push gave up waiting for the walk (M2S_PEER_TRAIL)");
+  if (e & ERRF_BUILD_TIMEOUT) return fail(M2S_ERR_HIP, "the LBVH build gave up waiting for a neighbouring tile of its sort");
   return M2S_OK;
 }
 
@@ -1158,6 +1159,7 @@ int m2s_mesh_create(const float* vertices, size_t n_vertices, const void* indice
     return bail(fail(M2S_ERR_HIP, "mesh build failed: %s", hipGetErrorString(hipGetLastError())));
   (void)hipEventElapsedTime(&m->build_ms, st->ev[0], st->ev[1]);
   if (*st->h_err & ERRF_INDEX_OOB) return bail(fail(M2S_ERR_BAD_ARG, "vertex index out of range (the reference panics indexing `vertices`)"));
+  if (*st->h_err & ERRF_BUILD_TIMEOUT) return bail(fail(M2S_ERR_HIP, "the LBVH build gave up waiting for a neighbouring tile of its sort"));
   *out_mesh = m;
   return M2S_OK;
 }
@@ -1399,6 +1401,32 @@ int m2s_mesh_generate_sdf(m2s_mesh* m, const float* queries, size_t n_queries, i
   }
   if (n_out) *n_out = n_queries;
   return finish_call(c, *st, d_err, c.timings, m->n_tris, n_queries, false);
+}
+
+// Test hook (not part of include/m2s.h): FNV-1a digests of the resident arrays of a mesh — triangle records, pre-test planes,
+// box nodes, oriented bounds, centroids, slot table, scene words.  tests/test_gpu_build.py compares two builds of one mesh
+// (M2S_BUILD=0 / 1) with it: the lean build must leave the same tree, byte for byte.
+int m2s_debug_mesh_digest(m2s_mesh* m, uint64_t out[8]) {
+  g_err[0] = 0;
+  if (!m || !out) return fail(M2S_ERR_BAD_ARG, "NULL argument");
+  std::lock_guard<std::mutex> mlk(m->mu);
+  M2S_HIP_CHECK(hipSetDevice(m->device));
+  M2S_HIP_CHECK(hipDeviceSynchronize());
+  const size_t n = m->n_tris, nn = n ? 2 * n - 1 : 0;
+  const void* ptr[7] = {m->dm.tris, m->dm.planes, m->dm.nodes, m->dm.ext, m->dm.cen, m->dm.slot_of, m->dm.scene};
+  const size_t bytes[7] = {n * sizeof(TriRec), n * sizeof(TriPlanes), nn * sizeof(NodeRec), nn * sizeof(NodeExt), n * 16, n * 4, n ? 32u : 0u};
+  std::vector<unsigned char> h;
+  for (int k = 0; k < 7; ++k) {
+    uint64_t f = 1469598103934665603ull;
+    if (bytes[k]) {
+      h.resize(bytes[k]);
+      M2S_HIP_CHECK(hipMemcpy(h.data(), ptr[k], bytes[k], hipMemcpyDeviceToHost));
+      for (size_t i = 0; i < bytes[k]; ++i) { f ^= h[i]; f *= 1099511628211ull; }
+    }
+    out[k] = f;
+  }
+  out[7] = n;
+  return M2S_OK;
 }
 
 }  // extern "C"

@@ -168,7 +168,7 @@ struct PeerOut {
 };
 
 // Device-side error flags (OR-ed into one int by kernels).
-enum : int { ERRF_INDEX_OOB = 1, ERRF_NAN = 2, ERRF_TRAIL_TIMEOUT = 4 };
+enum : int { ERRF_INDEX_OOB = 1, ERRF_NAN = 2, ERRF_TRAIL_TIMEOUT = 4, ERRF_BUILD_TIMEOUT = 8 };
 
 // Result modes of the nearest search.
 enum : int {
