@@ -195,16 +195,24 @@ typedef struct m2s_multi_opts {
   m2s_timings* timings;     /* optional, n_devices entries: per-shard phase timings */
   float* wall_ms;           /* optional: host wall time of the whole call */
   int32_t* exchange_used;   /* optional: the exchange that ran (M2S_XCHG_PEER / RCCL / NONE) */
-  /* ---- fields below exist when struct_size >= sizeof(m2s_multi_opts) of version 0.2 final (M2S_MULTI_OPTS_V1_SIZE = without) ---- */
-  int32_t partition;        /* enum m2s_partition */
+  /* ---- fields below exist when struct_size >= M2S_MULTI_OPTS_V2_SIZE (version 0.2; M2S_MULTI_OPTS_V1_SIZE = without) ---- */
+  int32_t partition;        /* enum m2s_partition.  A caller whose struct ends before this field gets M2S_PART_CONTIGUOUS. */
   int32_t reserved;
+  /* ---- fields below exist when struct_size >= sizeof(m2s_multi_opts) (version 0.3) ---- */
+  int32_t* partition_used;  /* optional: M2S_PART_CONTIGUOUS / INTERLEAVED / ADAPTIVE as it ran */
+  uint64_t* slabs;          /* optional, 3 * n_devices entries: x_begin, x_end, x_period of every shard as it ran (m2s_opts meaning) */
 } m2s_multi_opts;
 #define M2S_MULTI_OPTS_V1_SIZE 56
+#define M2S_MULTI_OPTS_V2_SIZE 64
 /* How the grid is cut.  CONTIGUOUS: shard k computes one x-slab.  INTERLEAVED: shard k computes the chunks k and n + k of 2n
  * (m2s_interleaved_slab): the cost of a layer varies along x — the deep interior of a body is the expensive part — and
  * contiguous slabs leave the middle shards with 30 % more work than the outer ones.  AUTO: interleaved for device-resident
- * results where the grid allows it, contiguous otherwise (host results stream out slab by slab). */
-enum m2s_partition { M2S_PART_AUTO = 0, M2S_PART_CONTIGUOUS = 1, M2S_PART_INTERLEAVED = 2 };
+ * results that are exchanged (PEER / RCCL) where the grid allows it, contiguous otherwise (host results stream out slab by slab;
+ * with M2S_XCHG_NONE buffer k holds m2s_slab_bounds(nx, n, k)).  ADAPTIVE: contiguous slabs of equal COST — the library keeps,
+ * per (grid, mesh size, sign method, shard count), the slab boundaries that m2s_balanced_slabs derives from the per-shard
+ * times of the previous call; the first call uses even slabs.  For callers that repeat a call (a time loop): the cost of a
+ * layer is not known in advance, but it can be measured.  `slabs` reports what ran. */
+enum m2s_partition { M2S_PART_AUTO = 0, M2S_PART_CONTIGUOUS = 1, M2S_PART_INTERLEAVED = 2, M2S_PART_ADAPTIVE = 3 };
 int m2s_generate_grid_sdf_multi(const float* vertices, size_t n_vertices, const void* indices, size_t n_indices,
                                 int index_bytes, int topology, const m2s_grid* grid, int sign_method, float* const* outs,
                                 const m2s_multi_opts* opts);
@@ -222,6 +230,13 @@ int m2s_generate_sdf_multi(const float* vertices, size_t n_vertices, const void*
                            size_t* n_out, const m2s_multi_opts* opts);
 /* Contiguous range [x_begin, x_end) of shard k out of n over nx units (x-layers, queries): sizes differ by at most one. */
 void m2s_slab_bounds(uint64_t nx, int n, int k, uint64_t* x_begin, uint64_t* x_end);
+/* Slab boundaries of equal cost.  prev_bounds[0 .. n] (0 = prev_bounds[0] <= ... <= prev_bounds[n] = nx) are the contiguous slabs of a
+ * previous call and cost[k] >= 0 what shard k spent on its slab (any unit; leave out what every shard repeats, e.g. the LBVH
+ * build).  With the cost density taken as constant inside every previous slab, new_bounds[0 .. n] cuts [0, nx) into n slabs of
+ * equal cost, every boundary a multiple of `unit` layers (a packet brick: 4 for cubic cells; 0 = 1) and every slab at least one unit
+ * (even slabs when nothing was measured or there are fewer units than shards).  Host-only, deterministic: every rank of a
+ * multi-process run computes the same boundaries from the same gathered costs. */
+int m2s_balanced_slabs(uint64_t nx, int n, uint64_t unit, const uint64_t* prev_bounds, const float* cost, uint64_t* new_bounds);
 /* The balanced partition: shard k takes the chunks k and n + k of 2n (m2s_opts.x_begin / x_end / x_period) when the grid allows
  * it — returns 1 — else its contiguous slab with *x_period = 0 — returns 0. */
 int m2s_interleaved_slab(const m2s_grid* grid, int n, int k, uint64_t* x_begin, uint64_t* x_end, uint64_t* x_period);

@@ -78,10 +78,14 @@ class M2SMultiOpts(C.Structure):
         ("exchange_used", C.POINTER(C.c_int32)),
         ("partition", C.c_int32),
         ("reserved", C.c_int32),
+        # version 0.3
+        ("partition_used", C.POINTER(C.c_int32)),
+        ("slabs", C.POINTER(C.c_uint64)),
     ]
 
 
-PART_AUTO, PART_CONTIGUOUS, PART_INTERLEAVED = 0, 1, 2
+MULTI_OPTS_V1_SIZE, MULTI_OPTS_V2_SIZE = 56, 64
+PART_AUTO, PART_CONTIGUOUS, PART_INTERLEAVED, PART_ADAPTIVE = 0, 1, 2, 3
 
 
 class M2SSdfInfo(C.Structure):
@@ -148,6 +152,7 @@ EXPORTS = [
     "m2s_generate_grid_sdf_multi",
     "m2s_generate_sdf_multi",
     "m2s_slab_bounds",
+    "m2s_balanced_slabs",
     "m2s_interleaved_slab",
     "m2s_shared_alloc",
     "m2s_shared_free",
@@ -258,6 +263,8 @@ def lib():
                                              C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(M2SMultiOpts)]
         L.m2s_slab_bounds.restype = None
         L.m2s_slab_bounds.argtypes = [C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.m2s_balanced_slabs.restype = C.c_int
+        L.m2s_balanced_slabs.argtypes = [C.c_uint64, C.c_int, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_float), C.POINTER(C.c_uint64)]
         L.m2s_interleaved_slab.restype = C.c_int
         L.m2s_interleaved_slab.argtypes = [C.POINTER(M2SGrid), C.c_int, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.m2s_shared_alloc.restype = C.c_int

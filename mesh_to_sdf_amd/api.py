@@ -289,6 +289,7 @@ class Partition(enum.IntEnum):
     Auto = 0
     Contiguous = 1
     Interleaved = 2
+    Adaptive = 3
 
 
 class Exchange(enum.IntEnum):
@@ -375,9 +376,12 @@ def generate_grid_sdf_multi(vertices, indices: Topology, grid: Grid, sign_method
     mo.partition = int(partition)
     tims = (M2STimings * max(n, 1))()
     mo.timings = C.cast(tims, C.POINTER(M2STimings))
-    wall, used = C.c_float(0.0), C.c_int32(-1)
+    wall, used, part_used = C.c_float(0.0), C.c_int32(-1), C.c_int32(-1)
     mo.wall_ms = C.pointer(wall)
     mo.exchange_used = C.pointer(used)
+    mo.partition_used = C.pointer(part_used)
+    slabs = (C.c_uint64 * (3 * max(n, 1)))()
+    mo.slabs = C.cast(slabs, C.POINTER(C.c_uint64))
     if a.device:
         mo.mem_kind = _lib.MEM_DEVICE
         dev0 = a.dev.index if a.dev.index is not None else a.torch.cuda.current_device()
@@ -403,8 +407,23 @@ def generate_grid_sdf_multi(vertices, indices: Topology, grid: Grid, sign_method
         info["wall_ms"] = float(wall.value)
         info["exchange"] = Exchange(used.value).name if used.value >= 0 else None
         info["timings"] = [tims[k] for k in range(n)]
+        info["partition"] = Partition(part_used.value).name if part_used.value >= 0 else None
+        info["slabs"] = [(int(slabs[3 * k]), int(slabs[3 * k + 1]), int(slabs[3 * k + 2])) for k in range(n)]
         info["_keep"] = tims
     return result
+
+
+def balanced_slabs(nx: int, unit: int, prev_bounds: Sequence[int], cost: Sequence[float]):
+    """m2s_balanced_slabs: n + 1 slab boundaries of equal cost from the boundaries and per-shard costs of a previous call."""
+    n = len(cost)
+    assert len(prev_bounds) == n + 1
+    pb = (C.c_uint64 * (n + 1))(*[int(b) for b in prev_bounds])
+    cs = (C.c_float * n)(*[float(c) for c in cost])
+    nb = (C.c_uint64 * (n + 1))()
+    rc = _lib.lib().m2s_balanced_slabs(int(nx), n, int(unit), pb, cs, nb)
+    if rc != _lib.M2S_OK:
+        _raise(rc)
+    return [int(b) for b in nb]
 
 
 def generate_sdf_multi(vertices, indices: Topology, query_points, acceleration_method: AccelerationMethod = None, *,

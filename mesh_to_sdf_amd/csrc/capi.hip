@@ -356,8 +356,8 @@ int run_grid_distance_push(Arena& ws, const CallCtx& c, DeviceState& st, const D
   static const uint32_t want_pieces = getenv("M2S_PUSH_PIECES") ? (uint32_t)std::max(1, atoi(getenv("M2S_PUSH_PIECES"))) : 4u;
   const uint64_t bx = 2ull << g.bl[0];                              // whole cut-list blocks (2 bricks) along x
   uint64_t lpp = (layers + want_pieces - 1) / want_pieces;
-  if (g.chunk_log < 31u) lpp = 1ull << g.chunk_log;                // interleaved slab: a piece = a chunk (contiguous in the grid)
-  lpp = std::max<uint64_t>(bx, (lpp + bx - 1) / bx * bx);
+  if (g.chunk_log < 31u) lpp = 1ull << g.chunk_log;                // interleaved slab: a piece = a chunk (contiguous in the grid; a multiple of 4 bricks)
+  else lpp = std::max<uint64_t>(bx, (lpp + bx - 1) / bx * bx);
   // thin pieces walk badly (one launch per piece, each ending in a partly filled tail; 512^3 x blob-100k cut into pieces of
   // 64 / 32 / 16 layers: 10.9 / 11.6 / 16.1 ms of walks in total): at least 8 bricks of layers per piece
   if (g.chunk_log >= 31u) {
@@ -510,11 +510,14 @@ int fill_grid_params(const m2s_grid* grid, const m2s_opts* opts, GridParams* g, 
   if (period != 0 && layers != 0) {
     // interleaved slab: chunks [xb + j * period, + C), C = x_end - x_begin a power of two that holds whole cut-list waves
     // (4 bricks along x), every chunk inside the grid; the virtual slab is the chunks laid end to end
-    const uint64_t C = layers, brick_layers = 1ull << g->bl[0];    // a packet brick must not straddle two chunks
+    // a chunk holds whole waves of the cut-list kernel and whole push pieces: 4 packet bricks along x (m2s.h).  (A chunk of ONE
+    // brick used to pass this check; the peer push then rounded its piece up to two bricks and walked two chunks as one
+    // contiguous range — wrong cells, silently.)
+    const uint64_t C = layers, brick_layers = 4ull << g->bl[0];
     uint32_t clog = 0;
     while ((1ull << clog) < C) ++clog;
     if ((1ull << clog) != C || C % brick_layers != 0 || period % C != 0 || period < C || period >= (1ull << 31))
-      return fail(M2S_ERR_BAD_ARG, "x_period %llu with a chunk of %llu layers: the chunk must be a power of two and a multiple of the packet brick (%llu layers), the period a multiple of the chunk",
+      return fail(M2S_ERR_BAD_ARG, "x_period %llu with a chunk of %llu layers: the chunk must be a power of two and a multiple of 4 packet bricks (%llu layers), the period a multiple of the chunk",
                   (unsigned long long)period, (unsigned long long)C, (unsigned long long)brick_layers);
     uint64_t chunks = 0;
     while (xb + chunks * period < gx) {
@@ -835,7 +838,7 @@ int m2s_interleaved_slab(const m2s_grid* grid, int n, int k, uint64_t* x_begin, 
   static const bool cube_only = getenv("M2S_BRICK_CUBE") && atoi(getenv("M2S_BRICK_CUBE")) != 0;
   if (cube_only) bl[0] = bl[1] = bl[2] = 2;
   else choose_brick_shape(grid->cell_size, bl);
-  if ((C & (C - 1)) != 0 || C % (1ull << bl[0]) != 0 || C < 16) return 0;
+  if ((C & (C - 1)) != 0 || C % (4ull << bl[0]) != 0) return 0;   // whole cut-list waves / push pieces per chunk (fill_grid_params checks the same)
   *x_begin = (uint64_t)k * C; *x_end = (uint64_t)(k + 1) * C; *x_period = (uint64_t)n * C;
   return 1;
 }

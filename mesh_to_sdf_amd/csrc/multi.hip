@@ -11,9 +11,13 @@
 // x-slab and peer list, so the multi-device path adds no second implementation of anything.
 #include <dlfcn.h>
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cstring>
+#include <functional>
+#include <map>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -93,11 +97,21 @@ int ensure_comms(const std::vector<int>& devices) {
     g_comms.streams.clear();
     return fail(M2S_ERR_HIP, "ncclCommInitAll over %zu devices failed: %s", devices.size(), r.GetErrorString(e));
   }
+  g_comms.devices = devices;   // from here on the cache describes what exists: a failure below tears it down again
   for (size_t k = 0; k < devices.size(); ++k) {
-    M2S_HIP_CHECK(hipSetDevice(devices[k]));
-    M2S_HIP_CHECK(hipStreamCreateWithFlags(&g_comms.streams[k], hipStreamNonBlocking));
+    if (hipSetDevice(devices[k]) != hipSuccess || hipStreamCreateWithFlags(&g_comms.streams[k], hipStreamNonBlocking) != hipSuccess) {
+      const hipError_t err = hipGetLastError();
+      for (size_t j = 0; j < devices.size(); ++j) {
+        (void)hipSetDevice(devices[j]);
+        if (g_comms.comms[j]) (void)r.CommDestroy(g_comms.comms[j]);
+        if (g_comms.streams[j]) (void)hipStreamDestroy(g_comms.streams[j]);
+      }
+      g_comms.comms.clear();
+      g_comms.streams.clear();
+      g_comms.devices.clear();
+      return fail(M2S_ERR_HIP, "stream for the RCCL exchange on device %d: %s", devices[k], hipGetErrorString(err));
+    }
   }
-  g_comms.devices = devices;
   return 0;
 }
 
@@ -158,6 +172,117 @@ bool enable_peer_access(const std::vector<int>& devices) {
     }
   return true;
 }
+
+// ---- shard workers -------------------------------------------------------------------------------------------
+// One host thread per shard.  Round 2 created and joined n std::threads in every call (0.1-0.3 ms of host time against a rank
+// step of 1.7 ms, and a thread that could not be created ended in std::terminate).  The workers now live as long as the
+// process: shard 0 runs on the caller's thread, shard k on worker k - 1, which sleeps on a condition variable between calls.
+// One multi call at a time owns the pool; a second one arriving meanwhile falls back to threads of its own.
+class ShardPool {
+ public:
+  // runs job(0..n-1) concurrently and returns when all are done; false if a thread could not be created (nothing left running)
+  bool run(int n, const std::function<void(int)>& job) {
+    if (n <= 1) { if (n == 1) job(0); return true; }
+    std::unique_lock<std::mutex> own(owner_, std::try_to_lock);
+    if (!own.owns_lock()) return run_adhoc(n, job);
+    try {
+      while ((int)workers_.size() < n - 1) {
+        workers_.emplace_back(new Worker());
+        Worker* w = workers_.back().get();
+        w->th = std::thread([w] { w->loop(); });
+      }
+    } catch (...) {
+      if (!workers_.empty() && !workers_.back()->th.joinable()) workers_.pop_back();
+      return false;
+    }
+    for (int k = 1; k < n; ++k) workers_[k - 1]->post([&job, k] { job(k); });
+    job(0);
+    for (int k = 1; k < n; ++k) workers_[k - 1]->wait();
+    return true;
+  }
+  ~ShardPool() {
+    for (auto& w : workers_) w->stop();
+    for (auto& w : workers_) if (w->th.joinable()) w->th.join();
+  }
+
+ private:
+  struct Worker {
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::function<void()> task;
+    bool has = false, done = false, quit = false;
+    void loop() {
+      for (;;) {
+        std::function<void()> t;
+        {
+          std::unique_lock<std::mutex> lk(mu);
+          cv.wait(lk, [this] { return has || quit; });
+          if (quit) return;
+          t = std::move(task);
+          has = false;
+        }
+        t();
+        {
+          std::lock_guard<std::mutex> lk(mu);
+          done = true;
+        }
+        cv.notify_all();
+      }
+    }
+    void post(std::function<void()> t) {
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        task = std::move(t);
+        has = true;
+        done = false;
+      }
+      cv.notify_all();
+    }
+    void wait() {
+      std::unique_lock<std::mutex> lk(mu);
+      cv.wait(lk, [this] { return done; });
+    }
+    void stop() {
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        quit = true;
+      }
+      cv.notify_all();
+    }
+  };
+  static bool run_adhoc(int n, const std::function<void(int)>& job) {
+    std::vector<std::thread> th;
+    bool ok = true;
+    try {
+      for (int k = 1; k < n; ++k) th.emplace_back(job, k);
+    } catch (...) {
+      ok = false;
+    }
+    if (ok) job(0);
+    for (auto& t : th) t.join();
+    return ok && (int)th.size() == n - 1;
+  }
+  std::mutex owner_;
+  std::vector<std::unique_ptr<Worker>> workers_;
+};
+ShardPool& shard_pool() {
+  static ShardPool p;
+  return p;
+}
+
+// ---- M2S_PART_ADAPTIVE: slabs of equal cost, from the previous call's per-shard times ------------------------------
+// The cost of an x-layer is not uniform and not known in advance (the deep interior of a body, the layers that cut a large cap of
+// its surface); a caller that repeats the call — a time loop, the bench — can have it measured: after every call the slabs are
+// re-cut so that the piecewise-constant cost density of the last call integrates to equal shares (m2s_balanced_slabs).
+struct AdaptiveKey {
+  m2s_grid grid;
+  size_t n_vertices, n_indices;
+  int sign_method, n;
+  bool operator<(const AdaptiveKey& o) const { return memcmp(this, &o, sizeof(*this)) < 0; }
+};
+std::mutex g_adaptive_mu;
+std::map<AdaptiveKey, std::vector<uint64_t>> g_adaptive;   // key -> n + 1 slab boundaries for the NEXT call
 
 // The part of a multi-device call that does not depend on what is computed: shards -> (device, lane), memory kind, exchange.
 struct MultiPlan {
@@ -232,6 +357,44 @@ void m2s_slab_bounds(uint64_t nx, int n, int k, uint64_t* x_begin, uint64_t* x_e
   *x_end = x0 + base + (kk < rem ? 1 : 0);
 }
 
+int m2s_balanced_slabs(uint64_t nx, int n, uint64_t unit, const uint64_t* prev_bounds, const float* cost, uint64_t* new_bounds) {
+  clear_error();
+  if (n <= 0 || !prev_bounds || !cost || !new_bounds) return fail(M2S_ERR_BAD_ARG, "m2s_balanced_slabs: NULL argument or n <= 0");
+  if (unit == 0) unit = 1;
+  if (prev_bounds[0] != 0 || prev_bounds[n] != nx) return fail(M2S_ERR_BAD_ARG, "m2s_balanced_slabs: prev_bounds must run from 0 to nx");
+  double total = 0.0;
+  for (int k = 0; k < n; ++k) {
+    if (prev_bounds[k + 1] < prev_bounds[k]) return fail(M2S_ERR_BAD_ARG, "m2s_balanced_slabs: prev_bounds not ascending");
+    if (!(cost[k] >= 0.0f) || !(cost[k] < 3.0e38f)) return fail(M2S_ERR_BAD_ARG, "m2s_balanced_slabs: cost[%d] is not a finite non-negative number", k);
+    total += prev_bounds[k + 1] > prev_bounds[k] ? (double)cost[k] : 0.0;
+  }
+  const uint64_t units = (nx + unit - 1) / unit;                  // the last unit may be partial
+  new_bounds[0] = 0;
+  new_bounds[n] = nx;
+  if (total <= 0.0 || units < (uint64_t)n) {                      // nothing measured, or fewer units than shards: even slabs
+    for (int k = 1; k < n; ++k) { uint64_t a, b; m2s_slab_bounds(nx, n, k, &a, &b); new_bounds[k] = a; }
+    return M2S_OK;
+  }
+  // C(x): cumulative cost, linear inside every previous slab; boundary k goes where C reaches k / n of the total
+  int seg = 0;
+  double before = 0.0;                                            // cost of the previous slabs left of `seg`
+  for (int k = 1; k < n; ++k) {
+    const double want = total * (double)k / (double)n;
+    while (seg < n - 1 && (prev_bounds[seg + 1] == prev_bounds[seg] || before + (double)cost[seg] < want)) {
+      before += prev_bounds[seg + 1] > prev_bounds[seg] ? (double)cost[seg] : 0.0;
+      ++seg;
+    }
+    const double len = (double)(prev_bounds[seg + 1] - prev_bounds[seg]);
+    const double frac = cost[seg] > 0.0f ? std::min(1.0, std::max(0.0, (want - before) / (double)cost[seg])) : 0.0;
+    const double x = (double)prev_bounds[seg] + frac * len;
+    uint64_t u = (uint64_t)(x / (double)unit + 0.5);              // to whole units ...
+    const uint64_t lo = new_bounds[k - 1] / unit + 1, hi = units - (uint64_t)(n - k);   // ... every shard keeps at least one
+    u = std::min(std::max(u, lo), hi);
+    new_bounds[k] = u * unit;
+  }
+  return M2S_OK;
+}
+
 int m2s_generate_grid_sdf_multi(const float* vertices, size_t n_vertices, const void* indices, size_t n_indices,
                                 int index_bytes, int topology, const m2s_grid* grid, int sign_method, float* const* outs,
                                 const m2s_multi_opts* opts) {
@@ -239,8 +402,10 @@ int m2s_generate_grid_sdf_multi(const float* vertices, size_t n_vertices, const 
   const auto t0 = std::chrono::steady_clock::now();
   if (!grid) return fail(M2S_ERR_BAD_ARG, "grid is NULL");
   if (opts && opts->struct_size != 0 && opts->struct_size < M2S_MULTI_OPTS_V1_SIZE) return fail(M2S_ERR_BAD_ARG, "m2s_multi_opts.struct_size too small");
-  int partition = (opts && opts->struct_size >= sizeof(m2s_multi_opts)) ? opts->partition : M2S_PART_AUTO;
-  if (partition < M2S_PART_AUTO || partition > M2S_PART_INTERLEAVED) return fail(M2S_ERR_BAD_ARG, "bad partition");
+  const bool v2 = opts && opts->struct_size >= M2S_MULTI_OPTS_V2_SIZE, v3 = opts && opts->struct_size >= sizeof(m2s_multi_opts);
+  // a version-0.1 caller (no `partition` field) reads its slabs from m2s_slab_bounds: contiguous for it
+  int partition = v2 ? opts->partition : M2S_PART_CONTIGUOUS;
+  if (partition < M2S_PART_AUTO || partition > M2S_PART_ADAPTIVE) return fail(M2S_ERR_BAD_ARG, "bad partition");
   const uint64_t nx = grid->cell_count[0], row = grid->cell_count[1] * grid->cell_count[2];
   const bool empty = nx == 0 || row == 0;
   MultiPlan mp;
@@ -254,7 +419,18 @@ int m2s_generate_grid_sdf_multi(const float* vertices, size_t n_vertices, const 
   std::vector<uint64_t> xb((size_t)n), xe((size_t)n);
   uint64_t period = 0;
   for (int k = 0; k < n; ++k) m2s_slab_bounds(nx, n, k, &xb[k], &xe[k]);
-  if (partition != M2S_PART_CONTIGUOUS && mem_kind == M2S_MEM_DEVICE && n > 1) {
+  // M2S_XCHG_NONE leaves buffer k with shard k's cells only: the caller finds them through m2s_slab_bounds unless it asked for
+  // another partition explicitly (and reads `slabs` back)
+  if (partition == M2S_PART_AUTO && exchange == M2S_XCHG_NONE) partition = M2S_PART_CONTIGUOUS;
+  AdaptiveKey akey{};
+  if (partition == M2S_PART_ADAPTIVE && n > 1 && !empty) {
+    akey.grid = *grid; akey.n_vertices = n_vertices; akey.n_indices = n_indices; akey.sign_method = sign_method; akey.n = n;
+    std::lock_guard<std::mutex> lk(g_adaptive_mu);
+    auto it = g_adaptive.find(akey);
+    if (it != g_adaptive.end())
+      for (int k = 0; k < n; ++k) { xb[k] = it->second[k]; xe[k] = it->second[k + 1]; }
+  }
+  if ((partition == M2S_PART_AUTO || partition == M2S_PART_INTERLEAVED) && mem_kind == M2S_MEM_DEVICE && n > 1) {
     std::vector<uint64_t> ib((size_t)n), ie((size_t)n);
     bool ok = true;
     for (int k = 0; k < n && ok; ++k) ok = m2s_interleaved_slab(grid, n, k, &ib[k], &ie[k], &period) != 0;
@@ -264,8 +440,13 @@ int m2s_generate_grid_sdf_multi(const float* vertices, size_t n_vertices, const 
   if (partition == M2S_PART_INTERLEAVED && period == 0 && n > 1)
     return fail(M2S_ERR_BAD_ARG, "this grid cannot be cut into interleaved chunks (m2s_interleaved_slab; device memory only)");
 
+  if (v3 && opts->partition_used) *opts->partition_used = period ? M2S_PART_INTERLEAVED : (partition == M2S_PART_ADAPTIVE ? M2S_PART_ADAPTIVE : M2S_PART_CONTIGUOUS);
+  if (v3 && opts->slabs)
+    for (int k = 0; k < n; ++k) { opts->slabs[3 * k] = xb[k]; opts->slabs[3 * k + 1] = xe[k]; opts->slabs[3 * k + 2] = period; }
   std::vector<int> rcs((size_t)n, 0);
   std::vector<std::string> errs((size_t)n);
+  std::vector<m2s_timings> own_timings(partition == M2S_PART_ADAPTIVE && !(opts && opts->timings) ? (size_t)n : 0);
+  m2s_timings* shard_timings = (opts && opts->timings) ? opts->timings : (own_timings.empty() ? nullptr : own_timings.data());
   auto shard = [&](int k) {
     m2s_opts o{};
     o.struct_size = sizeof(m2s_opts);
@@ -277,7 +458,8 @@ int m2s_generate_grid_sdf_multi(const float* vertices, size_t n_vertices, const 
     o.x_end = xe[k];
     o.x_period = (uint32_t)period;
     o.synchronous = 1;
-    o.timings = (opts && opts->timings) ? &opts->timings[k] : nullptr;
+    o.timings = shard_timings ? &shard_timings[k] : nullptr;
+    if (shard_timings) memset(&shard_timings[k], 0, sizeof(m2s_timings));
     float* peers[M2S_MAX_PEERS];
     if (exchange == M2S_XCHG_PEER) {
       uint32_t np = 0;
@@ -309,14 +491,23 @@ int m2s_generate_grid_sdf_multi(const float* vertices, size_t n_vertices, const 
     if (staged) (void)hipFree(staged);
     rcs[k] = rc;
   };
-  if (n == 1) shard(0);
-  else {
-    std::vector<std::thread> th;
-    for (int k = 0; k < n; ++k) th.emplace_back(shard, k);
-    for (auto& t : th) t.join();
-  }
+  if (!shard_pool().run(n, shard)) return fail(M2S_ERR_HIP, "could not start the shard threads");
   for (int k = 0; k < n; ++k)
     if (rcs[k]) return fail(rcs[k], "shard %d (device %d): %s", k, devices[k], errs[k].c_str());
+  if (partition == M2S_PART_ADAPTIVE && n > 1 && !empty && shard_timings) {
+    // next call's slabs: equal shares of this call's cost (what shards: everything but the LBVH build, which every shard repeats)
+    std::vector<uint64_t> prev((size_t)n + 1), next((size_t)n + 1);
+    std::vector<float> cost((size_t)n);
+    for (int k = 0; k < n; ++k) { prev[k] = xb[k]; cost[k] = std::max(shard_timings[k].total_ms - shard_timings[k].accel_build_ms, 0.0f); }
+    prev[n] = nx;
+    uint32_t bl[3];
+    choose_brick_shape(grid->cell_size, bl);
+    if (m2s_balanced_slabs(nx, n, 1ull << bl[0], prev.data(), cost.data(), next.data()) == M2S_OK) {
+      std::lock_guard<std::mutex> lk(g_adaptive_mu);
+      if (g_adaptive.size() > 64) g_adaptive.clear();
+      g_adaptive[akey] = next;
+    }
+  }
   // every shard returned synchronously: all slabs (and, with the peer exchange, all pushes) are complete
   if (exchange == M2S_XCHG_RCCL && !empty) {
     const int rc = rccl_gather(devices, outs, xb, xe, row, period, nx);
@@ -388,12 +579,7 @@ int m2s_generate_sdf_multi(const float* vertices, size_t n_vertices, const void*
     for (void* p : {sv, si, sq}) if (p) (void)hipFree(p);
     rcs[k] = rc;
   };
-  if (n == 1) shard(0);
-  else {
-    std::vector<std::thread> th;
-    for (int k = 0; k < n; ++k) th.emplace_back(shard, k);
-    for (auto& t : th) t.join();
-  }
+  if (!shard_pool().run(n, shard)) return fail(M2S_ERR_HIP, "could not start the shard threads");
   for (int k = 0; k < n; ++k)
     if (rcs[k]) return fail(rcs[k], "shard %d (device %d): %s", k, devices[k], errs[k].c_str());
   size_t total = 0;

@@ -38,18 +38,21 @@ def test_struct_layout_matches_header(tmp_path):
     src = tmp_path / "probe.c"
     src.write_text(
         '#include <stdio.h>\n#include <stddef.h>\n#include "m2s.h"\n'
-        'int main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %d\\n", sizeof(m2s_grid), sizeof(m2s_timings), sizeof(m2s_opts),'
+        'int main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %d %zu %zu %d %d\\n", sizeof(m2s_grid), sizeof(m2s_timings), sizeof(m2s_opts),'
         ' offsetof(m2s_opts, x_begin), offsetof(m2s_opts, timings), offsetof(m2s_timings, n_units),'
         ' offsetof(m2s_opts, lane), offsetof(m2s_opts, peer_out), sizeof(m2s_multi_opts), offsetof(m2s_multi_opts, timings),'
-        ' M2S_OPTS_V1_SIZE);return 0;}\n'
+        ' M2S_OPTS_V1_SIZE, offsetof(m2s_multi_opts, partition), offsetof(m2s_multi_opts, partition_used), M2S_MULTI_OPTS_V1_SIZE,'
+        ' M2S_MULTI_OPTS_V2_SIZE);return 0;}\n'
     )
     exe = tmp_path / "probe"
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
     got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
     want = [C.sizeof(_lib.M2SGrid), C.sizeof(_lib.M2STimings), C.sizeof(_lib.M2SOpts), _lib.M2SOpts.x_begin.offset,
             _lib.M2SOpts.timings.offset, _lib.M2STimings.n_units.offset, _lib.M2SOpts.lane.offset, _lib.M2SOpts.peer_out.offset,
-            C.sizeof(_lib.M2SMultiOpts), _lib.M2SMultiOpts.timings.offset, _lib.OPTS_V1_SIZE]
+            C.sizeof(_lib.M2SMultiOpts), _lib.M2SMultiOpts.timings.offset, _lib.OPTS_V1_SIZE, _lib.M2SMultiOpts.partition.offset,
+            _lib.M2SMultiOpts.partition_used.offset, _lib.MULTI_OPTS_V1_SIZE, _lib.MULTI_OPTS_V2_SIZE]
     assert _lib.M2SOpts.lane.offset == _lib.OPTS_V1_SIZE   # version-0.1 callers stop exactly where the new fields begin
+    assert _lib.M2SMultiOpts.partition.offset == _lib.MULTI_OPTS_V1_SIZE and _lib.M2SMultiOpts.partition_used.offset == _lib.MULTI_OPTS_V2_SIZE
     assert got == want
 
 
@@ -85,6 +88,51 @@ def test_triangle_count(lib):
         assert lib.m2s_triangle_count(99, n, 1, 1) == len(orc.get_triangles(99, list(range(n)), 1))
         assert lib.m2s_triangle_count(n, 0, 0, 0) == len(orc.get_triangles(n, None, 0))
         assert lib.m2s_triangle_count(n, 0, 0, 1) == len(orc.get_triangles(n, None, 1))
+
+
+def test_interleaved_slab_needs_whole_cut_list_waves_per_chunk():
+    """m2s_interleaved_slab (host-only): a chunk is a power of two and a multiple of 4 packet bricks along x, else the shard falls
+    back to its contiguous slab.  (Round 2 accepted a chunk of ONE brick — cell_size (0.125, 1, 1) has 16-layer bricks, nx = 128 on
+    4 shards gives 16-layer chunks — and the peer push then walked two chunks as one contiguous range.)"""
+    from mesh_to_sdf_amd import interleaved_slab
+
+    cubic = Grid.new([0, 0, 0], [1, 1, 1], [256, 64, 64])
+    assert interleaved_slab(cubic, 4, 1) == (32, 64, 128)            # chunks of 32 layers = 8 bricks of 4
+    assert interleaved_slab(cubic, 8, 3) == (48, 64, 128)            # 16 layers = exactly 4 bricks
+    assert interleaved_slab(Grid.new([0, 0, 0], [1, 1, 1], [128, 64, 64]), 8, 3)[2] == 0   # 8-layer chunks: 2 bricks -> contiguous
+    thin = Grid.new([0, 0, 0], [0.125, 1, 1], [128, 64, 64])         # bricks of 16 x 2 x 2 cells
+    assert interleaved_slab(thin, 4, 1) == (32, 64, 0)               # 16-layer chunks would be one brick: contiguous slab instead
+    assert interleaved_slab(Grid.new([0, 0, 0], [0.125, 1, 1], [1024, 64, 64]), 4, 1) == (128, 256, 512)   # 128 layers = 8 bricks
+
+
+def test_balanced_slabs_equalise_a_known_cost_profile():
+    """m2s_balanced_slabs (host-only): boundaries of equal cost under a piecewise-constant density; whole units; every shard keeps
+    at least one unit; degenerate inputs fall back to even slabs; bad inputs are M2S_ERR_BAD_ARG."""
+    from mesh_to_sdf_amd import balanced_slabs, slab_bounds
+
+    nx, n = 512, 8
+    even = [slab_bounds(nx, n, k)[0] for k in range(n)] + [nx]
+    assert balanced_slabs(nx, 4, even, [1.0] * n) == even                       # uniform cost: nothing moves
+    # cost density 1 on the outer quarters, 3 on the middle half (what a round body in its box looks like)
+    dens = lambda x: 3.0 if nx // 4 <= x < 3 * nx // 4 else 1.0
+    cost = [sum(dens(x) for x in range(even[k], even[k + 1])) for k in range(n)]
+    new = balanced_slabs(nx, 4, even, cost)
+    assert new[0] == 0 and new[-1] == nx and all(b % 4 == 0 for b in new) and all(new[k + 1] > new[k] for k in range(n))
+    share = [sum(dens(x) for x in range(new[k], new[k + 1])) for k in range(n)]
+    assert max(share) / min(share) < 1.12 < max(cost) / min(cost)               # 3.0 before, within a unit of layers after
+    again = balanced_slabs(nx, 4, new, share)                                   # a fixed point up to rounding
+    assert max(abs(a - b) for a, b in zip(again, new)) <= 4
+    # everything measured on one shard: the others still get a unit each
+    lop = balanced_slabs(64, 4, [0, 16, 32, 48, 64], [0.0, 0.0, 5.0, 0.0])
+    assert lop[0] == 0 and lop[-1] == 64 and all(lop[k + 1] - lop[k] >= 4 for k in range(4))
+    assert balanced_slabs(64, 4, [0, 16, 32, 48, 64], [0.0] * 4) == [0, 16, 32, 48, 64]      # nothing measured
+    assert balanced_slabs(10, 4, [0, 3, 6, 8, 10], [1.0, 2.0, 3.0, 4.0]) == [0, 3, 6, 8, 10]  # 3 units for 4 shards: even slabs
+    assert balanced_slabs(7, 0, [0, 7], [2.0]) == [0, 7]
+    for bad in (lambda: balanced_slabs(64, 4, [1, 16, 32, 48, 64], [1.0] * 4), lambda: balanced_slabs(64, 4, [0, 32, 16, 48, 64], [1.0] * 4),
+                lambda: balanced_slabs(64, 4, [0, 16, 32, 48, 64], [1.0, float("nan"), 1.0, 1.0])):
+        with pytest.raises(M2SError) as e:
+            bad()
+        assert e.value.code == _lib.ERR_BAD_ARG
 
 
 def test_argument_errors_before_any_device_work(lib):

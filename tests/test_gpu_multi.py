@@ -149,6 +149,93 @@ def test_multi_interleaved_where_the_grid_does_not_allow_it():
         generate_grid_sdf(dv, Topology.TriangleList(di), Grid.from_bounding_box([-1, -1, -1], [1, 1, 1], [96, 64, 64]), SignMethod.Raycast, x_slab=(0, 24), x_period=48)
 
 
+def test_one_brick_chunks_are_refused_and_auto_partition_stays_correct():
+    """with 16-layer packet bricks (cell_size 0.125 along x) a 16-layer chunk is ONE brick; the peer push used to round
+    its piece up to two bricks and walk two chunks as one range.  Explicit x_period with such a chunk is now M2S_ERR_BAD_ARG, and the
+    multi call's AUTO partition falls back to contiguous slabs there: every buffer equals the single call."""
+    import torch
+
+    from mesh_to_sdf_amd import M2SPanic
+
+    v, idx = meshes.blob(48, 25)
+    g = Grid.new([-2.0, -1.6, -1.6], [4.0 / 128, 3.2 / 16, 3.2 / 16], [128, 16, 16])
+    dv, di = _device_inputs(v, idx)
+    want = generate_grid_sdf(dv, Topology.TriangleList(di), g, SignMethod.Raycast)
+    with pytest.raises(M2SPanic):
+        generate_grid_sdf(dv, Topology.TriangleList(di), g, SignMethod.Raycast, x_slab=(16, 32), x_period=64)
+    for mode in (PeerMode.Push, PeerMode.Store):
+        outs = generate_grid_sdf_multi(dv, Topology.TriangleList(di), g, SignMethod.Raycast, devices=[0, 0, 0, 0], exchange=Exchange.Peer, peer_mode=mode)
+        for o in outs:
+            assert torch.equal(o.view(torch.int32), want.view(torch.int32))
+
+
+def test_adaptive_partition_and_persistent_workers():
+    """M2S_PART_ADAPTIVE: contiguous slabs re-cut after every call from the per-shard times of the call before (m2s_balanced_slabs);
+    whatever the boundaries, every buffer equals the single call.  The shard threads are the library's persistent workers: many
+    calls in a row, shard counts going up and down, and two host threads calling at once (the second falls back to its own threads)."""
+    import threading
+
+    import torch
+
+    v, idx = meshes.named("blob-100k")
+    lo, hi = meshes.extended_bbox(v, 0.1)
+    g = Grid.from_bounding_box(lo, hi, [128, 96, 96])
+    dv, di = _device_inputs(v, idx)
+    want = generate_grid_sdf(dv, Topology.TriangleList(di), g, SignMethod.Raycast)
+    seen = set()
+    for it in range(5):
+        info = {}
+        outs = generate_grid_sdf_multi(dv, Topology.TriangleList(di), g, SignMethod.Raycast, devices=[0, 0, 0, 0], exchange=Exchange.Peer,
+                                       partition=Partition.Adaptive, info=info)
+        for o in outs:
+            assert torch.equal(o.view(torch.int32), want.view(torch.int32))
+        assert info["partition"] == "Adaptive"
+        b = [s[0] for s in info["slabs"]] + [info["slabs"][-1][1]]
+        assert b[0] == 0 and b[-1] == 128 and all(b[k + 1] > b[k] and b[k] % 4 == 0 for k in range(4)) and all(s[2] == 0 for s in info["slabs"])
+        seen.add(tuple(b))
+    assert (0, 32, 64, 96, 128) in seen                                     # the first call knows nothing: even slabs
+    for n in (2, 4, 3, 1, 4):                                                # the worker pool grows and idles
+        info = {}
+        outs = generate_grid_sdf_multi(dv, Topology.TriangleList(di), g, SignMethod.Raycast, devices=[0] * n, exchange=Exchange.Peer, info=info)
+        assert all(torch.equal(o.view(torch.int32), want.view(torch.int32)) for o in outs)
+        assert info["partition"] in ("Interleaved", "Contiguous")
+    errs = []
+
+    def call():
+        try:
+            o = generate_grid_sdf_multi(dv, Topology.TriangleList(di), g, SignMethod.Raycast, devices=[0, 0], exchange=Exchange.Peer)
+            assert all(torch.equal(x.view(torch.int32), want.view(torch.int32)) for x in o)
+        except Exception as e:   # noqa: BLE001
+            errs.append(e)
+
+    th = [threading.Thread(target=call) for _ in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs
+
+
+def test_multi_xchg_none_keeps_contiguous_slabs():
+    """M2S_XCHG_NONE leaves buffer k with shard k's cells only, and a caller finds them through m2s_slab_bounds: AUTO must not
+    interleave there."""
+    import torch
+
+    v, idx = meshes.named("blob-100k")
+    lo, hi = meshes.extended_bbox(v, 0.1)
+    g = Grid.from_bounding_box(lo, hi, [128, 64, 64])
+    dv, di = _device_inputs(v, idx)
+    want = generate_grid_sdf(dv, Topology.TriangleList(di), g, SignMethod.Raycast).view(torch.int32)
+    info = {}
+    outs = [torch.zeros(128 * 64 * 64, dtype=torch.float32, device="cuda:0") for _ in range(4)]
+    generate_grid_sdf_multi(dv, Topology.TriangleList(di), g, SignMethod.Raycast, devices=[0, 0, 0, 0], outs=outs, exchange=Exchange.Nothing, info=info)
+    assert info["partition"] == "Contiguous"
+    row = 64 * 64
+    for k, o in enumerate(outs):
+        a, b = slab_bounds(128, 4, k)
+        assert torch.equal(o.view(torch.int32)[a * row:b * row], want[a * row:b * row])
+
+
 def test_multi_peer_push_large_slab_in_pieces():
     """A slab big enough for the piece pipeline (walk of piece i+1 beside the push of piece i)."""
     import torch
