@@ -305,6 +305,45 @@ def main():
             verified = all_agree(bool(torch.equal(out.view(torch.int32), ref.view(torch.int32))))
         del ref
 
+    # N > 1: what every rank spent where (means over the timed steps), and what its links give — so that ONE run on a multi-GPU
+    # node says which delivery (push / store / trail, peer vs RCCL) to choose instead of a bare number
+    per_rank = link_probe = None
+    if sharded or in_process:
+        def rank_line(ts, wall_ms):
+            dev_total = float(np.mean([t.total_ms for t in ts]))
+            return {"accel_build_ms": round(float(np.mean([t.accel_build_ms for t in ts])), 4), "seeds_and_cut_ms": round(float(np.mean([t.seed_ms for t in ts])), 4),
+                    "walk_ms": round(float(np.mean([t.distance_ms for t in ts])), 4), "walk_launches": int(ts[0].distance_launches),
+                    "device_total_ms": round(dev_total, 4), "step_wall_ms": round(wall_ms, 4),
+                    # after the last walk's kernels: the exposed part of the delivery (last piece's push / gather), the barrier wait for
+                    # the slowest rank, host overhead
+                    "after_walk_ms": round(wall_ms - dev_total, 4)}
+        if in_process:
+            info = {}
+            generate_grid_sdf_multi(dv, topo, grid, sign, devices=devices, outs=outs, exchange=Exchange.Auto, peer_mode=peer_mode, info=info)
+            per_rank = [dict(rank_line([t], info["wall_ms"]), shard=k, device=devices[k], slab=list(info["slabs"][k])) for k, t in enumerate(info["timings"])]
+            exchange_ran = info["exchange"]
+        else:
+            mine = dict(rank_line(tims, elapsed * 1e3 / args.steps), rank=rank)
+            per_rank = [None] * world
+            if world > 1:
+                dist.all_gather_object(per_rank, mine)
+            else:
+                per_rank = [mine]
+            exchange_ran = exchange
+        try:
+            from mesh_to_sdf_amd import peer_bandwidth
+            probe_cells = min(n ** 3, 16 << 20)                     # 64 MB to each peer
+            if in_process and len(set(devices)) > 1:
+                each, together = peer_bandwidth(outs[0], [o for o, d in zip(outs[1:], devices[1:]) if d != devices[0]], probe_cells)
+                link_probe = {"from_device": devices[0], "payload_mb": probe_cells * 4 >> 20, "gbps_per_peer": [round(x, 1) for x in each], "gbps_all_peers_at_once": round(together, 1)}
+            elif pg is not None and world > 1:
+                each, together = peer_bandwidth(pg.tensor, pg.peers, probe_cells)
+                mine = {"rank": rank, "payload_mb": probe_cells * 4 >> 20, "gbps_per_peer": [round(x, 1) for x in each], "gbps_all_peers_at_once": round(together, 1)}
+                link_probe = [None] * world
+                dist.all_gather_object(link_probe, mine)
+        except Exception as e:   # noqa: BLE001  (a probe must never cost the run its number)
+            link_probe = {"error": f"{type(e).__name__}: {e}"}
+
     # phase breakdown of one extra, untimed, synchronous one-shot call on this rank's whole slab
     ph = M2STimings()
     scratch_out = out if pg is None else torch.empty(n ** 3, dtype=torch.float32, device=dev)
@@ -394,6 +433,10 @@ def main():
                 "valu_issue_frac_pmc": valu_frac,
             },
         }
+        if per_rank is not None:
+            res["per_rank"] = per_rank
+            res["config"]["exchange_ran"] = exchange_ran
+            res["link_probe"] = link_probe
         if world_label == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"], rn, ref = cpu_baseline(v, idx, lo, hi, int(sign), args.cpu_seconds, n)
             # What a user switching from the reference sees (SURVEY.md header fact 2, §8c): this library's exact minimum

@@ -241,6 +241,14 @@ int m2s_balanced_slabs(uint64_t nx, int n, uint64_t unit, const uint64_t* prev_b
  * it — returns 1 — else its contiguous slab with *x_period = 0 — returns 0. */
 int m2s_interleaved_slab(const m2s_grid* grid, int n, int k, uint64_t* x_begin, uint64_t* x_end, uint64_t* x_period);
 
+/* What the links give: the copy kernel of M2S_PEER_PUSH (16 B per lane, 1 KiB per wave store instruction) writes the first n_cells
+ * floats of `src` (on `device`; -1 = current) into each of the n_peers buffers (peer-mapped device memory, as m2s_opts.peer_out) —
+ * first one peer at a time (gbps_each[k], optional), then all peers in one launch (*gbps_all, optional: the sum over the links).
+ * GB/s of payload, best of three timed launches per figure.  xGMI is point-to-point, so gbps_each is a per-link number and
+ * gbps_all / n_peers shows what a link keeps when all are busy: together they decide whether a slab's delivery hides under the
+ * walk.  Blocks until done. */
+int m2s_peer_bandwidth(const float* src, float* const* peers, uint32_t n_peers, size_t n_cells, int device, float* gbps_each, float* gbps_all);
+
 /* One process per GPU (torch.distributed / MPI launchers): the same no-collective exchange across processes.
  * Every rank allocates its whole-grid buffer with m2s_shared_alloc (a dedicated hipMalloc block, so that its IPC handle
  * maps exactly this buffer), exports it, exchanges the 64-byte handles by any host-side means, opens the other ranks'

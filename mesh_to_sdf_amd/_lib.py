@@ -154,6 +154,7 @@ EXPORTS = [
     "m2s_slab_bounds",
     "m2s_balanced_slabs",
     "m2s_interleaved_slab",
+    "m2s_peer_bandwidth",
     "m2s_shared_alloc",
     "m2s_shared_free",
     "m2s_ipc_export",
@@ -263,6 +264,8 @@ def lib():
                                              C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(M2SMultiOpts)]
         L.m2s_slab_bounds.restype = None
         L.m2s_slab_bounds.argtypes = [C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.m2s_peer_bandwidth.restype = C.c_int
+        L.m2s_peer_bandwidth.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_uint32, C.c_size_t, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         L.m2s_balanced_slabs.restype = C.c_int
         L.m2s_balanced_slabs.argtypes = [C.c_uint64, C.c_int, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_float), C.POINTER(C.c_uint64)]
         L.m2s_interleaved_slab.restype = C.c_int

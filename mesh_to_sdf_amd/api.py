@@ -413,6 +413,23 @@ def generate_grid_sdf_multi(vertices, indices: Topology, grid: Grid, sign_method
     return result
 
 
+def peer_bandwidth(src, peers, n_cells: int = None):
+    """m2s_peer_bandwidth: GB/s of the peer-push copy kernel from the CUDA tensor `src` into each tensor / SharedGrid of `peers` (one at
+    a time) and into all of them at once.  Returns (per_peer_gbps, all_together_gbps)."""
+    n = len(peers)
+    if n == 0:
+        return [], 0.0
+    n_cells = int(n_cells if n_cells is not None else src.numel())
+    ptrs = (C.c_void_p * n)(*[int(p.data_ptr()) for p in peers])
+    each = (C.c_float * n)()
+    allg = C.c_float(0.0)
+    dev = src.device.index if src.device.index is not None else -1
+    rc = _lib.lib().m2s_peer_bandwidth(int(src.data_ptr()), C.cast(ptrs, C.POINTER(C.c_void_p)), n, n_cells, dev, each, C.byref(allg))
+    if rc != _lib.M2S_OK:
+        _raise(rc)
+    return [float(x) for x in each], float(allg.value)
+
+
 def balanced_slabs(nx: int, unit: int, prev_bounds: Sequence[int], cost: Sequence[float]):
     """m2s_balanced_slabs: n + 1 slab boundaries of equal cost from the boundaries and per-shard costs of a previous call."""
     n = len(cost)

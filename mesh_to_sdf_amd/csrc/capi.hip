@@ -1406,6 +1406,58 @@ int m2s_mesh_generate_sdf(m2s_mesh* m, const float* queries, size_t n_queries, i
   return finish_call(c, *st, d_err, c.timings, m->n_tris, n_queries, false);
 }
 
+// Peer-write bandwidth probe (include/m2s.h): the copy kernel of M2S_PEER_PUSH, timed with HIP events on a stream of its own.
+int m2s_peer_bandwidth(const float* src, float* const* peers, uint32_t n_peers, size_t n_cells, int device, float* gbps_each, float* gbps_all) {
+  g_err[0] = 0;
+  if (!src || (n_peers && !peers) || n_peers > M2S_MAX_PEERS) return fail(M2S_ERR_BAD_ARG, "m2s_peer_bandwidth: bad arguments");
+  if (n_cells == 0 || n_peers == 0) { if (gbps_all) *gbps_all = 0.0f; return M2S_OK; }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(M2S_ERR_HIP, "no HIP device available");
+  if (device < 0) M2S_HIP_CHECK(hipGetDevice(&device));
+  if (device >= ndev) return fail(M2S_ERR_BAD_ARG, "device %d out of range (%d devices)", device, ndev);
+  M2S_HIP_CHECK(hipSetDevice(device));
+  hipStream_t st;
+  hipEvent_t a, b;
+  M2S_HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  M2S_HIP_CHECK(hipEventCreate(&a));
+  M2S_HIP_CHECK(hipEventCreate(&b));
+  int rc = M2S_OK;
+  auto timed = [&](const PeerOut& po, float* gbps) -> int {
+    float best = 0.0f;
+    for (int rep = 0; rep < 4; ++rep) {                           // the first repetition maps pages and warms the link up
+      M2S_HIP_CHECK(hipEventRecord(a, st));
+      const int r = launch_push_cells(st, src, po, 0, n_cells);
+      if (r) return r;
+      M2S_HIP_CHECK(hipEventRecord(b, st));
+      M2S_HIP_CHECK(hipStreamSynchronize(st));
+      float ms = 0.0f;
+      M2S_HIP_CHECK(hipEventElapsedTime(&ms, a, b));
+      if (rep && ms > 0.0f) best = std::max(best, (float)((double)n_cells * 4.0 * po.n / (ms * 1e-3) / 1e9));
+    }
+    *gbps = best;
+    return 0;
+  };
+  for (uint32_t k = 0; k < n_peers && !rc; ++k) {
+    if (!peers[k]) { rc = fail(M2S_ERR_BAD_ARG, "m2s_peer_bandwidth: peers[%u] is NULL", k); break; }
+    PeerOut one{};
+    one.n = 1;
+    one.p[0] = peers[k];
+    float g = 0.0f;
+    rc = timed(one, &g);
+    if (gbps_each) gbps_each[k] = g;
+  }
+  if (!rc && gbps_all) {
+    PeerOut all{};
+    all.n = n_peers;
+    for (uint32_t k = 0; k < n_peers; ++k) all.p[k] = peers[k];
+    rc = timed(all, gbps_all);
+  }
+  (void)hipEventDestroy(a);
+  (void)hipEventDestroy(b);
+  (void)hipStreamDestroy(st);
+  return rc;
+}
+
 // Test hook (not part of include/m2s.h): FNV-1a digests of the resident arrays of a mesh — triangle records, pre-test planes,
 // box nodes, oriented bounds, centroids, slot table, scene words.  tests/test_gpu_build.py compares two builds of one mesh
 // (M2S_BUILD=0 / 1) with it: the lean build must leave the same tree, byte for byte.

@@ -502,7 +502,10 @@ int m2s_generate_grid_sdf_multi(const float* vertices, size_t n_vertices, const 
     prev[n] = nx;
     uint32_t bl[3];
     choose_brick_shape(grid->cell_size, bl);
-    if (m2s_balanced_slabs(nx, n, 1ull << bl[0], prev.data(), cost.data(), next.data()) == M2S_OK) {
+    // boundaries on whole SUPER-bricks (8 packet bricks along x): a slab that is not a multiple of them walks in narrower super-bricks
+    // and loses more locality than balance can win (emulated 8-GPU ranks, 512^3 x blob-100k: slabs of 56 layers took 2.01 ms where
+    // 64 layers took 1.83; tools/exp_rank_step.py --partition adaptive) — so the cut only moves where shards own many of them
+    if (m2s_balanced_slabs(nx, n, 8ull << bl[0], prev.data(), cost.data(), next.data()) == M2S_OK) {
       std::lock_guard<std::mutex> lk(g_adaptive_mu);
       if (g_adaptive.size() > 64) g_adaptive.clear();
       g_adaptive[akey] = next;

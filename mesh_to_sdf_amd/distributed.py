@@ -163,12 +163,17 @@ class PeerGrid:
         if any(h is None for h in handles):
             self.close(sync=False)
             raise RuntimeError(f"a rank could not allocate / export its shared grid buffer ({why})")
+        # the same care for the second phase: a rank that cannot map a peer must not leave the others waiting in the step's barrier
         try:
             self.peers = [SharedGrid.open(h, n_cells, device) for r, h in enumerate(handles) if r != self.rank]
             self.tensor = self.local.tensor
-        except Exception:
+        except Exception as e:   # noqa: BLE001
+            why = e
+        opened = [None] * self.world
+        dist.all_gather_object(opened, why is None, group=group)
+        if not all(opened):
             self.close(sync=False)
-            raise
+            raise RuntimeError(f"a rank could not map a peer's shared grid buffer ({why})")
 
     def close(self, sync: bool = True):
         """`sync`: barrier between unmapping the peers and freeing the own buffer (nobody frees under a peer that is still
@@ -201,6 +206,11 @@ def generate_grid_sdf_sharded(vertices, indices: Topology, grid: Grid, sign_meth
                         slab costs 30 % more than an outer one), or its contiguous x-slab where the grid does not allow that;
       otherwise         `chunks` contiguous x-ranges, each gathered in place by an asynchronous RCCL all-gather that
                         overlaps the next chunk's compute.
+
+    Reuse of a PeerGrid across steps: the barrier at the end of a step orders the HOST threads.  A rank's next step starts
+    writing into every rank's buffer as soon as it is called, so whatever consumes `out` on the GPU (a kernel of the caller's, a
+    copy) must have finished on EVERY rank before ANY rank starts the next step — synchronise the consuming stream and put a
+    barrier in front of the next call, or double-buffer with two PeerGrids (bench.py consumes nothing between steps).
 
     compute_slab(out, x0, x1) may replace the slab computation (the CPU tests inject the oracle there
     so the partition / overlap / gather logic runs under gloo without a GPU)."""

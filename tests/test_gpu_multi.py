@@ -179,7 +179,7 @@ def test_adaptive_partition_and_persistent_workers():
 
     v, idx = meshes.named("blob-100k")
     lo, hi = meshes.extended_bbox(v, 0.1)
-    g = Grid.from_bounding_box(lo, hi, [128, 96, 96])
+    g = Grid.from_bounding_box(lo, hi, [256, 64, 64])
     dv, di = _device_inputs(v, idx)
     want = generate_grid_sdf(dv, Topology.TriangleList(di), g, SignMethod.Raycast)
     seen = set()
@@ -191,9 +191,9 @@ def test_adaptive_partition_and_persistent_workers():
             assert torch.equal(o.view(torch.int32), want.view(torch.int32))
         assert info["partition"] == "Adaptive"
         b = [s[0] for s in info["slabs"]] + [info["slabs"][-1][1]]
-        assert b[0] == 0 and b[-1] == 128 and all(b[k + 1] > b[k] and b[k] % 4 == 0 for k in range(4)) and all(s[2] == 0 for s in info["slabs"])
+        assert b[0] == 0 and b[-1] == 256 and all(b[k + 1] > b[k] and b[k] % 32 == 0 for k in range(4)) and all(s[2] == 0 for s in info["slabs"])
         seen.add(tuple(b))
-    assert (0, 32, 64, 96, 128) in seen                                     # the first call knows nothing: even slabs
+    assert (0, 64, 128, 192, 256) in seen                                   # the first call knows nothing: even slabs
     for n in (2, 4, 3, 1, 4):                                                # the worker pool grows and idles
         info = {}
         outs = generate_grid_sdf_multi(dv, Topology.TriangleList(di), g, SignMethod.Raycast, devices=[0] * n, exchange=Exchange.Peer, info=info)
@@ -455,11 +455,16 @@ def test_bench_contract_single_line_json_in_every_mode():
     assert d["n_gpus"] == 1 and d["unit"] == "Mvoxels/s" and d["roofline"]["bound"] == "hbm" and d["roofline"]["frac"] > 0
     d = _bench(small + ["--gpus", "3"], {"M2S_BENCH_DEVICES": "0,0,0"})                       # one process, three shards on this GPU
     assert d["n_gpus"] == 3 and d["config"]["gather_verified"] is True and d["config"]["exchange"] == "in-process"
+    assert len(d["per_rank"]) == 3 and all(r["walk_ms"] > 0 and r["accel_build_ms"] > 0 and len(r["slab"]) == 3 for r in d["per_rank"])
+    assert d["config"]["exchange_ran"] == "Peer"
     launch = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
               "--master-port", str(29700 + os.getpid() % 200)]
     for exchange in ("peer", "rccl"):                                                           # two ranks share this GPU (gloo: RCCL refuses that)
         d = _bench(small + ["--gpus", "2"], {"M2S_DIST_BACKEND": "gloo", "M2S_EXCHANGE": exchange}, launch)
         assert d["n_gpus"] == 2 and d["config"]["exchange"] == exchange and d["config"]["gather_verified"] is True
+        assert [r["rank"] for r in d["per_rank"]] == [0, 1] and all(r["walk_ms"] > 0 and r["step_wall_ms"] > 0 for r in d["per_rank"])
+        if exchange == "peer":                                                                  # the link probe ran on both ranks (here: into the same GPU's HBM)
+            assert [p["rank"] for p in d["link_probe"]] == [0, 1] and all(p["gbps_per_peer"][0] > 1.0 for p in d["link_probe"])
     d = _bench(small, {"M2S_FORCE_COLLECTIVES": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(29900 + os.getpid() % 90), "RANK": "0",
                        "WORLD_SIZE": "1", "M2S_EXCHANGE": "rccl"})                              # 1-rank nccl group: the banner case
     assert d["config"]["exchange"] == "rccl" and d["config"]["gather_verified"] is True

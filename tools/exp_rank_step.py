@@ -26,11 +26,12 @@ def main():
     ap.add_argument("--modes", default="none,trail,push,store")
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--ranks", default="")
-    ap.add_argument("--partition", default="contiguous", choices=["contiguous", "interleaved"])
+    ap.add_argument("--partition", default="contiguous", choices=["contiguous", "interleaved", "adaptive"])
+    ap.add_argument("--adapt-rounds", type=int, default=4, help="adaptive: rounds of (all ranks measured alone, slabs re-cut by m2s_balanced_slabs)")
     args = ap.parse_args()
     import torch
 
-    from mesh_to_sdf_amd import Grid, M2STimings, PeerMode, SignMethod, Topology, generate_grid_sdf, interleaved_slab, meshes, slab_bounds
+    from mesh_to_sdf_amd import Grid, M2STimings, PeerMode, SignMethod, Topology, balanced_slabs, generate_grid_sdf, interleaved_slab, meshes, slab_bounds
 
     v, idx = meshes.named(args.mesh)
     lo, hi = meshes.extended_bbox(v, 0.1)
@@ -59,6 +60,21 @@ def main():
     for world in [int(w) for w in args.world.split(",")]:
         peers = [torch.empty(n ** 3, dtype=torch.float32, device="cuda") for _ in range(world - 1)]
         ranks = [int(r) for r in args.ranks.split(",")] if args.ranks else (list(range(world)) if args.partition == "interleaved" else sorted({0, world // 2 - 1, world // 2, world - 1}))
+        if args.partition == "adaptive":
+            # what M2S_PART_ADAPTIVE / the bench's adaptive slabs converge to: every round measures all ranks (alone, no delivery)
+            # and re-cuts the slabs from their device times without the build
+            bounds = [slab_bounds(n, world, r)[0] for r in range(world)] + [n]
+            for rnd in range(args.adapt_rounds + 1):
+                walls, costs = [], []
+                for r in range(world):
+                    t = M2STimings()
+                    med, mn = timed(lambda: generate_grid_sdf(dv, topo, grid, sign, x_slab=(bounds[r], bounds[r + 1]), out=out, timings=t))
+                    walls.append(med)
+                    costs.append(max(t.total_ms - t.accel_build_ms, 0.0))
+                print(f"world {world} adaptive round {rnd}: bounds {bounds} wall per rank {[round(w, 3) for w in walls]} -> slowest {max(walls):.3f} ms, "
+                      f"bound {med1 / max(walls):.2f}x of {world}", flush=True)
+                bounds = balanced_slabs(n, 4, bounds, costs)
+            continue
         for mode in args.modes.split(","):
             worst = 0.0
             for r in ranks:
