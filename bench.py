@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--mesh", default="blob-100k")
     ap.add_argument("--sign", default="Raycast", choices=["Raycast", "Normal"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-live-pmc", action="store_true", help="do not measure roofline.traffic with rocprofv3 --pmc child runs after the timed region")
     ap.add_argument("--cpu-seconds", type=float, default=150.0, help="budget for the CPU baseline run (512^3 needs ~40-60 s)")
     ap.add_argument("--chunks", type=int, default=0, help="x-chunks per step whose all-gathers overlap compute (0 = auto)")
     ap.add_argument("--config", type=int, default=0, choices=[0, 2, 3, 4, 5],
@@ -55,7 +56,7 @@ def parse():
     args = ap.parse_args()
     if args.config in (2, 4, 5):
         args.mesh, args.grid, args.sign = {2: ("blob-100k", 256, "Raycast"), 4: ("blob-1M", 512, "Raycast"), 5: ("sheet-100k", 1024, "Normal")}[args.config]
-        args.no_cpu_baseline = True      # the CPU baseline belongs to the headline line
+        args.cpu_seconds = min(args.cpu_seconds, 45.0)   # a bounded sample (<= 384^3) of the config's own mesh / sign rule beside its line
     return args
 
 
@@ -88,6 +89,35 @@ def bench_queries(args):
     dist_ms = float(np.mean([t.distance_ms for t in tims]))      # Morton sort + seed lattice + k_packet<LIST, UNSIGNED, RAYS3>
     b_alg = 16.0 * nq + 12.0 * v.shape[0] + 12.0 * int(tims[0].n_triangles)   # 16 B per query + the mesh once
     achieved = b_alg / (dist_ms * 1e-3) / 1e9
+    traffic = traffic_src = None
+    if not args.no_live_pmc:
+        live, why_not = live_pmc(["--config", "3", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-live-pmc"])
+        if live is not None:
+            traffic = 2.0 * live["FETCH_SIZE"] * 1024.0 + live["WRITE_SIZE"] * 1024.0
+            traffic_src = (f"live: rocprofv3 --pmc child runs of this command after the timed region, k_packet only (the query sort and seed lattice in front "
+                           f"of it are not in this figure), {live['FETCH_SIZE_dispatches']} launches; FETCH_SIZE {live['FETCH_SIZE'] * 1024 / 1e6:.1f} MB as reported, "
+                           f"doubled (gfx950 half-count); WRITE_SIZE {live['WRITE_SIZE'] * 1024 / 1e6:.1f} MB")
+        elif why_not != "child run":
+            traffic_src = f"live measurement unavailable ({why_not})"
+    extra = {}
+    if not args.no_cpu_baseline:
+        # "CPU BVH nearest + 3-ray sign" beside the 10 M-query run (generic/rtree_bvh.rs:79-174): the oracle's
+        # BVH-accelerated exact search + best-of-three rays, all host threads, on the first 1 M queries of the same set; the same
+        # sample also checks the GPU result bit for bit
+        import oracle as orc
+
+        ns = 1_000_000
+        qs = meshes.uniform_queries(lo, hi, nq)[:ns]
+        cores = orc.hardware_threads()
+        t1 = time.perf_counter()
+        want = orc.generate_sdf(v, idx, qs, accel=3, fast=True, threads=cores)
+        dt = time.perf_counter() - t1
+        got = generate_sdf(dv, topo, dq[:ns].contiguous(), AccelerationMethod.RtreeBvh).cpu().numpy()
+        extra["cpu_baseline"] = {"value": round(ns / dt / 1e6, 4), "unit": "Mqueries/s", "cores": cores, "kind": "port",
+                                 "sample": f"the first {ns} of the {nq} queries, same mesh: C++ restatement of the reference's exact nearest search + "
+                                           f"best-of-three rays with a BVH (oracle/, fast path), {cores} threads, {dt:.2f} s"}
+        extra["oracle_check"] = {"queries": ns, "bit_identical": bool(np.array_equal(got.view(np.uint32), want.view(np.uint32))),
+                                 "sign_mismatches": int(np.count_nonzero(np.signbit(got) != np.signbit(want)))}
     emit(json.dumps({
         "metric": "Mqueries/s for generate_sdf (10M random queries, 100k tris, RtreeBvh)", "value": round(nq * args.steps / elapsed / 1e6, 2),
         "unit": "Mqueries/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed * 1e3 / args.steps, 4),
@@ -96,9 +126,53 @@ def bench_queries(args):
                                "(nearest distance + best of three rays), inputs/outputs resident in HBM", "queries": nq, "mesh": "blob-100k"},
         "phases_ms": {"accel_build": round(float(np.mean([t.accel_build_ms for t in tims])), 4), "sort_seed_walk": round(dist_ms, 4)},
         "roofline": {"bound": "hbm", "kernel": "k_packet<LIST, MODE_UNSIGNED, SIGN_RAYS3> (+ the query sort and seed lattice in front of it)",
-                     "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
-                     "algorithmic_bytes_per_launch": b_alg, "avg_launch_ms": round(dist_ms, 4)},
+                     "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
+                     "traffic_source": traffic_src, "algorithmic_bytes_per_launch": b_alg, "avg_launch_ms": round(dist_ms, 4)},
+        **extra,
     }))
+
+
+def live_pmc(child_args, kernel="k_packet"):
+    """HBM-side traffic and VALU issue of the dominant kernel, MEASURED for this very invocation: after the timed region the same
+    command is run again as a child under `rocprofv3 --pmc`, one pass per counter group (FETCH_SIZE and WRITE_SIZE do not fit one
+    pass: /opt/skills/guides/MI355X_MICROARCH.md), and the per-dispatch sums of the kernel's rows are averaged.  Returns
+    (dict, None) or (None, reason)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+
+    if os.environ.get("M2S_BENCH_CHILD") == "1":
+        return None, "child run"
+    if shutil.which("rocprofv3") is None:
+        return None, "rocprofv3 is not on PATH"
+    got = {}
+    for counters in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU GRBM_GUI_ACTIVE SQ_WAVES"):
+        d = tempfile.mkdtemp(prefix="m2s_pmc_", dir="/tmp")
+        try:
+            cmd = ["rocprofv3", "--pmc"] + counters.split() + ["--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--",
+                                                                sys.executable, os.path.abspath(__file__)] + child_args
+            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp", M2S_BENCH_CHILD="1"), capture_output=True, text=True, timeout=400)
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None, f"rocprofv3 --pmc {counters} failed (rc {r.returncode}): {r.stderr[-300:]}"
+            acc = {}
+            for f in files:
+                for row in csv.DictReader(open(f)):
+                    if kernel in row["Kernel_Name"]:
+                        per = acc.setdefault(row["Counter_Name"], {})
+                        per[row["Dispatch_Id"]] = per.get(row["Dispatch_Id"], 0.0) + float(row["Counter_Value"])
+            for c in counters.split():
+                if c not in acc:
+                    return None, f"no {c} rows for {kernel}"
+                got[c] = sum(acc[c].values()) / len(acc[c])
+                got[c + "_dispatches"] = len(acc[c])
+        except Exception as e:   # noqa: BLE001
+            return None, f"{type(e).__name__}: {e}"
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return got, None
 
 
 def cpu_baseline(v, idx, lo, hi, sign, budget_s, headline_n):
@@ -370,12 +444,24 @@ def main():
         valu_frac = None
         pmc_src = None
         pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
-        # the PMC figure is per launch over the WHOLE 512^3 grid: it only applies to the 1-GPU, 1-launch step
-        if os.path.exists(pmc) and world_label == 1 and launches == args.steps and n == 512 and args.mesh == "blob-100k":
+        if world_label == 1 and launches == args.steps and not args.no_live_pmc:
+            child = ["--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-live-pmc", "--grid", str(n), "--mesh", args.mesh, "--sign", args.sign]
+            live, why_not = live_pmc(child)
+            if live is not None:
+                # KiB -> bytes; FETCH_SIZE doubled: gfx950's rocprofv3 tallies 128-byte requests at 64 B (MI355X_MICROARCH.md, HBM section)
+                traffic = 2.0 * live["FETCH_SIZE"] * 1024.0 + live["WRITE_SIZE"] * 1024.0
+                valu_frac = round(live["SQ_INSTS_VALU"] / (1024.0 * (live["GRBM_GUI_ACTIVE"] / 8.0) / 2.0), 3)
+                pmc_src = (f"live: rocprofv3 --pmc child runs of this command after the timed region, one pass per counter group, averaged over "
+                           f"{live['FETCH_SIZE_dispatches']} launches; FETCH_SIZE {live['FETCH_SIZE'] * 1024 / 1e6:.1f} MB as reported, doubled (gfx950 half-count); "
+                           f"WRITE_SIZE {live['WRITE_SIZE'] * 1024 / 1e6:.1f} MB")
+            elif why_not != "child run":
+                pmc_src = f"live measurement unavailable ({why_not})"
+        # fallback: the PMC figure of the last committed passes, per launch over the WHOLE 512^3 grid (1-GPU, 1-launch step only)
+        if traffic is None and os.path.exists(pmc) and world_label == 1 and launches == args.steps and n == 512 and args.mesh == "blob-100k":
             try:
                 pj = json.load(open(pmc))
                 traffic = pj.get("k_packet_hbm_bytes_per_launch")
-                pmc_src = f"static: profiles/pmc_latest.json ({pj.get('source', 'rocprofv3 --pmc')}), not collected in this run"
+                pmc_src = (pmc_src + "; " if pmc_src else "") + f"static: profiles/pmc_latest.json ({pj.get('source', 'rocprofv3 --pmc')}), not collected in this run"
                 valu_frac = pj.get("valu_issue_frac")
             except Exception:
                 traffic = None
@@ -425,8 +511,8 @@ def main():
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 6),
                 "traffic": traffic,
-                # NOT measured in this run: constants from the last committed rocprofv3 --pmc passes of this same command
-                "traffic_source": (pmc_src if traffic is not None else None),
+                # "live: ..." = measured by rocprofv3 --pmc child runs of this invocation; "static: ..." = the last committed passes
+                "traffic_source": pmc_src,
                 "algorithmic_bytes_per_launch": b_alg,
                 "avg_launch_ms": round(dist_ms, 4),
                 # context, from the same PMC passes: the kernel's real ceiling is VALU issue
@@ -448,6 +534,7 @@ def main():
                                        "reference": f"oracle PROPAGATE (generate/grid.rs:383-558 restated), {res['cpu_baseline']['cores']} heaps",
                                        **reference_parity(ours, ref, normal_sign=(args.sign == "Normal"))}
             del ours, ref
+        if world_label == 1 and not args.no_cpu_baseline and args.config == 0:
             # the PCIe-inclusive drop-in call (host pointers in/out), reported for DESIGN.md; never `value`
             host_out = np.empty(n ** 3, np.float32)
             times = []

@@ -49,7 +49,7 @@ extern "C" {
 #endif
 
 #define M2S_VERSION_MAJOR 0
-#define M2S_VERSION_MINOR 3   /* 0.3: + m2s_generate_sdf_multi (additive; 0.2 callers are unaffected) */
+#define M2S_VERSION_MINOR 4   /* 0.4: + m2s_warmup, m2s_peer_bandwidth, m2s_balanced_slabs, M2S_PART_ADAPTIVE, m2s_multi_opts.partition_used / slabs (additive) */
 
 /* Return codes.  The reference panics where this ABI returns a negative code; the Rust shim
  * turns a negative code back into panic!(m2s_last_error()). */
@@ -399,6 +399,14 @@ int m2s_gltf_instances(const m2s_gltf* gltf, m2s_instance* out, size_t capacity)
 void m2s_gltf_close(m2s_gltf* gltf);
 
 /* Library / device introspection. */
+/* The one-off costs of a process's first call, paid now instead: the HIP runtime and this library's code objects on `device`
+ * (-1 = the current one), the streams and events of the device's context, `workspace_bytes` of device workspace (0 = none: it
+ * grows on demand; a 512^3 grid call needs ~0.6 GB, 10 M queries ~1.5 GB) and, for callers of the host-pointer entry points, the
+ * pinned staging ring (`host_ring_bytes` > 0: three slots of min(host_ring_bytes, 64 MB)).  Optional, idempotent, blocking.
+ * The reference's usage is one call per process (examples/demo.rs:29-54): without this the first call pays 20-40 ms (grid,
+ * host result) to ~0.9 s (10 M queries through host pointers) on top of its steady-state time — INTEGRATION.md has the breakdown;
+ * M2S_HOST_TIMES=1 prints it per call on stderr. */
+int m2s_warmup(int device, size_t workspace_bytes, size_t host_ring_bytes);
 int m2s_version(void);               /* major*1000 + minor */
 int m2s_device_count(void);          /* HIP devices visible; 0 if none (every compute call then fails with M2S_ERR_HIP) */
 const char* m2s_last_error(void);    /* thread-local message of the last failing call on this thread */

@@ -124,6 +124,7 @@ EXPORTS = [
     "m2s_grid_cell_center",
     "m2s_grid_cell_idx",
     "m2s_triangle_count",
+    "m2s_warmup",
     "m2s_version",
     "m2s_device_count",
     "m2s_last_error",
@@ -205,6 +206,8 @@ def lib():
         L.m2s_grid_cell_idx.argtypes = [C.POINTER(M2SGrid), C.POINTER(C.c_uint64)]
         L.m2s_triangle_count.restype = C.c_size_t
         L.m2s_triangle_count.argtypes = [C.c_size_t, C.c_size_t, C.c_int, C.c_int]
+        L.m2s_warmup.restype = C.c_int
+        L.m2s_warmup.argtypes = [C.c_int, C.c_size_t, C.c_size_t]
         L.m2s_version.restype = C.c_int
         L.m2s_device_count.restype = C.c_int
         L.m2s_last_error.restype = C.c_char_p

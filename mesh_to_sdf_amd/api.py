@@ -413,6 +413,13 @@ def generate_grid_sdf_multi(vertices, indices: Topology, grid: Grid, sign_method
     return result
 
 
+def warmup(device: int = -1, workspace_bytes: int = 0, host_ring_bytes: int = 0):
+    """m2s_warmup: pay the one-off costs of a process's first call now (runtime, code objects, context, optional workspace / pinned ring)."""
+    rc = _lib.lib().m2s_warmup(int(device), int(workspace_bytes), int(host_ring_bytes))
+    if rc != _lib.M2S_OK:
+        _raise(rc)
+
+
 def peer_bandwidth(src, peers, n_cells: int = None):
     """m2s_peer_bandwidth: GB/s of the peer-push copy kernel from the CUDA tensor `src` into each tensor / SharedGrid of `peers` (one at
     a time) and into all of them at once.  Returns (per_peer_gbps, all_together_gbps)."""

@@ -1372,4 +1372,24 @@ int build_device_mesh(Arena& ws, hipStream_t st, const float* d_verts, size_t n_
   return 0;
 }
 
+// m2s_warmup: the first launch of a kernel of this translation unit makes the runtime load its code object (all its kernels).
+__global__ void k_warm_bvh() {}
+void warm_bvh(hipStream_t st) {
+  hipLaunchKernelGGL(k_warm_bvh, dim3(1), dim3(64), 0, st);
+  // ... and resolves a kernel FUNCTION at its own first launch (~0.3 ms each): ask for the attributes of the ones a first call uses
+  const void* fns[] = {
+      (const void*)k_tri_setup,
+      (const void*)k_clear_aux,
+      (const void*)k_morton_hist,
+      (const void*)k_karras,
+      (const void*)k_treelet_roots_block,
+      (const void*)k_treelet_lanes,
+      (const void*)k_seg_build,
+      (const void*)k_emit,
+      (const void*)k_node_ext};
+  hipFuncAttributes attr;
+  for (const void* f : fns) (void)hipFuncGetAttributes(&attr, f);
+  (void)hipGetLastError();
+}
+
 }  // namespace m2s

@@ -1,5 +1,6 @@
 // capi.hip — the C ABI of include/m2s.h: argument checks that mirror the reference's panics,
 // per-device workspace, host<->device staging for the drop-in (host pointer) case, phase timing.
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -45,6 +46,24 @@ int fail(int code, const char* fmt, ...) {
   va_end(ap);
   return code;
 }
+
+// M2S_HOST_TIMES=1: where the host time of a call goes (first calls especially: runtime start, code objects, workspace, pinned ring).
+struct HostClock {
+  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now(), last = t0;
+  bool on = getenv("M2S_HOST_TIMES") != nullptr;
+  char line[512] = "";
+  void lap(const char* what) {
+    if (!on) return;
+    const auto now = std::chrono::steady_clock::now();
+    const size_t n = strlen(line);
+    snprintf(line + n, sizeof(line) - n, " %s %.2f ms,", what, std::chrono::duration<double, std::milli>(now - last).count());
+    last = now;
+  }
+  void done(const char* call) {
+    if (!on) return;
+    fprintf(stderr, "[m2s host time] %s:%s total %.2f ms\n", call, line, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+  }
+};
 
 // HIP multiplexes a process's streams onto a few hardware queues (4 by default): every stream this library creates can
 // end up sharing a queue with one of the caller's and serialise work the caller meant to overlap (measured: the two
@@ -921,10 +940,12 @@ int m2s_generate_grid_sdf(const float* vertices, size_t n_vertices, const void* 
   }
   if (!out) return fail(M2S_ERR_BAD_ARG, "out is NULL");
 
+  HostClock hc;
   CallCtx c;
   DeviceState* st = nullptr;
   rc = resolve_ctx(opts, &c, &st);
   if (rc) return rc;
+  hc.lap("runtime + context");
   if (g.chunk_log < 31u && c.mem_kind != M2S_MEM_DEVICE) return fail(M2S_ERR_BAD_ARG, "m2s_opts.x_period needs mem_kind == M2S_MEM_DEVICE");
 
   size_t need = bvh_workspace_bytes(n_tris) + 4096;
@@ -934,13 +955,15 @@ int m2s_generate_grid_sdf(const float* vertices, size_t n_vertices, const void* 
     need += align_up(n_vertices * 12) + align_up(n_indices * (size_t)(indices ? index_bytes : 0)) + align_up(slab_cells * 4) + 1024;
   rc = ensure_capacity(*st, need);
   if (rc) return rc;
+  hc.lap("workspace");
   Arena ws{st->base, st->cap, 0};
 
   int* d_err = ws.take<int>(16);
-  M2S_HIP_CHECK(hipMemsetAsync(d_err, 0, 64, c.stream));
+  M2S_HIP_CHECK(hipMemsetAsync(d_err, 0, 64, c.stream));   // the first kernel-side call: loads this library's code objects
   StagedMesh sm;
   rc = stage_mesh(ws, c, vertices, n_vertices, indices, n_indices, index_bytes, &sm);
   if (rc) return rc;
+  hc.lap("mesh staged");
   float* d_out = out;
   float* d_slab = nullptr;
   if (c.mem_kind == M2S_MEM_HOST) {
@@ -1008,6 +1031,7 @@ int m2s_generate_grid_sdf(const float* vertices, size_t n_vertices, const void* 
   rc = build_device_mesh(ws, c.stream, sm.d_verts, n_vertices, sm.d_indices, n_indices, index_bytes, topology, n_tris, d_err, &mesh,
                          &seeds_beside_build);
   if (rc) return rc;
+  hc.lap("build enqueued (code objects on a first call)");
   M2S_HIP_CHECK(hipEventRecord(st->ev[1], c.stream));
   st->planes_done = nullptr;
   if (st->early_planes) {
@@ -1027,8 +1051,10 @@ int m2s_generate_grid_sdf(const float* vertices, size_t n_vertices, const void* 
     uint32_t pieces = 1;
     rc = run_grid_distance_to_host(ws, c, *st, mesh, g, sign_method, plane, d_slab, d_err, out + (size_t)xb * ny * nz, &pieces);
     if (rc) return rc;
+    hc.lap("walks + pinned ring + copy into the caller's array");
     rc = finish_call(c, *st, d_err, c.timings, n_tris, slab_cells, sign_method == M2S_SIGN_RAYCAST, false);
     if (c.timings) c.timings->distance_launches = pieces;   // distance_ms then covers the seed passes of every piece too
+    hc.done("m2s_generate_grid_sdf (host result)");
     return rc;
   }
   if (c.peers.n && c.peer_mode != M2S_PEER_STORE && !getenv("M2S_STATS")) {
@@ -1044,7 +1070,10 @@ int m2s_generate_grid_sdf(const float* vertices, size_t n_vertices, const void* 
   if (rc) return rc;
   if (c.mem_kind == M2S_MEM_HOST)
     M2S_HIP_CHECK(hipMemcpyAsync(out + (size_t)xb * ny * nz, d_slab, slab_cells * 4, hipMemcpyDeviceToHost, c.stream));
-  return finish_call(c, *st, d_err, c.timings, n_tris, slab_cells, sign_method == M2S_SIGN_RAYCAST, true);
+  rc = finish_call(c, *st, d_err, c.timings, n_tris, slab_cells, sign_method == M2S_SIGN_RAYCAST, true);
+  hc.lap("enqueue + wait");
+  hc.done("m2s_generate_grid_sdf");
+  return rc;
 }
 
 int m2s_generate_sdf(const float* vertices, size_t n_vertices, const void* indices, size_t n_indices, int index_bytes,
@@ -1064,10 +1093,12 @@ int m2s_generate_sdf(const float* vertices, size_t n_vertices, const void* indic
   if (n_queries == 0) return M2S_OK;
   if (!out) return fail(M2S_ERR_BAD_ARG, "out is NULL");
 
+  HostClock hc;
   CallCtx c;
   DeviceState* st = nullptr;
   rc = resolve_ctx(opts, &c, &st);
   if (rc) return rc;
+  hc.lap("runtime + context");
 
   int mode, sign_src, algorithm;
   select_generic_mode(accel, sign_method, c.algorithm, &mode, &sign_src, &algorithm);
@@ -1077,6 +1108,7 @@ int m2s_generate_sdf(const float* vertices, size_t n_vertices, const void* indic
     need += align_up(n_vertices * 12) + align_up(n_indices * (size_t)(indices ? index_bytes : 0)) + align_up(n_queries * 12) + align_up(n_queries * 4) + 1024;
   rc = ensure_capacity(*st, need);
   if (rc) return rc;
+  hc.lap("workspace");
   Arena ws{st->base, st->cap, 0};
   int* d_err = ws.take<int>(16);
   M2S_HIP_CHECK(hipMemsetAsync(d_err, 0, 64, c.stream));
@@ -1092,11 +1124,13 @@ int m2s_generate_sdf(const float* vertices, size_t n_vertices, const void* indic
     rc = staged_h2d(*st, c.stream, reinterpret_cast<char*>(dq), reinterpret_cast<const char*>(queries), n_queries * 12);
     if (rc) return rc;
     d_q = dq;
+    hc.lap("queries to the device (pinned ring on a first call)");
   }
   M2S_HIP_CHECK(hipEventRecord(st->ev[0], c.stream));
   DeviceMesh mesh;
   rc = build_device_mesh(ws, c.stream, sm.d_verts, n_vertices, sm.d_indices, n_indices, index_bytes, topology, n_tris, d_err, &mesh);
   if (rc) return rc;
+  hc.lap("build enqueued (code objects on a first call)");
   M2S_HIP_CHECK(hipEventRecord(st->ev[1], c.stream));
   M2S_HIP_CHECK(hipEventRecord(st->ev[2], c.stream));
   unsigned long long* d_stats = nullptr;
@@ -1112,7 +1146,51 @@ int m2s_generate_sdf(const float* vertices, size_t n_vertices, const void* indic
     if (rc) return rc;
   }
   if (n_out) *n_out = n_queries;
-  return finish_call(c, *st, d_err, c.timings, n_tris, n_queries, false);
+  rc = finish_call(c, *st, d_err, c.timings, n_tris, n_queries, false);
+  hc.lap("sort + walk + result");
+  hc.done("m2s_generate_sdf");
+  return rc;
+}
+
+// Pays the one-off costs of a process's first call now (include/m2s.h).
+int m2s_warmup(int device, size_t workspace_bytes, size_t host_ring_bytes) {
+  g_err[0] = 0;
+  m2s_opts o{};
+  o.struct_size = sizeof(m2s_opts);
+  o.device = device;
+  o.mem_kind = M2S_MEM_DEVICE;
+  o.synchronous = 1;
+  CallCtx c;
+  DeviceState* st = nullptr;
+  int rc = resolve_ctx(&o, &c, &st);                             // runtime, device, the context's events and stream
+  if (rc) return rc;
+  if (workspace_bytes) { rc = ensure_capacity(*st, workspace_bytes); if (rc) return rc; }
+  if (host_ring_bytes) { rc = ensure_ring(*st, std::min<size_t>(host_ring_bytes, (size_t)64 << 20)); if (rc) return rc; }
+  rc = ensure_side_stream(*st);
+  if (rc) return rc;
+  if (!st->side_stream2) { rc = create_side_stream(&st->side_stream2); if (rc) return rc; }
+  if (!st->copy_stream) M2S_HIP_CHECK(hipStreamCreateWithFlags(&st->copy_stream, hipStreamNonBlocking));
+  {
+    // the first copy between PAGEABLE host memory and the device makes the runtime set up its staging path (measured: 15 ms of a first
+    // call's mesh upload): a few bytes each way through the workspace
+    constexpr size_t probe = (size_t)4 << 20;                     // large enough to take the runtime's chunked staging path
+    rc = ensure_capacity(*st, probe);
+    if (rc) return rc;
+    std::vector<char> tmp(probe, 0);
+    M2S_HIP_CHECK(hipMemcpyAsync(st->base, tmp.data(), probe, hipMemcpyHostToDevice, c.stream));
+    M2S_HIP_CHECK(hipMemcpyAsync(tmp.data(), st->base, probe, hipMemcpyDeviceToHost, c.stream));
+    // ... and the first touch of freshly allocated device memory maps its pages (17 ms for the 0.7 GB of a 512^3 call): touch it all now
+    M2S_HIP_CHECK(hipMemsetAsync(st->base, 0, workspace_bytes ? st->cap : 256, c.stream));
+    M2S_HIP_CHECK(hipStreamSynchronize(c.stream));
+  }
+  warm_bvh(c.stream);                                            // one empty kernel per translation unit: the runtime loads a code object
+  warm_sign(c.stream);                                           // (all the unit's kernels) at the first launch out of it
+  warm_distance(c.stream);
+  warm_serde(c.stream);
+  warm_client(c.stream);
+  M2S_HIP_CHECK(hipGetLastError());
+  M2S_HIP_CHECK(hipStreamSynchronize(c.stream));
+  return M2S_OK;
 }
 
 

@@ -187,4 +187,8 @@ int launch_merge_instances(Arena& ws, hipStream_t st, const InstanceDev* d_inst,
   return 0;
 }
 
+// m2s_warmup: the first launch of a kernel of this translation unit makes the runtime load its code object (all its kernels).
+__global__ void k_warm_client() {}
+void warm_client(hipStream_t st) { hipLaunchKernelGGL(k_warm_client, dim3(1), dim3(64), 0, st); }
+
 }  // namespace m2s

@@ -212,6 +212,12 @@ struct Arena {
 };
 
 // ---- host launchers implemented in the .hip files ------------------------------------------
+// one empty kernel per translation unit (m2s_warmup)
+void warm_bvh(hipStream_t st);
+void warm_sign(hipStream_t st);
+void warm_distance(hipStream_t st);
+void warm_serde(hipStream_t st);
+void warm_client(hipStream_t st);
 // bvh.hip: flatten topology, build triangle records + LBVH in pre-order layout.
 size_t bvh_workspace_bytes(size_t n_tris);
 // `after_setup` (optional) is called twice with the input-order centroid array and triangle records: with phase 0 once the kernels that fill

@@ -1808,4 +1808,36 @@ int launch_query_distance(Arena& ws, hipStream_t st, const DeviceMesh& mesh, con
   return 0;
 }
 
+// m2s_warmup: the first launch of a kernel of this translation unit makes the runtime load its code object (all its kernels).
+__global__ void k_warm_distance() {}
+void warm_distance(hipStream_t st) {
+  hipLaunchKernelGGL(k_warm_distance, dim3(1), dim3(64), 0, st);
+  // ... and resolves a kernel FUNCTION at its own first launch (~0.3 ms each): ask for the attributes of the ones a first call uses
+  const void* fns[] = {
+      (const void*)k_packet<true, MODE_UNSIGNED, SIGN_GRID_PLANE, false>,
+      (const void*)k_packet<true, MODE_NORMAL_FOLD, SIGN_NONE, false>,
+      (const void*)k_packet<false, MODE_UNSIGNED, SIGN_RAYS3, false>,
+      (const void*)k_packet<false, MODE_NEAREST_NORMAL, SIGN_NONE, false>,
+      (const void*)k_cut<true>,
+      (const void*)k_cut<false>,
+      (const void*)k_lane<MODE_UNSIGNED, SIGN_GRID_PLANE>,
+      (const void*)k_lane_q<MODE_UNSIGNED, SIGN_RAYS3>,
+      (const void*)k_jfa_splat,
+      (const void*)k_jfa_load,
+      (const void*)k_jfa_pass,
+      (const void*)k_seed_remap,
+      (const void*)k_qbounds,
+      (const void*)k_qbounds_final,
+      (const void*)k_qkeys,
+      (const void*)k_qgather,
+      (const void*)k_qcells,
+      (const void*)k_qtable_mode,
+      (const void*)k_qpacket_bounds,
+      (const void*)k_qlattice,
+      (const void*)k_push_cells};
+  hipFuncAttributes attr;
+  for (const void* f : fns) (void)hipFuncGetAttributes(&attr, f);
+  (void)hipGetLastError();
+}
+
 }  // namespace m2s

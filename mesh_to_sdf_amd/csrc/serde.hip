@@ -210,4 +210,8 @@ int launch_decode_points(hipStream_t st, const uint8_t* d_src, uint64_t n, float
   return 0;
 }
 
+// m2s_warmup: the first launch of a kernel of this translation unit makes the runtime load its code object (all its kernels).
+__global__ void k_warm_serde() {}
+void warm_serde(hipStream_t st) { hipLaunchKernelGGL(k_warm_serde, dim3(1), dim3(64), 0, st); }
+
 }  // namespace m2s

@@ -315,4 +315,19 @@ int build_grid_sign_plane(Arena& ws, hipStream_t st, const DeviceMesh& mesh, con
   return 0;
 }
 
+// m2s_warmup: the first launch of a kernel of this translation unit makes the runtime load its code object (all its kernels).
+__global__ void k_warm_sign() {}
+void warm_sign(hipStream_t st) {
+  hipLaunchKernelGGL(k_warm_sign, dim3(1), dim3(64), 0, st);
+  // ... and resolves a kernel FUNCTION at its own first launch (~0.3 ms each): ask for the attributes of the ones a first call uses
+  const void* fns[] = {
+      (const void*)k_ray_mark,
+      (const void*)k_ray_mark_big,
+      (const void*)k_scan_x,
+      (const void*)k_scan_y};
+  hipFuncAttributes attr;
+  for (const void* f : fns) (void)hipFuncGetAttributes(&attr, f);
+  (void)hipGetLastError();
+}
+
 }  // namespace m2s

@@ -15,6 +15,18 @@ static int fails = 0;
 int main(int argc, char** argv) {
   printf("m2s version %d, %d HIP device(s)\n", m2s_version(), m2s_device_count());
   if (m2s_device_count() < 1) { printf("no GPU: nothing to run\n"); return 77; }
+  {
+    /* m2s_warmup: optional, idempotent; the calls below then find runtime, code objects and context ready */
+    int w1 = m2s_warmup(-1, 0, 0), w2 = m2s_warmup(0, (size_t)1 << 20, (size_t)1 << 20);
+    uint64_t pb[5] = {0, 16, 32, 48, 64}, nb[5] = {0, 0, 0, 0, 0};
+    float cost[4] = {1.0f, 3.0f, 3.0f, 1.0f};
+    int rb;
+    CHECK(w1 == M2S_OK && w2 == M2S_OK, "m2s_warmup twice");
+    CHECK(m2s_warmup(1000, 0, 0) == M2S_ERR_BAD_ARG, "m2s_warmup on a device that does not exist -> M2S_ERR_BAD_ARG");
+    rb = m2s_balanced_slabs(64, 4, 4, pb, cost, nb);
+    CHECK(rb == M2S_OK && nb[0] == 0 && nb[4] == 64 && nb[1] > 16 && nb[2] == 32 && nb[3] < 48, "m2s_balanced_slabs moves the cuts towards the cheap ends (%d %d %d)",
+          (int)nb[1], (int)nb[2], (int)nb[3]);
+  }
 
   /* lib.rs:13-31 */
   const float vertices[9] = {0.f, 1.f, 0.f, 1.f, 2.f, 3.f, 1.f, 3.f, 4.f};
