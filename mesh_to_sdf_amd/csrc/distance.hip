@@ -334,7 +334,7 @@ __global__ __launch_bounds__(256) void k_packet(DeviceMesh mesh, GridParams g, c
                                                 int* __restrict__ err, uint32_t n_packets, uint32_t chunk,
                                                 const uint32_t* __restrict__ seed_in, uint32_t seed_shift,
                                                 uint32_t seed_ny, uint32_t seed_nz,
-                                                const GridParams* __restrict__ seed_lattice, CutList cut, PeerOut peers) {
+                                                const GridParams* __restrict__ seed_lattice, CutList cut, PeerOut peers, float mix_thr) {
   const int lane = threadIdx.x & 63;
   const uint32_t block = xcd_remap(blockIdx.x, chunk);
   const uint32_t packet = block * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -418,6 +418,9 @@ __global__ __launch_bounds__(256) void k_packet(DeviceMesh mesh, GridParams g, c
       eval_triangle<MODE>(best, p, tr);
     }
 
+    // M2S_MIX_CELLS (experiment): packets whose first voxel is nearer to its seed triangle than mix_thr are left to the lane walk
+    // (k_lane, launched beside this kernel with the complementary test)
+    if (GRID && mix_thr > 0.0f && __shfl(best.d2, 0) < mix_thr * mix_thr) return;
     float thr = prune_bound(best.d2, slack);
     if (STATS && GRID) {
       const float cells = __shfl(__builtin_amdgcn_sqrtf(best.d2), 0) / fabsf(g.size[0]);
@@ -780,7 +783,7 @@ template <int MODE, int SIGN>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(M2S_LANE_WAVES, 8))) void k_lane(DeviceMesh mesh, GridParams g, const uint32_t* __restrict__ plane,
                                               float* __restrict__ out, int* __restrict__ err, uint32_t n_packets,
                                               const uint32_t* __restrict__ seed_in, uint32_t seed_shift, uint32_t seed_ny, uint32_t seed_nz,
-                                              uint32_t bx_off, PeerOut peers, bool greedy) {
+                                              uint32_t bx_off, PeerOut peers, bool greedy, float mix_thr) {
   const int lane = threadIdx.x & 63;
   const uint32_t packet = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (packet >= n_packets) return;
@@ -798,6 +801,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(M2S_LANE_WA
     if (seed_in != nullptr)
       slot = min(seed_in[(((vox.bx + bx_off) >> seed_shift) * seed_ny + (vox.by >> seed_shift)) * seed_nz + (vox.bz >> seed_shift)], mesh.n_tris - 1);
     eval_triangle<MODE>(best, p, mesh.tris[slot]);
+    if (mix_thr > 0.0f && !(__shfl(best.d2, 0) < mix_thr * mix_thr)) return;   // M2S_MIX_CELLS: this packet belongs to k_packet
     if (greedy) greedy_leaf<MODE>(mesh, p, best);
     uint32_t st_nodes = 0, st_exact = 0;               // M2S_STATS
     __shared__ LaneShare lane_share[4];                // one per wave of the workgroup
@@ -1385,7 +1389,7 @@ void launch_packet(hipStream_t st, const DeviceMesh& mesh, const GridParams& g, 
                    uint32_t n_q, const uint32_t* plane, float* out, int* err, uint32_t n_packets,
                    const uint32_t* seed_in = nullptr, uint32_t seed_shift = 0, uint32_t seed_ny = 0,
                    uint32_t seed_nz = 0, const GridParams* seed_lattice = nullptr, CutList cut = {nullptr, 0, 0, 0, 0, nullptr},
-                   const PeerOut* peers_in = nullptr) {
+                   const PeerOut* peers_in = nullptr, float mix_thr = 0.0f) {
   PeerOut peers{};
   if (peers_in) peers = *peers_in;
   static const uint32_t wpb = getenv("M2S_WPB") ? std::min(4u, std::max(1u, (uint32_t)atoi(getenv("M2S_WPB")))) : 1u;   // waves (packets) per workgroup: single-wave groups free their slot as soon as the walk ends (4 -> 1: -3.8 %)
@@ -1402,21 +1406,21 @@ void launch_packet(hipStream_t st, const DeviceMesh& mesh, const GridParams& g, 
     const uint32_t code = 0x80000000u | run_log;
     if (mesh.stats != nullptr)
       hipLaunchKernelGGL((k_packet<GRID, MODE, SIGN, true>), dim3(grid_blocks), dim3(64 * wpb), 0, st, mesh, g,
-                         qs, perm, n_q, plane, out, err, n_packets, code, seed_in, seed_shift, seed_ny, seed_nz, seed_lattice, cut, peers);
+                         qs, perm, n_q, plane, out, err, n_packets, code, seed_in, seed_shift, seed_ny, seed_nz, seed_lattice, cut, peers, mix_thr);
     else if (GRID && MODE == MODE_UNSIGNED && SIGN == SIGN_GRID_PLANE && getenv("M2S_LDS_STAGE") && atoi(getenv("M2S_LDS_STAGE")) != 0)
       hipLaunchKernelGGL((k_packet<GRID, MODE_UNSIGNED, SIGN_GRID_PLANE, false, true>), dim3(grid_blocks), dim3(64 * wpb), wpb * STAGE_CAP, st, mesh, g,
-                         qs, perm, n_q, plane, out, err, n_packets, code, seed_in, seed_shift, seed_ny, seed_nz, seed_lattice, cut, peers);
+                         qs, perm, n_q, plane, out, err, n_packets, code, seed_in, seed_shift, seed_ny, seed_nz, seed_lattice, cut, peers, mix_thr);
     else
       hipLaunchKernelGGL((k_packet<GRID, MODE, SIGN, false>), dim3(grid_blocks), dim3(64 * wpb), 0, st, mesh, g,
-                         qs, perm, n_q, plane, out, err, n_packets, code, seed_in, seed_shift, seed_ny, seed_nz, seed_lattice, cut, peers);
+                         qs, perm, n_q, plane, out, err, n_packets, code, seed_in, seed_shift, seed_ny, seed_nz, seed_lattice, cut, peers, mix_thr);
     return;
   }
   if (mesh.stats != nullptr)   // M2S_STATS: the counting variant (a few SALU ops more per node)
     hipLaunchKernelGGL((k_packet<GRID, MODE, SIGN, true>), dim3(remap ? chunk * 8 : blocks), dim3(64 * wpb), 0, st, mesh, g,
-                       qs, perm, n_q, plane, out, err, n_packets, chunk, seed_in, seed_shift, seed_ny, seed_nz, seed_lattice, cut, peers);
+                       qs, perm, n_q, plane, out, err, n_packets, chunk, seed_in, seed_shift, seed_ny, seed_nz, seed_lattice, cut, peers, mix_thr);
   else
     hipLaunchKernelGGL((k_packet<GRID, MODE, SIGN, false>), dim3(remap ? chunk * 8 : blocks), dim3(64 * wpb), 0, st, mesh, g,
-                       qs, perm, n_q, plane, out, err, n_packets, chunk, seed_in, seed_shift, seed_ny, seed_nz, seed_lattice, cut, peers);
+                       qs, perm, n_q, plane, out, err, n_packets, chunk, seed_in, seed_shift, seed_ny, seed_nz, seed_lattice, cut, peers, mix_thr);
 }
 template <bool GRID, int MODE, int SIGN>
 void launch_brute(hipStream_t st, const DeviceMesh& mesh, const GridParams& g, const float* q, uint32_t n_q,
@@ -1638,17 +1642,22 @@ int launch_grid_walk(hipStream_t st, const DeviceMesh& mesh, const GridParams& g
     const unsigned blocks = (packets + 3) / 4;
     const bool lane_greedy = getenv("M2S_LANE_GREEDY") ? atoi(getenv("M2S_LANE_GREEDY")) != 0 : true;
     if (mode == MODE_UNSIGNED && d_inside_plane)
-      hipLaunchKernelGGL((k_lane<MODE_UNSIGNED, SIGN_GRID_PLANE>), dim3(blocks), dim3(256), 0, st, mesh, g, d_inside_plane, d_out, d_err, packets, seed1, sh1, s1ny, s1nz, bx_off, pz, lane_greedy);
+      hipLaunchKernelGGL((k_lane<MODE_UNSIGNED, SIGN_GRID_PLANE>), dim3(blocks), dim3(256), 0, st, mesh, g, d_inside_plane, d_out, d_err, packets, seed1, sh1, s1ny, s1nz, bx_off, pz, lane_greedy, 0.0f);
     else if (mode == MODE_UNSIGNED)
-      hipLaunchKernelGGL((k_lane<MODE_UNSIGNED, SIGN_NONE>), dim3(blocks), dim3(256), 0, st, mesh, g, nullptr, d_out, d_err, packets, seed1, sh1, s1ny, s1nz, bx_off, pz, lane_greedy);
+      hipLaunchKernelGGL((k_lane<MODE_UNSIGNED, SIGN_NONE>), dim3(blocks), dim3(256), 0, st, mesh, g, nullptr, d_out, d_err, packets, seed1, sh1, s1ny, s1nz, bx_off, pz, lane_greedy, 0.0f);
     else
-      hipLaunchKernelGGL((k_lane<MODE_NORMAL_FOLD, SIGN_NONE>), dim3(blocks), dim3(256), 0, st, mesh, g, nullptr, d_out, d_err, packets, seed1, sh1, s1ny, s1nz, bx_off, pz, lane_greedy);
+      hipLaunchKernelGGL((k_lane<MODE_NORMAL_FOLD, SIGN_NONE>), dim3(blocks), dim3(256), 0, st, mesh, g, nullptr, d_out, d_err, packets, seed1, sh1, s1ny, s1nz, bx_off, pz, lane_greedy, 0.0f);
     M2S_HIP_CHECK(hipGetLastError());
     return 0;
   }
+  // M2S_MIX_CELLS=c (experiment): the packets within c cells of their seed triangle walk lane by lane (k_lane), the others together
+  const float mix_cells = getenv("M2S_MIX_CELLS") ? (float)atof(getenv("M2S_MIX_CELLS")) : 0.0f;
+  const float mix_thr = mix_cells > 0.0f && seed1 != nullptr && !brute && pz.n == 0 && pz.progress == nullptr ? mix_cells * fabsf(g.size[0]) : 0.0f;
+  if (mix_thr > 0.0f && mode == MODE_UNSIGNED && d_inside_plane)
+    hipLaunchKernelGGL((k_lane<MODE_UNSIGNED, SIGN_GRID_PLANE>), dim3((packets + 3) / 4), dim3(256), 0, st, mesh, g, d_inside_plane, d_out, d_err, packets, seed1, sh1, s1ny, s1nz, bx_off, pz, true, mix_thr);
   if (mode == MODE_UNSIGNED && d_inside_plane) {
     if (brute) launch_brute<true, MODE_UNSIGNED, SIGN_GRID_PLANE>(st, mesh, g, nullptr, 0, d_inside_plane, d_out, d_err, packets, peers);
-    else launch_packet<true, MODE_UNSIGNED, SIGN_GRID_PLANE>(st, mesh, g, nullptr, nullptr, 0, d_inside_plane, d_out, d_err, packets, seed1, sh1, s1ny, s1nz, nullptr, cut, peers);
+    else launch_packet<true, MODE_UNSIGNED, SIGN_GRID_PLANE>(st, mesh, g, nullptr, nullptr, 0, d_inside_plane, d_out, d_err, packets, seed1, sh1, s1ny, s1nz, nullptr, cut, peers, mix_thr);
   } else if (mode == MODE_UNSIGNED) {
     if (brute) launch_brute<true, MODE_UNSIGNED, SIGN_NONE>(st, mesh, g, nullptr, 0, nullptr, d_out, d_err, packets, peers);
     else launch_packet<true, MODE_UNSIGNED, SIGN_NONE>(st, mesh, g, nullptr, nullptr, 0, nullptr, d_out, d_err, packets, seed1, sh1, s1ny, s1nz, nullptr, cut, peers);
