@@ -160,7 +160,11 @@ int m2s_generate_sdf(const float* vertices, size_t n_vertices, const void* indic
                      int topology, const float* queries, size_t n_queries, int accel, int sign_method, float* out,
                      size_t* n_out, const m2s_opts* opts);
 
-/* generate_grid_sdf — generate/grid.rs:265-378.  out: cell_count[0]*[1]*[2] f32, caller owned. */
+/* generate_grid_sdf — generate/grid.rs:265-378.  out: cell_count[0]*[1]*[2] f32, caller owned.
+ * Semantics: the EXACT minimum over all triangles (what generate/grid.rs:693-724 asserts the grid path to equal).  SURVEY.md §8(b)
+ * sketched a `semantics` argument selecting the reference's label propagation (generate/grid.rs:495-558) instead; it is
+ * deliberately absent: that output depends on rayon::current_num_threads(), is never below the exact minimum and exceeds it on
+ * 0.03 % (512^3) to 59 % (1 M triangles in 128^3) of the cells — there is no one result to reproduce. */
 int m2s_generate_grid_sdf(const float* vertices, size_t n_vertices, const void* indices, size_t n_indices,
                           int index_bytes, int topology, const m2s_grid* grid, int sign_method, float* out,
                           const m2s_opts* opts);

@@ -283,7 +283,16 @@ __device__ __forceinline__ uint32_t stab_count(const DeviceMesh& mesh, f3 p) {
 #ifndef M2S_CUT_MAX
 #define M2S_CUT_MAX 15   // 7: 12.0 ms, 15: 11.7 ms (512^3 x blob-100k)
 #endif
-constexpr uint32_t CUT_MAX = M2S_CUT_MAX, CUT_WORDS = 2 * (M2S_CUT_MAX + 1);   // [0] = number of ranges, then (start, end) pairs
+// A list is ONE 64-byte record (round 2: 128 B of (start, end) byte offsets — 268 MB of lists for a 537 MB output):
+//   word 0        number of ranges
+//   word 1 + k    [25:0] start of range k (node record index), [31:26] its length: code c < 48 = c + 1 records exactly,
+//                 48 <= c < 63 = 64 << (c - 48) records (rounded up), 63 = to the end of the tree
+// Short ranges — the subtrees of a few triangles that make up almost every list — are exact; a long one (the last range of a
+// saturated list) may come out up to twice as long, a superset a walk may always take; a range that then reaches into the next
+// one is cut at the next one's start by the walk.  k_cut writes a word when its range closes, as before (ranges kept in LDS or
+// scratch until the end and written as one record cost k_cut 20-35 %: five waves per SIMD, or scratch traffic).
+constexpr uint32_t CUT_MAX = M2S_CUT_MAX, CUT_WORDS = M2S_CUT_MAX + 1;
+static_assert(M2S_CUT_MAX <= 15, "the range count has four bits");
 struct CutList {
   const uint32_t* lists;   // CUT_WORDS words per block, nullptr: walk the whole tree
   uint32_t log, ny, nz;    // bricks per block per axis = 2^log; blocks along y and z
@@ -378,7 +387,7 @@ __global__ __launch_bounds__(256) void k_packet(DeviceMesh mesh, GridParams g, c
       const uint32_t cb = GRID ? __builtin_amdgcn_readfirstlane((((vox.bx + cut.bx_off) >> cut.log) * cut.ny + (vox.by >> cut.log)) * cut.nz + (vox.bz >> cut.log))
                                : packet;
       cl = cut.lists + (size_t)cb * CUT_WORDS;
-      n_ranges = cl[0] + cl[CUT_WORDS - 1];   // the last word is always 0 (k_cut): it only pulls the second line in
+      n_ranges = cl[0];
     }
     if (seed_in != nullptr) {
       // seed: a triangle near this packet's centre, from the seed pass
@@ -435,9 +444,13 @@ __global__ __launch_bounds__(256) void k_packet(DeviceMesh mesh, GridParams g, c
     // the offset operand directly and the loop carries no address arithmetic.
     constexpr uint32_t NB = (uint32_t)sizeof(NodeExt);
     if (STATS) st_ranges = n_ranges;
+    uint32_t cut_done = 0;                                                      // end of the previous range (byte offset)
     for (uint32_t range = 0; range < n_ranges; ++range) {
-    uint32_t off = cl ? cl[1 + 2 * range] : 0u;
-    const uint32_t end = cl ? cl[2 + 2 * range] : mesh.n_nodes * NB;
+    const uint32_t cut_word = cl ? cl[1 + range] : 0u, cut_code = cut_word >> 26;
+    const uint32_t cut_len = cut_code < 48u ? cut_code + 1u : (cut_code == 63u ? mesh.n_nodes : 64u << (cut_code - 48u));
+    uint32_t off = cl ? max((cut_word & 0x3ffffffu) * NB, cut_done) : 0u;
+    const uint32_t end = cl ? min((cut_word & 0x3ffffffu) + cut_len, mesh.n_nodes) * NB : mesh.n_nodes * NB;
+    cut_done = end;
     if (STATS) { st_rbytes += end - off; st_rmax = max(st_rmax, end - off); }
     extern __shared__ float4 stage_lds[];
     const uint32_t stage_base = off;
@@ -1021,6 +1034,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(M2S_LANE_WA
 // GRID = false (generic queries): "brick" = packet of sorted queries, lane = packet, 64 consecutive packets (neighbours in
 // the Morton order) per wave; centre and radius from `centres` (k_qpacket_bounds), the seed from the lattice cell of the
 // centre (as k_packet<false> does), `nbx` = the number of wave slots the packet walk was launched with.
+constexpr uint32_t NB_CUT = (uint32_t)sizeof(NodeExt);
 template <bool GRID>
 __global__ __launch_bounds__(64) void k_cut(DeviceMesh mesh, GridParams g, const uint32_t* __restrict__ seeds, uint32_t seed_shift,
                                             uint32_t seed_ny, uint32_t seed_nz, uint32_t nbx, uint32_t nby, uint32_t nbz,
@@ -1084,6 +1098,11 @@ __global__ __launch_bounds__(64) void k_cut(DeviceMesh mesh, GridParams g, const
   constexpr uint32_t NB = (uint32_t)sizeof(NodeExt);
   const uint32_t end = mesh.n_nodes * NB;
   uint32_t* out = lists + ((size_t)(in_grid ? (GRID ? (bk[0] * nby + bk[1]) * nbz + bk[2] : pk) : 0u)) * CUT_WORDS;
+  auto cut_word = [](uint32_t start, uint32_t stop) {      // byte offsets -> list word (see CUT_WORDS)
+    const uint32_t len = (stop - start) / NB_CUT;
+    const uint32_t code = len <= 48u ? len - 1u : min(63u, 48u + (32u - (uint32_t)__clz((int)((len + 63u) / 64u - 1u))));
+    return (start / NB_CUT) | (code << 26);
+  };
   uint32_t n = 0, last_start = 0, last_end = 0, resume = 0, opened = 0;   // per lane
   uint32_t off = 0, steps = 0;                                // wave-uniform
   while (off < end) {
@@ -1130,7 +1149,7 @@ __global__ __launch_bounds__(64) void k_cut(DeviceMesh mesh, GridParams g, const
       // keep this subtree: [off, skip).  Adjacent subtrees merge; past CUT_MAX ranges the last one grows over the gap
       if (n > 0 && (last_end == off || n == CUT_MAX)) last_end = nr.skip;
       else {
-        if (n > 0) { out[1 + 2 * (n - 1)] = last_start; out[2 + 2 * (n - 1)] = last_end; }
+        if (n > 0) out[n] = cut_word(last_start, last_end);
         ++n; last_start = off; last_end = nr.skip;
       }
     }
@@ -1140,10 +1159,8 @@ __global__ __launch_bounds__(64) void k_cut(DeviceMesh mesh, GridParams g, const
   }
   if (!in_grid) return;
   if (n == 0) { n = 1; last_start = 0; last_end = end; }    // cannot happen with finite input; never walk nothing
-  out[1 + 2 * (n - 1)] = last_start;
-  out[2 + 2 * (n - 1)] = last_end;
+  out[n] = cut_word(last_start, last_end);
   out[0] = n;
-  out[CUT_WORDS - 1] = 0;   // unused word in the list's second cache line, read by k_packet to prefetch that line
 }
 
 // ---- k_brute --------------------------------------------------------------------------------
