@@ -7,7 +7,7 @@ OUT=$PWD/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 python bench.py --steps 20 --warmup 3 > $OUT/bench.json 2> $OUT/bench.err
-BENCH="python $PWD/bench.py --steps 6 --warmup 1 --no-cpu-baseline"
+BENCH="python $PWD/bench.py --steps 6 --warmup 1 --no-cpu-baseline --no-live-pmc"
 ( cd /tmp && rocprofv3 --kernel-trace --stats -d $OUT/trace -o t -- $BENCH > $OUT/trace.log 2>&1 )
 DB=$(find $OUT/trace -name "*.db" | head -1)
 python tools/rocpd_summary.py $DB > $OUT/kernel_stats.md 2>> $OUT/trace.log
