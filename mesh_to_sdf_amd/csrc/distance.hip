@@ -285,12 +285,31 @@ __device__ __forceinline__ uint32_t stab_count(const DeviceMesh& mesh, f3 p) {
 #endif
 // A list is ONE 64-byte record (round 2: 128 B of (start, end) byte offsets — 268 MB of lists for a 537 MB output):
 //   word 0        number of ranges
-//   word 1 + k    [25:0] start of range k (node record index), [31:26] its length: code c < 48 = c + 1 records exactly,
-//                 48 <= c < 63 = 64 << (c - 48) records (rounded up), 63 = to the end of the tree
-// Short ranges — the subtrees of a few triangles that make up almost every list — are exact; a long one (the last range of a
-// saturated list) may come out up to twice as long, a superset a walk may always take; a range that then reaches into the next
-// one is cut at the next one's start by the walk.  k_cut writes a word when its range closes, as before (ranges kept in LDS or
-// scratch until the end and written as one record cost k_cut 20-35 %: five waves per SIMD, or scratch traffic).
+//   word 1 + k    low S bits: start of range k (node record index), S = bits needed for the tree's node count; the other 32 - S bits:
+//                 its length as a small float — 5 bits of exponent e, M = 27 - S bits of mantissa m: e = 0 means m + 1 records,
+//                 e >= 1 means (2^M + m) << (e - 1), the smallest such value that is >= the true length
+// Lengths up to 2^(M+1) records are exact and longer ones exceed the truth by less than 2^-M (100 k triangles: M = 9, 0.2 %; 1 M: M = 6,
+// 1.6 %; the 2^25-triangle limit: M = 1): a superset of the subtrees, which a walk may always take, and one that hardly costs — a first
+// form with 6-bit power-of-two lengths walked up to twice a long range: 14 % more node tests and 4.8 % more time on 512^3 x blob-1M
+// (same box: 26.60 against 25.37 ms; the headline 8.40 against 8.43 ms).  A range that
+// reaches into the next one is cut at the next one's start by the walk.  k_cut writes a word when its range closes, as before (ranges
+// kept in LDS or scratch until the end and written as one record cost k_cut 20-35 %: five waves per SIMD, or scratch traffic).
+__host__ __device__ __forceinline__ uint32_t cut_start_bits(uint32_t n_nodes) {
+  uint32_t b = 1;
+  while (b < 27u && (1u << b) < n_nodes) ++b;
+  return b;
+}
+__device__ __forceinline__ uint32_t cut_decode_len(uint32_t code, uint32_t M) {
+  const uint32_t e = code >> M, m = code & ((1u << M) - 1u);
+  return e == 0u ? m + 1u : ((1u << M) + m) << (e - 1u);
+}
+__device__ __forceinline__ uint32_t cut_encode_len(uint32_t len, uint32_t M) {          // smallest representable value >= len (len >= 1)
+  if (len <= (1u << M)) return len - 1u;
+  uint32_t sh = (32u - (uint32_t)__clz((int)len)) - (M + 1u);                            // len >> sh lies in [2^M, 2^(M+1))
+  uint32_t mant = (len + (1u << sh) - 1u) >> sh;
+  if (mant == (2u << M)) { mant = 1u << M; ++sh; }
+  return ((sh + 1u) << M) | (mant - (1u << M));
+}
 constexpr uint32_t CUT_MAX = M2S_CUT_MAX, CUT_WORDS = M2S_CUT_MAX + 1;
 static_assert(M2S_CUT_MAX <= 15, "the range count has four bits");
 struct CutList {
@@ -445,11 +464,12 @@ __global__ __launch_bounds__(256) void k_packet(DeviceMesh mesh, GridParams g, c
     constexpr uint32_t NB = (uint32_t)sizeof(NodeExt);
     if (STATS) st_ranges = n_ranges;
     uint32_t cut_done = 0;                                                      // end of the previous range (byte offset)
+    const uint32_t cut_S = cut_start_bits(mesh.n_nodes);
     for (uint32_t range = 0; range < n_ranges; ++range) {
-    const uint32_t cut_word = cl ? cl[1 + range] : 0u, cut_code = cut_word >> 26;
-    const uint32_t cut_len = cut_code < 48u ? cut_code + 1u : (cut_code == 63u ? mesh.n_nodes : 64u << (cut_code - 48u));
-    uint32_t off = cl ? max((cut_word & 0x3ffffffu) * NB, cut_done) : 0u;
-    const uint32_t end = cl ? min((cut_word & 0x3ffffffu) + cut_len, mesh.n_nodes) * NB : mesh.n_nodes * NB;
+    const uint32_t cut_word = cl ? cl[1 + range] : 0u, cut_first = cut_word & ((1u << cut_S) - 1u);
+    const uint32_t cut_len = cut_decode_len(cut_word >> cut_S, 27u - cut_S);
+    uint32_t off = cl ? max(cut_first * NB, cut_done) : 0u;
+    const uint32_t end = cl ? (uint32_t)min((unsigned long long)cut_first + cut_len, (unsigned long long)mesh.n_nodes) * NB : mesh.n_nodes * NB;
     cut_done = end;
     if (STATS) { st_rbytes += end - off; st_rmax = max(st_rmax, end - off); }
     extern __shared__ float4 stage_lds[];
@@ -1098,10 +1118,9 @@ __global__ __launch_bounds__(64) void k_cut(DeviceMesh mesh, GridParams g, const
   constexpr uint32_t NB = (uint32_t)sizeof(NodeExt);
   const uint32_t end = mesh.n_nodes * NB;
   uint32_t* out = lists + ((size_t)(in_grid ? (GRID ? (bk[0] * nby + bk[1]) * nbz + bk[2] : pk) : 0u)) * CUT_WORDS;
-  auto cut_word = [](uint32_t start, uint32_t stop) {      // byte offsets -> list word (see CUT_WORDS)
-    const uint32_t len = (stop - start) / NB_CUT;
-    const uint32_t code = len <= 48u ? len - 1u : min(63u, 48u + (32u - (uint32_t)__clz((int)((len + 63u) / 64u - 1u))));
-    return (start / NB_CUT) | (code << 26);
+  const uint32_t cut_S = cut_start_bits(mesh.n_nodes);
+  auto cut_word = [cut_S](uint32_t start, uint32_t stop) {   // byte offsets -> list word (see CUT_WORDS)
+    return (start / NB_CUT) | (cut_encode_len((stop - start) / NB_CUT, 27u - cut_S) << cut_S);
   };
   uint32_t n = 0, last_start = 0, last_end = 0, resume = 0, opened = 0;   // per lane
   uint32_t off = 0, steps = 0;                                // wave-uniform

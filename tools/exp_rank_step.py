@@ -26,7 +26,7 @@ def main():
     ap.add_argument("--modes", default="none,trail,push,store")
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--ranks", default="")
-    ap.add_argument("--partition", default="contiguous", choices=["contiguous", "interleaved", "adaptive"])
+    ap.add_argument("--partition", default="contiguous", choices=["contiguous", "interleaved", "interleaved4", "adaptive"])
     ap.add_argument("--adapt-rounds", type=int, default=4, help="adaptive: rounds of (all ranks measured alone, slabs re-cut by m2s_balanced_slabs)")
     args = ap.parse_args()
     import torch
@@ -59,7 +59,7 @@ def main():
           f"seed+cut {t.seed_ms:.3f} distance {t.distance_ms:.3f} total {t.total_ms:.3f}")
     for world in [int(w) for w in args.world.split(",")]:
         peers = [torch.empty(n ** 3, dtype=torch.float32, device="cuda") for _ in range(world - 1)]
-        ranks = [int(r) for r in args.ranks.split(",")] if args.ranks else (list(range(world)) if args.partition == "interleaved" else sorted({0, world // 2 - 1, world // 2, world - 1}))
+        ranks = [int(r) for r in args.ranks.split(",")] if args.ranks else (list(range(world)) if args.partition.startswith("interleaved") else sorted({0, world // 2 - 1, world // 2, world - 1}))
         if args.partition == "adaptive":
             # what M2S_PART_ADAPTIVE / the bench's adaptive slabs converge to: every round measures all ranks (alone, no delivery)
             # and re-cuts the slabs from their device times without the build
@@ -82,6 +82,9 @@ def main():
                 if args.partition == "interleaved":
                     a, b, period = interleaved_slab(grid, world, r)
                     xs = (a, b)
+                if args.partition == "interleaved4":       # four chunks per rank: chunk r of every quarter of the grid
+                    c = n // (4 * world)
+                    xs, period = (r * c, (r + 1) * c), world * c
                 kw = {} if mode == "none" else {"peer_out": peers, "peer_mode": {"push": PeerMode.Push, "store": PeerMode.Store, "trail": PeerMode.Trail}[mode]}
                 t = M2STimings()
                 med, mn = timed(lambda: generate_grid_sdf(dv, topo, grid, sign, x_slab=xs, x_period=period, out=out, timings=t, **kw))
