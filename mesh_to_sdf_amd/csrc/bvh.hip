@@ -1188,7 +1188,7 @@ size_t bvh_workspace_bytes(size_t n_tris) {
 
 int build_device_mesh(Arena& ws, hipStream_t st, const float* d_verts, size_t n_verts, const void* d_indices,
                       size_t n_indices, int index_bytes, int topology, size_t n_tris, int* d_err, DeviceMesh* out,
-                      const std::function<int(const float4*, const TriRec*, int)>* after_setup) {
+                      const std::function<int(const float4*, const TriRec*, int)>* after_setup, bool records_only) {
   (void)n_indices;
   out->cen_raw = nullptr;
   out->slot_of = nullptr;
@@ -1247,6 +1247,16 @@ int build_device_mesh(Arena& ws, hipStream_t st, const float* d_verts, size_t n_
 
   const unsigned B = 256;
   static const uint32_t leaf_max = getenv("M2S_LEAF_MAX") ? std::max(1u, (uint32_t)atoi(getenv("M2S_LEAF_MAX"))) : 2u;
+  if (records_only) {
+    // a tiny problem (grid_is_tiny): all voxels x all triangles needs the triangle records and nothing else — no keys, no sort, no tree
+    hipLaunchKernelGGL(k_tri_setup, dim3(cdiv(n_tris, B)), dim3(B), 0, st, d_verts, (uint32_t)n_verts, d_indices,
+                       index_bytes, topology, (uint32_t)n_tris, raw, boxes, cen_raw, scene, 8, d_err);
+    M2S_HIP_CHECK(hipGetLastError());
+    out->cen_raw = cen_raw;
+    out->tris = raw;
+    out->n_nodes = 0;
+    return 0;
+  }
   if (lean) {
     hipLaunchKernelGGL(k_tri_setup, dim3(cdiv(n_tris, B)), dim3(B), 0, st, d_verts, (uint32_t)n_verts, d_indices,
                        index_bytes, topology, (uint32_t)n_tris, raw, boxes, cen_raw, scene, 8, d_err);

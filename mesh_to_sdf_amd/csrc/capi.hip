@@ -442,7 +442,7 @@ int run_grid_distance_trail(Arena& ws, const CallCtx& c, DeviceState& st, const 
   st.have_raw_seeds = false;
   if (rc) return rc;
   const uint64_t row = (uint64_t)g.n[1] * g.n[2];
-  const bool trailing = !plan.lane_walk && c.algorithm == 0 && mesh.n_nodes != 0 && g.chunk_log >= 31u;   // k_packet counts its packets; the other walks do not
+  const bool trailing = !plan.lane_walk && plan.brute_acc == nullptr && c.algorithm == 0 && mesh.n_nodes != 0 && g.chunk_log >= 31u;   // k_packet counts its packets; the other walks do not
   PeerOut walk_peers{};
   if (trailing) {
     const size_t counters = (size_t)trail_units(g) * (trail_rows(g) + 1u);
@@ -983,7 +983,9 @@ int m2s_generate_grid_sdf(const float* vertices, size_t n_vertices, const void* 
   const uint32_t* plane = nullptr;
   st->early_planes = false;
   static const bool early_sign = !(getenv("M2S_EARLY_SIGN") && atoi(getenv("M2S_EARLY_SIGN")) == 0);
-  const bool beside = seed_overlap && c.algorithm == 0 && !getenv("M2S_STATS") && grid_walk_wants_seeds(g, n_tris, c.algorithm);
+  // tiny problems (cells x triangles small): all voxels against all triangles, no tree (distance.hip k_brute_split)
+  const bool tiny = grid_is_tiny(g, n_tris, c.algorithm) && !getenv("M2S_STATS");
+  const bool beside = !tiny && seed_overlap && c.algorithm == 0 && !getenv("M2S_STATS") && grid_walk_wants_seeds(g, n_tris, c.algorithm);
   const std::function<int(const float4*, const TriRec*, int)> seeds_beside_build = [&](const float4* cen_raw, const TriRec* raw, int phase) -> int {
     if (!side_stream_wanted(c.sync)) return 0;               // no side stream for this call: seeds as part of the walk's preparation
     if (phase == 0) {                                        // the centroid / record kernels are enqueued: mark that point
@@ -1029,7 +1031,7 @@ int m2s_generate_grid_sdf(const float* vertices, size_t n_vertices, const void* 
     return 0;
   };
   rc = build_device_mesh(ws, c.stream, sm.d_verts, n_vertices, sm.d_indices, n_indices, index_bytes, topology, n_tris, d_err, &mesh,
-                         &seeds_beside_build);
+                         &seeds_beside_build, tiny);
   if (rc) return rc;
   hc.lap("build enqueued (code objects on a first call)");
   M2S_HIP_CHECK(hipEventRecord(st->ev[1], c.stream));

@@ -225,7 +225,7 @@ size_t bvh_workspace_bytes(size_t n_tris);
 // (enqueue the side work — the seed passes — on another stream behind that event; bvh.hip says why there).
 int build_device_mesh(Arena& ws, hipStream_t st, const float* d_verts, size_t n_verts, const void* d_indices,
                       size_t n_indices, int index_bytes, int topology, size_t n_tris, int* d_err, DeviceMesh* out,
-                      const std::function<int(const float4*, const TriRec*, int)>* after_setup = nullptr);
+                      const std::function<int(const float4*, const TriRec*, int)>* after_setup = nullptr, bool records_only = false);
 
 // sign.hip: grid-line ray parity -> one "inside" bit per voxel (bit plane in grid layout).
 size_t sign_workspace_bytes(const GridParams& g, size_t n_tris);
@@ -241,7 +241,9 @@ struct GridWalkPlan {
   const uint32_t* cut_lists = nullptr;
   uint32_t cut_log = 0, cut_ny = 0, cut_nz = 0;
   bool lane_walk = false;
+  uint32_t* brute_acc = nullptr;   // tiny problems (grid_is_tiny): per-voxel minima of k_brute_split; no seeds, no lists, no tree
 };
+bool grid_is_tiny(const GridParams& g, size_t n_tris, int algorithm);
 // Seed lattice of a slab: one triangle id per packet brick (ids index the centroid array it was computed from).
 struct SeedLattice {
   uint32_t* ids = nullptr;

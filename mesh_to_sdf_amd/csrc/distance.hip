@@ -114,6 +114,24 @@ __device__ __forceinline__ uint32_t grid_brick_count(const GridParams& g) {
   return bricks_along(g.xe - g.xb, g.bl[0]) * bricks_along(g.n[1], g.bl[1]) * bricks_along(g.n[2], g.bl[2]);
 }
 
+// Bricks in plain z-y-x order, no padding to super-bricks (k_brute_split: every packet costs the same, order is irrelevant).
+__device__ __forceinline__ GridBrick grid_lane_voxel_plain(const GridParams& g, uint32_t brick, int lane) {
+  const uint32_t nby = bricks_along(g.n[1], g.bl[1]), nbz = bricks_along(g.n[2], g.bl[2]);
+  const uint32_t bz = brick % nbz, t = brick / nbz, by = t % nby, bx = t / nby;
+  GridBrick v;
+  const uint32_t lx = g.bl[0], ly = g.bl[1], lz = g.bl[2], l = (uint32_t)lane;
+  const uint32_t layers = g.xe - g.xb, xv = (bx << lx) + (l >> (ly + lz));
+  v.y = (by << ly) + ((l >> lz) & ((1u << ly) - 1u));
+  v.z = (bz << lz) + (l & ((1u << lz) - 1u));
+  v.in_range = xv < layers && v.y < g.n[1] && v.z < g.n[2];
+  v.brick_in_grid = true;
+  v.bx = bx; v.by = by; v.bz = bz;
+  v.x = slab_x(g, min(xv, layers - 1u));
+  v.y = min(v.y, g.n[1] - 1);
+  v.z = min(v.z, g.n[2] - 1);
+  return v;
+}
+
 // XCD-aware work order: the dispatcher places block b on XCD b % 8.  Each XCD works through runs of consecutive
 // packets (its private L2 keeps seeing the same part of the BVH), and the runs are dealt out round-robin:
 // chunk has bit 31 set: interleaved mode — XCD x takes the runs x, x+8, x+16, ... of 2^run_log blocks (run_log in
@@ -1258,6 +1276,72 @@ __global__ __launch_bounds__(256) void k_brute(DeviceMesh mesh, GridParams g, co
     for (uint32_t i = 0; i < peers.n; ++i) peers.p[i][out_index + (size_t)g.out_off] = result;
 }
 
+// ---- k_brute_split: tiny problems without a tree -------------------------------------------------------------------
+// The reference's own criterion shapes include a 16^3 grid over an 11 k-triangle mesh (benches/generate_grid_sdf.rs:8-34): 4 096
+// voxels are 64 waves, each lane walks the tree alone, and the call lasts as long as its slowest lane's chain of dependent loads
+// (0.7 ms) on top of a 0.17 ms build.  All voxels x all triangles is only 46 M evaluations there — 0.1 ms if the whole chip takes
+// part, and no tree is needed at all.  k_brute gives a block ALL triangles (16 blocks for 16^3); here the triangles are cut into
+// chunks as well: block (x, y) evaluates voxel block x against triangle chunk y and folds its minima into per-voxel words with
+// atomic minima (non-negative floats order like their bit patterns; min is associative and commutative: bit-identical to k_brute
+// and to every walk), k_brute_finish turns them into signed distances.  Chosen for cells x triangles <= M2S_BRUTE_MAX.
+template <int MODE>
+__global__ __launch_bounds__(256) void k_brute_split(DeviceMesh mesh, GridParams g, uint32_t* __restrict__ acc, int* __restrict__ err,
+                                                     uint32_t n_packets, uint32_t tiles_per_chunk) {
+  __shared__ TriRec tile[TILE];
+  const int lane = threadIdx.x & 63;
+  const uint32_t packet = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const bool active = packet < n_packets;
+  f3 p = {0, 0, 0};
+  bool store = false;
+  if (active) {
+    const GridBrick vox = grid_lane_voxel_plain(g, packet, lane);
+    p = grid_point(g, vox);
+    store = vox.in_range;
+  }
+  Best<MODE> best;
+  const uint32_t t_begin = blockIdx.y * tiles_per_chunk * TILE, t_end = min(mesh.n_tris, t_begin + tiles_per_chunk * TILE);
+  for (uint32_t t0 = t_begin; t0 < t_end; t0 += TILE) {
+    const uint32_t nt = min((uint32_t)TILE, t_end - t0);
+    __syncthreads();
+    {
+      const float4* src = reinterpret_cast<const float4*>(mesh.tris + t0);
+      float4* dst = reinterpret_cast<float4*>(tile);
+      for (uint32_t i = threadIdx.x; i < nt * 6; i += 256) dst[i] = src[i];
+    }
+    __syncthreads();
+    for (uint32_t k = 0; k < nt; ++k) eval_triangle<MODE>(best, p, tile[k]);
+  }
+  if (!active || !store) return;
+  const size_t slot = ((size_t)packet * 64u + lane) * 2u;
+  atomicMin(&acc[slot], __float_as_uint(best.d2));
+  if (MODE == MODE_NORMAL_FOLD) {
+    atomicMin(&acc[slot + 1], __float_as_uint(best.d2pos));
+    if (best.nan) atomicOr(err, ERRF_NAN);
+  }
+}
+template <int MODE, int SIGN>
+__global__ __launch_bounds__(256) void k_brute_finish(GridParams g, const uint32_t* __restrict__ plane, const uint32_t* __restrict__ acc,
+                                                      float* __restrict__ out, uint32_t n_packets, PeerOut peers) {
+  const int lane = threadIdx.x & 63;
+  const uint32_t packet = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (packet >= n_packets) return;
+  const GridBrick vox = grid_lane_voxel_plain(g, packet, lane);
+  if (!vox.in_range) return;
+  const size_t slot = ((size_t)packet * 64u + lane) * 2u;
+  Best<MODE> best;
+  best.d2 = __uint_as_float(acc[slot]);
+  best.d2pos = __uint_as_float(acc[slot + 1]);
+  bool negate = false;
+  if (MODE == MODE_UNSIGNED && SIGN == SIGN_GRID_PLANE) {
+    const size_t w = ((size_t)vox.x * g.n[1] + vox.y) * g.nzw + (vox.z >> 5);
+    negate = (plane[w] >> (vox.z & 31u)) & 1u;
+  }
+  const float result = finish<MODE>(best, negate);
+  const size_t out_index = ((size_t)vox.x * g.n[1] + vox.y) * g.n[2] + vox.z - (size_t)g.out_off;
+  out[out_index] = result;
+  for (uint32_t i = 0; i < peers.n; ++i) peers.p[i][out_index + (size_t)g.out_off] = result;
+}
+
 // ---- query ordering (generic path): Morton sort so that a packet is spatially compact ---------
 __device__ __forceinline__ int ordf(float f) {
   int i = __float_as_int(f);
@@ -1500,8 +1584,21 @@ static size_t cut_blocks(const GridParams& g, uint32_t log) {
   return (size_t)bricks_along(nbx, log) * bricks_along(nby, log) * bricks_along(nbz, log);
 }
 
+// Tiny problems take k_brute_split: at most 2^22 cells and cells x triangles <= 1e8 + 3000 x triangles (M2S_BRUTE_MAX overrides the
+// product's limit; read per call: the tests switch it).  Measured (tools/exp_tiny.py, whole calls, brute / build + walk): blob-11k 16^3
+// 0.34 / 0.92 ms, 20^3 0.58 / 0.96, 24^3 0.92 / 0.83; blob-100k 8^3 0.41 / 2.21, 12^3 1.08 / 2.55, 16^3 2.21 / 2.22; blob-6k 16^3 0.20 / 0.74,
+// 32^3 1.10 / 0.61 — brute force runs at 178 G point-triangle pairs per second (half the chip's fp32 issue rate), the walks of such
+// grids as long as their slowest lane's chain of dependent loads, which grows with the mesh.
+bool grid_is_tiny(const GridParams& g, size_t n_tris, int algorithm) {
+  if (algorithm != 0 || n_tris == 0 || g.xe <= g.xb || g.n[1] == 0 || g.n[2] == 0 || g.chunk_log < 31u) return false;
+  const double limit = getenv("M2S_BRUTE_MAX") ? atof(getenv("M2S_BRUTE_MAX")) : 1.0e8 + 3.0e3 * (double)n_tris;
+  const double cells = (double)(g.xe - g.xb) * g.n[1] * g.n[2];
+  return cells <= 4194304.0 && cells * (double)n_tris <= limit;
+}
 size_t grid_distance_workspace_bytes(const GridParams& g) {
   const size_t bricks = (size_t)host_brick_count(g);
+  if ((double)(g.xe - g.xb) * g.n[1] * g.n[2] <= 4194304.0)   // room for k_brute_split's per-voxel words
+    return bricks * 44 + bricks + 16384 + cut_blocks(g, 0) * CUT_WORDS * 4 + bricks * 64 * 8 + 4096;
   const size_t trail_counters = (size_t)bricks_along(g.xe - g.xb, g.bl[0]) * (bricks_along(g.n[1], g.bl[1]) + 1) * 4;   // M2S_PEER_TRAIL progress
   return bricks * 44 + bricks + 16384 + cut_blocks(g, 0) * CUT_WORDS * 4 + trail_counters + 1024;   // seeds + cut lists (one per brick)
 }
@@ -1569,6 +1666,11 @@ int prepare_grid_walk(Arena& ws, hipStream_t st, const DeviceMesh& mesh, const G
   *plan = GridWalkPlan{};
   if (g.xe <= g.xb || g.n[1] == 0 || g.n[2] == 0) return 0;
   const uint32_t packets = host_brick_count(g);
+  if (grid_is_tiny(g, mesh.n_tris, algorithm)) {
+    plan->brute_acc = ws.take<uint32_t>((size_t)packets * 64 * 2);
+    if (!plan->brute_acc) { set_error("internal: brute-force workspace too small"); return M2S_ERR_HIP_INTERNAL; }
+    return 0;
+  }
   const bool brute = algorithm == 1;
   const uint32_t* seed1 = nullptr;
   uint32_t sh1 = 0, s1ny = 0, s1nz = 0;
@@ -1674,6 +1776,25 @@ int launch_grid_walk(hipStream_t st, const DeviceMesh& mesh, const GridParams& g
   const uint32_t* seed1 = plan.seeds;
   const uint32_t sh1 = plan.seed_shift, s1ny = plan.seed_ny, s1nz = plan.seed_nz;
   const CutList cut = {plan.cut_lists, plan.cut_log, plan.cut_ny, plan.cut_nz, bx_off, nullptr};
+  if (plan.brute_acc != nullptr) {
+    // ~4 blocks per CU over (voxel blocks x triangle chunks); a chunk is a whole number of 128-triangle tiles
+    const uint32_t real = bricks_along(g.xe - g.xb, g.bl[0]) * bricks_along(g.n[1], g.bl[1]) * bricks_along(g.n[2], g.bl[2]);   // no super-brick padding here
+    const uint32_t vblocks = (real + 3) / 4, tiles = (mesh.n_tris + TILE - 1) / TILE;
+    const uint32_t chunks = std::max(1u, std::min(tiles, (1024u + vblocks - 1) / vblocks));
+    const uint32_t tiles_per_chunk = (tiles + chunks - 1) / chunks;
+    const uint32_t ychunks = (tiles + tiles_per_chunk - 1) / tiles_per_chunk;
+    M2S_HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)plan.brute_acc, 0x7f800000, (size_t)packets * 64 * 2, st));   // +inf: where every search starts (Best<>)
+    if (mode == MODE_UNSIGNED) {
+      hipLaunchKernelGGL((k_brute_split<MODE_UNSIGNED>), dim3(vblocks, ychunks), dim3(256), 0, st, mesh, g, plan.brute_acc, d_err, real, tiles_per_chunk);
+      if (d_inside_plane) hipLaunchKernelGGL((k_brute_finish<MODE_UNSIGNED, SIGN_GRID_PLANE>), dim3(vblocks), dim3(256), 0, st, g, d_inside_plane, (const uint32_t*)plan.brute_acc, d_out, real, pz);
+      else hipLaunchKernelGGL((k_brute_finish<MODE_UNSIGNED, SIGN_NONE>), dim3(vblocks), dim3(256), 0, st, g, (const uint32_t*)nullptr, (const uint32_t*)plan.brute_acc, d_out, real, pz);
+    } else {
+      hipLaunchKernelGGL((k_brute_split<MODE_NORMAL_FOLD>), dim3(vblocks, ychunks), dim3(256), 0, st, mesh, g, plan.brute_acc, d_err, real, tiles_per_chunk);
+      hipLaunchKernelGGL((k_brute_finish<MODE_NORMAL_FOLD, SIGN_NONE>), dim3(vblocks), dim3(256), 0, st, g, (const uint32_t*)nullptr, (const uint32_t*)plan.brute_acc, d_out, real, pz);
+    }
+    M2S_HIP_CHECK(hipGetLastError());
+    return 0;
+  }
   if (plan.lane_walk) {
     const unsigned blocks = (packets + 3) / 4;
     const bool lane_greedy = getenv("M2S_LANE_GREEDY") ? atoi(getenv("M2S_LANE_GREEDY")) != 0 : true;

@@ -23,7 +23,8 @@ def cut_lists_mode(request):
     """The cut lists (k_cut) are used from 100 000 packets per launch upwards and the packet walk of generic queries from a
     few million queries; the second run of every test lowers the thresholds and forces the packet walks, so that the nasty
     small inputs below (degenerate, non-finite, huge, anisotropic, sliced, duplicated) meet packets and cut lists too; the third
-    run forces the lane walks (k_lane, k_lane_q) on everything that is small enough for them to be quick."""
+    run forces the lane walks (k_lane, k_lane_q) on everything that is small enough for them to be quick.  In the default run
+    the tiny grids (cells x triangles <= M2S_BRUTE_MAX) take the tree-less k_brute_split."""
     import os
 
     mode = request.param
@@ -38,10 +39,12 @@ def cut_lists_mode(request):
         os.environ["M2S_CUT_MIN_PACKETS"] = "8"
         os.environ["M2S_QUERY_CUT_MIN"] = "1"
         os.environ["M2S_LANE_WALK"] = "0"
+        os.environ["M2S_BRUTE_MAX"] = "0"         # no brute-force shortcut for tiny problems (the default mode takes it): the walks must see them
     elif mode == "lane walks":
         os.environ["M2S_LANE_WALK"] = "1"
+        os.environ["M2S_BRUTE_MAX"] = "0"
     yield
-    for k in ("M2S_CUT_MIN_PACKETS", "M2S_QUERY_CUT_MIN", "M2S_LANE_WALK"):
+    for k in ("M2S_CUT_MIN_PACKETS", "M2S_QUERY_CUT_MIN", "M2S_LANE_WALK", "M2S_BRUTE_MAX"):
         os.environ.pop(k, None)
 
 
@@ -436,6 +439,45 @@ def test_config2_256_sub_lattice():
     par = orc.grid_ray_parity(v, idx, g.get_first_cell(), g.get_cell_size(), [n, n, n]).reshape(n, n, n, 3)
     inside = (par.sum(-1) >= 2)
     assert np.array_equal(np.signbit(sdf.cpu().numpy()), inside), "256^3 signs (all cells)"
+
+
+def test_tiny_grids_brute_force_matches_walks_and_oracle(suzanne):
+    """Tiny problems (cells x triangles <= 1e8 + 3000 T) skip the LBVH and run all voxels against all triangles (k_brute_split, 2-D
+    decomposition + atomic minima): must equal the walks bit for bit — device and host results, slabs, persistent mesh, both sign
+    rules, anisotropic cells, a ragged grid — and the oracle.  (The reference's criterion bench has this shape: 16^3 over 11 k triangles.)"""
+    import os
+
+    import torch
+
+    from mesh_to_sdf_amd import Mesh
+
+    if os.environ.get("M2S_BRUTE_MAX") == "0":
+        pytest.skip("this run forces the walks")
+    v, idx = suzanne
+    for counts, lo_hi in (([16, 16, 16], None), ([13, 7, 21], None), ([24, 5, 9], ((-2.0, -0.5, -1.0), (2.0, 0.5, 1.5)))):
+        g = grid_of(v, counts) if lo_hi is None else Grid.from_bounding_box(lo_hi[0], lo_hi[1], counts)
+        for sign in (SignMethod.Raycast, SignMethod.Normal):
+            os.environ["M2S_BRUTE_MAX"] = "0"
+            try:
+                walk = generate_grid_sdf(v, Topology.TriangleList(idx), g, sign)
+            finally:
+                os.environ.pop("M2S_BRUTE_MAX", None)
+            t = M2STimings()
+            brute = generate_grid_sdf(v, Topology.TriangleList(idx), g, sign, timings=t)
+            assert_bit_equal(brute, walk, f"brute force vs walk {counts} {sign.name}")
+            assert_bit_equal(brute, oracle_grid(v, idx, g, sign), f"brute force vs oracle {counts} {sign.name}")
+            assert t.n_units == g.get_total_cell_count() and t.accel_build_ms < 0.1          # no tree was built
+            dv = torch.as_tensor(v, device="cuda")
+            di = torch.as_tensor(idx.astype(np.int64), device="cuda")
+            dev = generate_grid_sdf(dv, Topology.TriangleList(di), g, sign)
+            assert_bit_equal(dev.cpu().numpy(), walk, "device-resident")
+            parts = torch.full_like(dev, float("nan"))
+            cut = counts[0] // 3
+            for xs in ((0, cut), (cut, counts[0])):
+                generate_grid_sdf(dv, Topology.TriangleList(di), g, sign, x_slab=xs, out=parts)
+            assert_bit_equal(parts.cpu().numpy(), walk, "two slabs")
+            with Mesh(dv, Topology.TriangleList(di)) as m:
+                assert_bit_equal(m.generate_grid_sdf(g, sign).cpu().numpy(), walk, "persistent mesh")
 
 
 def test_x_slabs_concatenate(suzanne):
