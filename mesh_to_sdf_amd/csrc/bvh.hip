@@ -705,6 +705,63 @@ __global__ __launch_bounds__(TREELET_MAX) void k_treelet(const int2* __restrict_
   }
 }
 
+// The treelet roots straight from the sorted keys, without the hierarchy (lean build: replaces the first k_karras and the roots
+// kernel).  The radix tree over the keys (ties broken by position, as k_karras does: the common prefix of two EQUAL keys j < j' is
+// 64 + clz(j ^ j')) has the property that the common prefix of any two positions is the minimum of the ADJACENT prefixes between
+// them, so the nodes that contain position p are found by growing [l, r] from [p, p]: the next node up shares c = max(d[l - 1], d[r])
+// bits and reaches as far as the adjacent prefixes stay >= c.  The largest such node of at most TREELET_MAX triangles is p's
+// treelet; it is a root of the old list iff it has at least 3 triangles, and its first position reports it.  A block keeps the
+// adjacent prefixes of its 256 positions plus 66 either side in LDS (a node of <= 64 reaches no further, and one step beyond shows
+// that its parent is too large).
+__device__ __forceinline__ int adjacent_prefix(const uint64_t* __restrict__ keys, int n, int j) {   // delta(j, j + 1) of k_karras; -1 outside
+  if (j < 0 || j + 1 >= n) return -1;
+  const uint64_t a = keys[j], b = keys[j + 1];
+  return a == b ? 64 + __clz((uint32_t)j ^ (uint32_t)(j + 1)) : __clzll((long long)(a ^ b));
+}
+__global__ __launch_bounds__(256) void k_roots_from_keys(const uint64_t* __restrict__ keys, int n, int2* __restrict__ roots,
+                                                         int* __restrict__ n_roots) {
+  constexpr int HALO = TREELET_MAX + 2;
+  __shared__ int s_d[256 + 2 * HALO];
+  __shared__ int s_wcnt[4], s_base;
+  const int base = blockIdx.x * 256, lo = base - HALO;
+  for (int t = threadIdx.x; t < 256 + 2 * HALO; t += 256) s_d[t] = adjacent_prefix(keys, n, lo + t);
+  __syncthreads();
+  const int p = base + (int)threadIdx.x;
+  bool is_root = false;
+  int l = p, r = p;
+  if (p < n) {
+    // ONE flat loop, one neighbour per step (nested "extend while the prefix stays >= c" loops cost 74 us: in lockstep a wave pays
+    // the longest extension of any lane at every level).  The neighbours join in the order of their prefix with p — the running minimum
+    // of the adjacent prefixes towards them, non-increasing on either side — so the two sides are merged like two sorted lists; a
+    // node is complete whenever the next candidate's prefix is smaller than the last one taken.
+    int kl = 0, kr = 0;                                           // neighbours taken on the left / right
+    int ml = s_d[p - 1 - lo], mr = s_d[p - lo];                  // prefix at which the next one on either side would join
+    while (kl + kr + 1 < TREELET_MAX + 1) {
+      const int v = max(ml, mr);
+      if (v < 0) break;                                           // nobody left: [l, r] is the whole array
+      if (kl + kr + 1 == TREELET_MAX) break;                     // the next node up would hold more than TREELET_MAX
+      if (ml >= mr) { ++kl; ml = min(ml, s_d[p - kl - 1 - lo]); }
+      else { ++kr; mr = min(mr, s_d[p + kr - lo]); }
+      if (max(ml, mr) < v) { l = p - kl; r = p + kr; }           // that level is complete: a node
+    }
+    is_root = l == p && r - l + 1 >= 3;
+  }
+  const unsigned long long bal = __ballot(is_root);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) s_wcnt[wave] = __popcll(bal);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int total = s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
+    s_base = total ? atomicAdd(n_roots, total) : 0;
+  }
+  __syncthreads();
+  if (is_root) {
+    int off = s_base + (int)__popcll(bal & ((1ull << lane) - 1ull));
+    for (int w = 0; w < wave; ++w) off += s_wcnt[w];
+    roots[off] = make_int2(l, r - l + 1);
+  }
+}
+
 // The same treelets with the items held BY POSITION IN THE LANES of one wave instead of in LDS arrays that every lane loops over.
 // k_treelet's four loops per level run over the lane's whole segment — O(m^2) LDS reads per level, one LDS round trip per
 // iteration: 62 us for 100 k triangles (every wave waiting on its own chain) and 290 us for 1 M (the LDS pipes saturated).  Here a
@@ -1308,7 +1365,11 @@ int build_device_mesh(Arena& ws, hipStream_t st, const float* d_verts, size_t n_
   }
   M2S_HIP_CHECK(rocprim::radix_sort_pairs(tmp, sort_tmp, keys, keys2, vals, order, n_tris, 0, 64, st));
   }
-  if (n > 1) hipLaunchKernelGGL(k_karras, dim3(cdiv(n_tris - 1, B)), dim3(B), 0, st, keys2, n, range, child, parent);
+  static const bool treelets = !(getenv("M2S_TREELETS") && atoi(getenv("M2S_TREELETS")) == 0);
+  const bool treelet_pass = n > 2 && treelets && !getenv("M2S_KEYS_FILE");
+  // lean build: the treelet roots come straight from the sorted keys (k_roots_from_keys), so the hierarchy is derived ONCE, after the treelets
+  const bool roots_from_keys = lean && treelet_pass && TREELET_MAX == 64 && !(getenv("M2S_ROOTS_FROM_KEYS") && atoi(getenv("M2S_ROOTS_FROM_KEYS")) == 0);
+  if (n > 1 && !roots_from_keys) hipLaunchKernelGGL(k_karras, dim3(cdiv(n_tris - 1, B)), dim3(B), 0, st, keys2, n, range, child, parent);
   if (after_setup) {
     // phase 1: `st` now holds ~100 us of work (keys, sort, hierarchy) — the time the host needs to enqueue the side
     // work (the seed passes, behind the phase-0 mark).  Launching it at phase 0 left `st` idle for those ~100 us (a
@@ -1317,11 +1378,11 @@ int build_device_mesh(Arena& ws, hipStream_t st, const float* d_verts, size_t n_
     const int rc = (*after_setup)(cen_raw, raw, 1);
     if (rc) return rc;
   }
-  static const bool treelets = !(getenv("M2S_TREELETS") && atoi(getenv("M2S_TREELETS")) == 0);
-  if (n > 2 && treelets && !getenv("M2S_KEYS_FILE")) {
+  if (treelet_pass) {
     // treelet pass: the nodes of at most TREELET_MAX triangles are rebuilt by sweep splits, then the hierarchy is derived again
     int2* roots = reinterpret_cast<int2*>(child);   // child[] is not used by the kernels below and is rewritten by the second k_karras
-    if (lean) hipLaunchKernelGGL(k_treelet_roots_block, dim3(cdiv(n_tris - 1, B)), dim3(B), 0, st, n, range, parent, roots, scene + 7);
+    if (roots_from_keys) hipLaunchKernelGGL(k_roots_from_keys, dim3(cdiv(n_tris, B)), dim3(B), 0, st, (const uint64_t*)keys2, n, roots, scene + 7);
+    else if (lean) hipLaunchKernelGGL(k_treelet_roots_block, dim3(cdiv(n_tris - 1, B)), dim3(B), 0, st, n, range, parent, roots, scene + 7);
     else hipLaunchKernelGGL(k_treelet_roots, dim3(cdiv(n_tris - 1, B)), dim3(B), 0, st, n, range, parent, roots, scene + 7);
     if (lean && TREELET_MAX == 64 && !(getenv("M2S_TREELET_LANES") && atoi(getenv("M2S_TREELET_LANES")) == 0))
       hipLaunchKernelGGL(k_treelet_lanes, dim3((unsigned)std::min<size_t>((n_tris + 2) / 3, 8192)), dim3(64), 0, st, roots, scene + 7, boxes, keys2, order);
