@@ -153,7 +153,7 @@ def live_pmc(child_args, kernel="k_packet"):
         try:
             cmd = ["rocprofv3", "--pmc"] + counters.split() + ["--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--",
                                                                 sys.executable, os.path.abspath(__file__)] + child_args
-            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp", M2S_BENCH_CHILD="1"), capture_output=True, text=True, timeout=400)
+            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp", M2S_BENCH_CHILD="1"), capture_output=True, text=True, timeout=150)
             files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
             if r.returncode != 0 or not files:
                 return None, f"rocprofv3 --pmc {counters} failed (rc {r.returncode}): {r.stderr[-300:]}"

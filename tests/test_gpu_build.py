@@ -75,6 +75,33 @@ def test_lean_build_same_tree_duplicates_and_degenerates():
     _same_tree(v2, np.arange(6000, dtype=np.uint32), "all in one cell")
 
 
+def test_lean_build_same_tree_adversarial_keys():
+    """What the treelet roots from the sorted keys (k_roots_from_keys) must get right without the hierarchy: runs of EQUAL keys on both
+    sides of the treelet size (the tie-break by position), clusters that fill a node exactly to 64 / 65, keys that differ only in their
+    last bits, a few far outliers that stretch the Morton cells, a regular lattice of identical triangles (many equal prefixes)."""
+    rng = np.random.default_rng(23)
+    tri = rng.uniform(-1, 1, (1, 3, 3)).astype(np.float32) * np.float32(0.01)
+    for copies in (2, 3, 63, 64, 65, 66, 127, 128, 129, 200):
+        v = np.concatenate([np.repeat(tri, copies, axis=0).reshape(-1, 3), rng.uniform(-1, 1, (3 * 37, 3)).astype(np.float32)])
+        _same_tree(v, np.arange(v.shape[0], dtype=np.uint32), f"{copies} copies of one triangle + 37 others")
+    # clusters of exactly 64 / 65 near-identical centres, far apart
+    for per in (64, 65):
+        parts = []
+        for c in range(9):
+            centre = rng.uniform(-100, 100, (1, 1, 3)).astype(np.float32)
+            parts.append(centre + rng.uniform(-1e-4, 1e-4, (per, 3, 3)).astype(np.float32))
+        v = np.concatenate(parts).reshape(-1, 3)
+        _same_tree(v, np.arange(v.shape[0], dtype=np.uint32), f"clusters of {per}")
+    # two far outliers squeeze everything else into a corner of the Morton cube
+    v = np.concatenate([rng.uniform(0, 1e-3, (3 * 500, 3)).astype(np.float32), np.float32([[1e6, 1e6, 1e6]] * 3), np.float32([[-1e6, 3.0, 2.0]] * 3)])
+    _same_tree(v, np.arange(v.shape[0], dtype=np.uint32), "outliers")
+    # a regular lattice of identical small triangles: long runs of equal key prefixes
+    gx, gy, gz = np.meshgrid(np.arange(12), np.arange(11), np.arange(10), indexing="ij")
+    base = np.stack([gx, gy, gz], -1).reshape(-1, 1, 3).astype(np.float32)
+    v = (base + np.float32([[0, 0, 0], [0.3, 0, 0], [0, 0.3, 0]])).reshape(-1, 3)
+    _same_tree(v, np.arange(v.shape[0], dtype=np.uint32), "lattice")
+
+
 def test_lean_build_same_tree_blob_1m():
     v, idx = meshes.named("blob-1M")
     _same_tree(v, idx, "blob-1M")
