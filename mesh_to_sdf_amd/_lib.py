@@ -206,6 +206,10 @@ def lib():
         L.m2s_grid_cell_idx.argtypes = [C.POINTER(M2SGrid), C.POINTER(C.c_uint64)]
         L.m2s_triangle_count.restype = C.c_size_t
         L.m2s_triangle_count.argtypes = [C.c_size_t, C.c_size_t, C.c_int, C.c_int]
+        if os.environ.get("M2S_LIB") and not hasattr(L, "m2s_warmup"):
+            # an A/B build of an OLDER library (tools/exp_ab.py): it lacks the entry points added since; the old ones are all the A/B uses
+            _lib = L
+            return L
         L.m2s_warmup.restype = C.c_int
         L.m2s_warmup.argtypes = [C.c_int, C.c_size_t, C.c_size_t]
         L.m2s_version.restype = C.c_int

@@ -304,29 +304,28 @@ __device__ __forceinline__ uint32_t stab_count(const DeviceMesh& mesh, f3 p) {
 // A list is ONE 64-byte record (round 2: 128 B of (start, end) byte offsets — 268 MB of lists for a 537 MB output):
 //   word 0        number of ranges
 //   word 1 + k    low S bits: start of range k (node record index), S = bits needed for the tree's node count; the other 32 - S bits:
-//                 its length as a small float — 5 bits of exponent e, M = 27 - S bits of mantissa m: e = 0 means m + 1 records,
-//                 e >= 1 means (2^M + m) << (e - 1), the smallest such value that is >= the true length
-// Lengths up to 2^(M+1) records are exact and longer ones exceed the truth by less than 2^-M (100 k triangles: M = 9, 0.2 %; 1 M: M = 6,
-// 1.6 %; the 2^25-triangle limit: M = 1): a superset of the subtrees, which a walk may always take, and one that hardly costs — a first
+//                 its length as a small float — 5 bits of exponent e, M = 27 - S bits of mantissa m: m << e records, the smallest
+//                 such value that is >= the true length
+// Lengths below 2^M records are exact and longer ones exceed the truth by less than 2^-(M-1) (100 k triangles: M = 9, 0.4 %; 1 M: M = 6,
+// 3 %; the 2^25-triangle limit: M = 1): a superset of the subtrees, which a walk may always take, and one that hardly costs — a first
 // form with 6-bit power-of-two lengths walked up to twice a long range: 14 % more node tests and 4.8 % more time on 512^3 x blob-1M
 // (same box: 26.60 against 25.37 ms; the headline 8.40 against 8.43 ms).  A range that
-// reaches into the next one is cut at the next one's start by the walk.  k_cut writes a word when its range closes, as before (ranges
+// reaches into the next one is walked there twice (harmless: a minimum).  k_cut writes a word when its range closes, as before (ranges
 // kept in LDS or scratch until the end and written as one record cost k_cut 20-35 %: five waves per SIMD, or scratch traffic).
 __host__ __device__ __forceinline__ uint32_t cut_start_bits(uint32_t n_nodes) {
   uint32_t b = 1;
   while (b < 27u && (1u << b) < n_nodes) ++b;
   return b;
 }
-__device__ __forceinline__ uint32_t cut_decode_len(uint32_t code, uint32_t M) {
-  const uint32_t e = code >> M, m = code & ((1u << M) - 1u);
-  return e == 0u ? m + 1u : ((1u << M) + m) << (e - 1u);
-}
+// length code: 5 bits of exponent e above M bits of mantissa, len = mantissa << e (explicit leading bit: no special case in the walk's
+// decode, which runs once per range of every packet on the scalar unit)
+__device__ __forceinline__ uint32_t cut_decode_len(uint32_t code, uint32_t M) { return (code & ((1u << M) - 1u)) << (code >> M); }
 __device__ __forceinline__ uint32_t cut_encode_len(uint32_t len, uint32_t M) {          // smallest representable value >= len (len >= 1)
-  if (len <= (1u << M)) return len - 1u;
-  uint32_t sh = (32u - (uint32_t)__clz((int)len)) - (M + 1u);                            // len >> sh lies in [2^M, 2^(M+1))
-  uint32_t mant = (len + (1u << sh) - 1u) >> sh;
-  if (mant == (2u << M)) { mant = 1u << M; ++sh; }
-  return ((sh + 1u) << M) | (mant - (1u << M));
+  if (len < (1u << M)) return len;                                                      // exact, e = 0
+  uint32_t e = (32u - (uint32_t)__clz((int)len)) - M;                                   // len >> e lies in [2^(M-1), 2^M)
+  uint32_t mant = (len + (1u << e) - 1u) >> e;
+  if (mant == (1u << M)) { mant >>= 1; ++e; }
+  return (e << M) | mant;
 }
 constexpr uint32_t CUT_MAX = M2S_CUT_MAX, CUT_WORDS = M2S_CUT_MAX + 1;
 static_assert(M2S_CUT_MAX <= 15, "the range count has four bits");
@@ -415,16 +414,25 @@ __global__ __launch_bounds__(256) void k_packet(DeviceMesh mesh, GridParams g, c
     const float scale = fmaxf(mesh_scale(mesh), fmaxf(fabsf(p.x), fmaxf(fabsf(p.y), fabsf(p.z))));
     const float slack = 4.0e-6f * scale + (MODE == MODE_NORMAL_FOLD ? 2.5e-6f : 0.0f);
 
-    // pre-order ranges to walk: the brick's cut list (grid path), or the whole tree.  The list is 128 bytes that nobody has
-    // touched before (written by k_cut, read once): both of its cache lines are requested here, in front of the seed
-    // evaluation, so that the ~1 us of the miss passes under its 120 instructions instead of in front of the walk.
+    // pre-order ranges to walk: the brick's cut list (grid path), or the whole tree.  The list is 64 bytes that nobody has
+    // touched before (written by k_cut, read once): it is requested here, in front of the seed evaluation, so that the ~1 us of
+    // the miss passes under its 120 instructions instead of in front of the walk.
     const uint32_t* cl = nullptr;
-    uint32_t n_ranges = 1;
+    uint32_t n_ranges = 1, cut_off_v = 0, cut_end_v = 0;
     if (cut.lists != nullptr) {
       const uint32_t cb = GRID ? __builtin_amdgcn_readfirstlane((((vox.bx + cut.bx_off) >> cut.log) * cut.ny + (vox.by >> cut.log)) * cut.nz + (vox.bz >> cut.log))
                                : packet;
       cl = cut.lists + (size_t)cb * CUT_WORDS;
-      n_ranges = cl[0];
+      // The whole 64-byte record with ONE vector load — lane l takes word l — requested here, in front of the seed evaluation;
+      // lanes 1..15 then decode their range side by side (eight VALU instructions for the whole list), and the range loop below
+      // fetches (start, end) of range k from lane 1 + k with two v_readlane: no load and no scalar arithmetic per range.  (Decoding
+      // on the scalar unit, one range at a time, cost the Normal-sign walk of 1024^3 1.3 %: 9 SALU x ~10 ranges per packet.)
+      const uint32_t cw = cl[(uint32_t)lane & 15u];
+      const uint32_t cS = cut_start_bits(mesh.n_nodes), cfirst = cw & ((1u << cS) - 1u);
+      const uint32_t clen = ((cw >> cS) & ((1u << (27u - cS)) - 1u)) << (cw >> 27);
+      cut_off_v = cfirst * (uint32_t)sizeof(NodeExt);
+      cut_end_v = min(cfirst + clen, mesh.n_nodes) * (uint32_t)sizeof(NodeExt);
+      n_ranges = __builtin_amdgcn_readfirstlane(cw);
     }
     if (seed_in != nullptr) {
       // seed: a triangle near this packet's centre, from the seed pass
@@ -481,14 +489,11 @@ __global__ __launch_bounds__(256) void k_packet(DeviceMesh mesh, GridParams g, c
     // the offset operand directly and the loop carries no address arithmetic.
     constexpr uint32_t NB = (uint32_t)sizeof(NodeExt);
     if (STATS) st_ranges = n_ranges;
-    uint32_t cut_done = 0;                                                      // end of the previous range (byte offset)
-    const uint32_t cut_S = cut_start_bits(mesh.n_nodes);
+
     for (uint32_t range = 0; range < n_ranges; ++range) {
-    const uint32_t cut_word = cl ? cl[1 + range] : 0u, cut_first = cut_word & ((1u << cut_S) - 1u);
-    const uint32_t cut_len = cut_decode_len(cut_word >> cut_S, 27u - cut_S);
-    uint32_t off = cl ? max(cut_first * NB, cut_done) : 0u;
-    const uint32_t end = cl ? (uint32_t)min((unsigned long long)cut_first + cut_len, (unsigned long long)mesh.n_nodes) * NB : mesh.n_nodes * NB;
-    cut_done = end;
+    // (a rounded-up range may reach into the next one: those records are then walked twice, which changes no minimum)
+    uint32_t off = cl ? (uint32_t)__builtin_amdgcn_readlane((int)cut_off_v, (int)(1u + range)) : 0u;
+    const uint32_t end = cl ? (uint32_t)__builtin_amdgcn_readlane((int)cut_end_v, (int)(1u + range)) : mesh.n_nodes * NB;
     if (STATS) { st_rbytes += end - off; st_rmax = max(st_rmax, end - off); }
     extern __shared__ float4 stage_lds[];
     const uint32_t stage_base = off;
