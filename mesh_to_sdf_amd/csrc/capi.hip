@@ -1564,4 +1564,13 @@ int m2s_debug_mesh_digest(m2s_mesh* m, uint64_t out[8]) {
   return M2S_OK;
 }
 
+// Test hook (not part of include/m2s.h): the cut-list word of one range and what the walk decodes from it (distance.hip CutList) —
+// host arithmetic only, no device needed.  tests/test_capi_cpu.py checks the superset property for every tree size.
+int m2s_debug_cut_code(uint32_t n_nodes, uint32_t start, uint32_t len, uint32_t out[3]) {
+  g_err[0] = 0;
+  if (!out || n_nodes == 0 || n_nodes > (1u << 26) || len == 0 || start >= n_nodes || len > n_nodes - start) return fail(M2S_ERR_BAD_ARG, "bad range");
+  cut_word_roundtrip(n_nodes, start, len, &out[0], &out[1], &out[2]);
+  return M2S_OK;
+}
+
 }  // extern "C"

@@ -275,6 +275,7 @@ int launch_grid_distance(Arena& ws, hipStream_t st, const DeviceMesh& mesh, cons
                          hipEvent_t ev_before_final, hipEvent_t wait_before_final = nullptr, bool pipelined = false,
                          const SeedLattice* raw_seeds = nullptr, hipEvent_t wait_raw_seeds = nullptr,
                          const PeerOut* peers = nullptr);
+void cut_word_roundtrip(uint32_t n_nodes, uint32_t start, uint32_t len, uint32_t* word, uint32_t* first, uint32_t* end);   // test hook
 size_t query_workspace_bytes(size_t n_q);
 int launch_query_distance(Arena& ws, hipStream_t st, const DeviceMesh& mesh, const float* d_queries, size_t n_q,
                           int mode, int sign_src, int algorithm, float* d_out, int* d_err);

@@ -319,10 +319,10 @@ __host__ __device__ __forceinline__ uint32_t cut_start_bits(uint32_t n_nodes) {
 }
 // length code: 5 bits of exponent e above M bits of mantissa, len = mantissa << e (explicit leading bit: no special case in the walk's
 // decode, which runs once per range of every packet on the scalar unit)
-__device__ __forceinline__ uint32_t cut_decode_len(uint32_t code, uint32_t M) { return (code & ((1u << M) - 1u)) << (code >> M); }
-__device__ __forceinline__ uint32_t cut_encode_len(uint32_t len, uint32_t M) {          // smallest representable value >= len (len >= 1)
+__host__ __device__ __forceinline__ uint32_t cut_decode_len(uint32_t code, uint32_t M) { return (code & ((1u << M) - 1u)) << (code >> M); }
+__host__ __device__ __forceinline__ uint32_t cut_encode_len(uint32_t len, uint32_t M) { // smallest representable value >= len (len >= 1)
   if (len < (1u << M)) return len;                                                      // exact, e = 0
-  uint32_t e = (32u - (uint32_t)__clz((int)len)) - M;                                   // len >> e lies in [2^(M-1), 2^M)
+  uint32_t e = (32u - (uint32_t)__builtin_clz(len)) - M;                                // len >> e lies in [2^(M-1), 2^M)
   uint32_t mant = (len + (1u << e) - 1u) >> e;
   if (mant == (1u << M)) { mant >>= 1; ++e; }
   return (e << M) | mant;
@@ -1843,6 +1843,18 @@ int launch_grid_distance(Arena& ws, hipStream_t st, const DeviceMesh& mesh, cons
   if (wait_before_final) M2S_HIP_CHECK(hipStreamWaitEvent(st, wait_before_final, 0));
   if (ev_before_final) M2S_HIP_CHECK(hipEventRecord(ev_before_final, st));
   return launch_grid_walk(st, mesh, g, mode, d_inside_plane, algorithm, plan, 0, d_out, d_err, peers);
+}
+
+// Test hook (capi.hip m2s_debug_cut_code): the list word k_cut writes for the range [start, start + len) of a tree of n_nodes records,
+// and the (first, end) records k_packet reads back from it.
+void cut_word_roundtrip(uint32_t n_nodes, uint32_t start, uint32_t len, uint32_t* word, uint32_t* first, uint32_t* end) {
+  const uint32_t S = cut_start_bits(n_nodes);
+  const uint32_t w = start | (cut_encode_len(len, 27u - S) << S);
+  *word = w;
+  const uint32_t f = w & ((1u << S) - 1u);
+  const uint32_t l = ((w >> S) & ((1u << (27u - S)) - 1u)) << (w >> 27);                // as k_packet decodes it
+  *first = f;
+  *end = std::min(f + l, n_nodes);
 }
 
 size_t query_workspace_bytes(size_t n_q) {

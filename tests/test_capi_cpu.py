@@ -135,6 +135,40 @@ def test_balanced_slabs_equalise_a_known_cost_profile():
         assert e.value.code == _lib.ERR_BAD_ARG
 
 
+def test_cut_list_words_are_supersets_for_every_tree_size(lib):
+    """distance.hip CutList: a list word carries a range's start exactly and its length as a small float rounded UP — the walk may take a
+    superset of a subtree range, never less.  Host arithmetic of the library itself (test hook m2s_debug_cut_code), every width of the
+    start field from 1 to 26 bits (1 … 2^25 triangles), lengths around every power of two and random ones."""
+    fn = lib.m2s_debug_cut_code
+    fn.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]
+    fn.restype = C.c_int
+    out = (C.c_uint32 * 3)()
+    rng = np.random.default_rng(5)
+    sizes = [1, 2, 3, 5, 1935, 22399, 199999, 1999999, (1 << 24) + 77, (1 << 26) - 1] + [int(rng.integers(1, 1 << 26)) for _ in range(20)]
+    worst = {}
+    for n in sizes:
+        S = max(1, (n - 1).bit_length())
+        M = 27 - S
+        lens = {1, n, max(1, n // 2), max(1, n // 3)}
+        for b in range(0, S + 1):
+            for d in (-1, 0, 1, 2):
+                v = (1 << b) + d
+                if 1 <= v <= n:
+                    lens.add(v)
+        lens |= {int(x) for x in rng.integers(1, n + 1, 200)}
+        for ln in sorted(lens):
+            for start in {0, n - ln, int(rng.integers(0, n - ln + 1))}:
+                assert fn(n, start, ln, out) == 0
+                word, first, end = out[0], out[1], out[2]
+                assert first == start
+                assert start + ln <= end <= n, (n, start, ln, end)
+                if start + ln < end < n and M >= 2:            # the excess stays below 2^-(M-1) of the length (lengths < 2^M are exact)
+                    assert ln >= (1 << M) and (end - start - ln) * (1 << (M - 1)) <= ln, (n, start, ln, end, M)
+                    worst[M] = max(worst.get(M, 0.0), (end - start - ln) / ln)
+    assert fn(100, 90, 11, out) != 0 and fn(0, 0, 1, out) != 0 and fn(100, 0, 0, out) != 0
+    assert worst                                               # some long ranges were rounded
+
+
 def test_argument_errors_before_any_device_work(lib):
     v = np.zeros((3, 3), np.float32)
     with pytest.raises(M2SError) as e:
