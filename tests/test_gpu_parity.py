@@ -31,6 +31,8 @@ def cut_lists_mode(request):
     big = any(t in request.node.name for t in ("full_size", "10M", "512", "1024", "config", "256"))
     if mode != "default" and "full_size" in request.node.name:
         pytest.skip("large enough to use the cut lists anyway")
+    if mode != "default" and "four_million" in request.node.name:
+        pytest.skip("the test switches the walks itself")
     if mode != "default" and any(t in request.node.name for t in ("parity_sheet100k_256", "parity_blob1m")):
         pytest.skip("a report against minutes of CPU propagation: once is enough (the kernels' modes are covered by the other tests)")
     if mode == "lane walks" and big:
@@ -478,6 +480,41 @@ def test_tiny_grids_brute_force_matches_walks_and_oracle(suzanne):
             assert_bit_equal(parts.cpu().numpy(), walk, "two slabs")
             with Mesh(dv, Topology.TriangleList(di)) as m:
                 assert_bit_equal(m.generate_grid_sdf(g, sign).cpu().numpy(), walk, "persistent mesh")
+
+
+def test_four_million_triangles_every_walk_equals_brute_force():
+    """A mesh of 4 M triangles (23-bit record indices: the cut lists' length codes keep 4 mantissa bits; the build sorts 4 M keys):
+    the lane walk (what such a coarse grid takes by default), the packet walk from the root and the packet walk from cut lists must all
+    equal the tree-less all-pairs kernel (algorithm = 1, itself pinned on the oracle by the suzanne tests) bit for bit, both sign rules."""
+    import os
+
+    import torch
+
+    from mesh_to_sdf_amd import meshes
+
+    v, idx = meshes.blob(2000, 1001, detail=True)
+    assert len(idx) // 3 == 4_000_000
+    lo, hi = meshes.extended_bbox(v, 0.1)
+    g = Grid.from_bounding_box(lo, hi, [40, 36, 44])
+    dv = torch.as_tensor(v, device="cuda")
+    topo = Topology.TriangleList(torch.as_tensor(idx.astype(np.int64), device="cuda").to(torch.int32))
+    saved = {k: os.environ.get(k) for k in ("M2S_LANE_WALK", "M2S_CUT_MIN_PACKETS", "M2S_BRUTE_MAX")}
+    try:
+        for sign in (SignMethod.Raycast, SignMethod.Normal):
+            want = generate_grid_sdf(dv, topo, g, sign, algorithm=1).cpu().numpy()
+            assert np.isfinite(want).all() and (want < 0).any() and (want > 0).any()
+            for name, env in (("default", {}), ("packet walk", {"M2S_LANE_WALK": "0"}),
+                              ("packet walk + cut lists", {"M2S_LANE_WALK": "0", "M2S_CUT_MIN_PACKETS": "1"}), ("lane walk", {"M2S_LANE_WALK": "1"})):
+                for k in saved:
+                    os.environ.pop(k, None)
+                os.environ.update(env)
+                got = generate_grid_sdf(dv, topo, g, sign).cpu().numpy()
+                assert_bit_equal(got, want, f"4 M triangles, {sign.name}, {name}")
+    finally:
+        for k, val in saved.items():
+            os.environ.pop(k, None)
+            if val is not None:
+                os.environ[k] = val
 
 
 def test_x_slabs_concatenate(suzanne):
