@@ -1129,6 +1129,21 @@ int m2s_generate_sdf(const float* vertices, size_t n_vertices, const void* indic
     hc.lap("queries to the device (pinned ring on a first call)");
   }
   M2S_HIP_CHECK(hipEventRecord(st->ev[0], c.stream));
+  // What the queries need before the walk — bounding box, Morton keys, sort, packet table, gather (distance.hip prepare_query_walk) — does
+  // not need the tree: a synchronous call runs it on the side stream beside the build (M2S_QUERY_OVERLAP=0: behind it, as round 2 did)
+  QueryPlan qplan;
+  static const bool q_overlap = !(getenv("M2S_QUERY_OVERLAP") && atoi(getenv("M2S_QUERY_OVERLAP")) == 0);
+  const bool beside = q_overlap && algorithm == 0 && n_tris != 0 && n_queries >= 32768 && side_stream_wanted(c.sync) && !getenv("M2S_STATS");
+  if (beside) {
+    rc = ensure_side_stream(*st);
+    if (rc) return rc;
+    if (!st->qprep_done) M2S_HIP_CHECK(hipEventCreateWithFlags(&st->qprep_done, hipEventDisableTiming));
+    M2S_HIP_CHECK(hipEventRecord(st->fork_ev, c.stream));                 // the queries are on the device
+    M2S_HIP_CHECK(hipStreamWaitEvent(st->side_stream, st->fork_ev, 0));
+    rc = prepare_query_walk(ws, st->side_stream, d_q, n_queries, n_tris, sign_src, algorithm, &qplan);
+    if (rc) return rc;
+    M2S_HIP_CHECK(hipEventRecord(st->qprep_done, st->side_stream));
+  }
   DeviceMesh mesh;
   rc = build_device_mesh(ws, c.stream, sm.d_verts, n_vertices, sm.d_indices, n_indices, index_bytes, topology, n_tris, d_err, &mesh);
   if (rc) return rc;
@@ -1138,7 +1153,13 @@ int m2s_generate_sdf(const float* vertices, size_t n_vertices, const void* indic
   unsigned long long* d_stats = nullptr;
   rc = stats_begin(ws, c.stream, &mesh, &d_stats);
   if (rc) return rc;
-  rc = launch_query_distance(ws, c.stream, mesh, d_q, n_queries, mode, sign_src, algorithm, d_out, d_err);
+  if (beside) {
+    M2S_HIP_CHECK(hipStreamWaitEvent(c.stream, st->qprep_done, 0));
+  } else {
+    rc = prepare_query_walk(ws, c.stream, d_q, n_queries, n_tris, sign_src, algorithm, &qplan);
+    if (rc) return rc;
+  }
+  rc = launch_query_walk(ws, c.stream, mesh, d_q, qplan, mode, sign_src, algorithm, d_out, d_err);
   if (rc) return rc;
   M2S_HIP_CHECK(hipEventRecord(st->ev[3], c.stream));
   rc = stats_end(c.stream, d_stats);

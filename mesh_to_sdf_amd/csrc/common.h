@@ -277,6 +277,20 @@ int launch_grid_distance(Arena& ws, hipStream_t st, const DeviceMesh& mesh, cons
                          const PeerOut* peers = nullptr);
 void cut_word_roundtrip(uint32_t n_nodes, uint32_t start, uint32_t len, uint32_t* word, uint32_t* first, uint32_t* end);   // test hook
 size_t query_workspace_bytes(size_t n_q);
+// What the walk of a generic query set needs besides the mesh (prepare_query_walk; device pointers into the call's arena).
+struct QueryPlan {
+  size_t n_q = 0;
+  const int* qb = nullptr;          // ordered-int bounding box of the queries
+  const uint32_t* perm = nullptr;   // sorted position -> input index
+  const float4* sorted = nullptr;   // queries in Morton order
+  const uint32_t* table = nullptr;  // packet table (k_qcells), nullptr: 64 consecutive queries per packet
+  const float4* centres = nullptr;  // (centre, radius) per packet when cut lists will be used
+  uint32_t launched = 0;
+  bool lane_walk = false, seeds = false;
+};
+int prepare_query_walk(Arena& ws, hipStream_t st, const float* d_queries, size_t n_q, size_t n_tris, int sign_src, int algorithm, QueryPlan* plan);
+int launch_query_walk(Arena& ws, hipStream_t st, const DeviceMesh& mesh, const float* d_queries, const QueryPlan& plan,
+                      int mode, int sign_src, int algorithm, float* d_out, int* d_err);
 int launch_query_distance(Arena& ws, hipStream_t st, const DeviceMesh& mesh, const float* d_queries, size_t n_q,
                           int mode, int sign_src, int algorithm, float* d_out, int* d_err);
 

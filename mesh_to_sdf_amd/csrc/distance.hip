@@ -1400,8 +1400,10 @@ __device__ __forceinline__ uint32_t expand10q(uint32_t v) {
   x = (x | x << 2) & 0x09249249u;
   return x;
 }
+// `drop`: low key bits cleared.  The sort then runs over the bits [drop, 30) only — 10 M queries need 21 bits (2 M cells) to form their
+// packets, three radix passes instead of four; queries of one finest cell stay in input order, which k_qcells treats like identical keys.
 __global__ __launch_bounds__(256) void k_qkeys(const float* __restrict__ q, uint32_t n_q, const int* __restrict__ b,
-                                               uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+                                               uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t drop) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_q) return;
   uint32_t c[3];
@@ -1411,7 +1413,7 @@ __global__ __launch_bounds__(256) void k_qkeys(const float* __restrict__ q, uint
     u = (u == u) ? fminf(fmaxf(u, 0.0f), 1.0f) : 0.0f;
     c[k] = min((uint32_t)(u * 1024.0f), 1023u);
   }
-  keys[i] = (expand10q(c[0]) << 2) | (expand10q(c[1]) << 1) | expand10q(c[2]);
+  keys[i] = (((expand10q(c[0]) << 2) | (expand10q(c[1]) << 1) | expand10q(c[2])) >> drop) << drop;
   vals[i] = i;
 }
 // Seed lattice for generic queries: QL^3 cells over the query bounding box (description kept on the device).
@@ -1482,13 +1484,23 @@ __global__ void k_qtable_mode(uint32_t* __restrict__ table, uint32_t n, uint32_t
 
 // (centre, radius) of the bounding box of every packet's queries: one wave per packet.  The radius is rounded up; a packet
 // with a non-finite coordinate gets radius inf (its cut list then keeps the whole tree).
-__global__ __launch_bounds__(256) void k_qpacket_bounds(const float4* __restrict__ sorted, const uint32_t* __restrict__ table,
-                                                        uint32_t n_q, uint32_t launched, float4* __restrict__ centres) {
+// `raw` != nullptr: the kernel also brings the packet's queries into sorted order (sorted[i] = raw[perm[i]]; the packets partition the
+// sorted range, so every query is written once) — the gather that k_qgather does in a pass of its own otherwise.
+__global__ __launch_bounds__(256) void k_qpacket_bounds(float4* __restrict__ sorted, const uint32_t* __restrict__ table,
+                                                        uint32_t n_q, uint32_t launched, float4* __restrict__ centres,
+                                                        const float* __restrict__ raw, const uint32_t* __restrict__ perm) {
   const uint32_t packet = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
   if (packet >= launched) return;
   uint32_t first, cnt;
   if (!query_packet_range(table, packet, n_q, &first, &cnt)) return;
-  const float4 v = sorted[first + min(lane, cnt - 1u)];
+  float4 v;
+  if (raw != nullptr) {
+    const size_t s = perm[first + min(lane, cnt - 1u)];
+    v = make_float4(raw[3 * s], raw[3 * s + 1], raw[3 * s + 2], 0.0f);
+    if (lane < cnt) sorted[first + lane] = v;
+  } else {
+    v = sorted[first + min(lane, cnt - 1u)];
+  }
   float lo[3] = {v.x, v.y, v.z}, hi[3] = {v.x, v.y, v.z};
   bool bad = !(fabsf(v.x) < 3.0e37f) | !(fabsf(v.y) < 3.0e37f) | !(fabsf(v.z) < 3.0e37f);
   for (int o = 32; o >= 1; o >>= 1)
@@ -1866,21 +1878,16 @@ size_t query_workspace_bytes(size_t n_q) {
   return n * (8 + 8 + 4 + 4 + 16 + 1 + 4) + (n / 32 + 64) * (16 + 4 * CUT_WORDS) + tmp + sel + 21 * 256 + (size_t)64 * 64 * 64 * 44 + 8192 + 24 * 1024 + 256;
 }
 
-int launch_query_distance(Arena& ws, hipStream_t st, const DeviceMesh& mesh, const float* d_queries, size_t n_q,
-                          int mode, int sign_src, int algorithm, float* d_out, int* d_err) {
-  if (n_q == 0) return 0;
-  GridParams g{};
+// Generic queries in two parts.  prepare_query_walk needs the queries only — bounding box, Morton keys, sort, packet table, the
+// packets' centres and the gather into sorted order — so a one-shot call runs it on a side stream BESIDE the LBVH build (capi.hip:
+// 0.8 ms of bandwidth-bound passes next to 0.24 ms of latency-bound launches for 10 M queries x 100 k triangles); launch_query_walk
+// needs the tree: seed lattice, cut lists, walk.  launch_query_distance is both on one stream (persistent meshes, asynchronous calls).
+int prepare_query_walk(Arena& ws, hipStream_t st, const float* d_queries, size_t n_q, size_t n_tris, int sign_src, int algorithm, QueryPlan* plan) {
+  *plan = QueryPlan{};
+  plan->n_q = n_q;
+  if (n_q == 0 || algorithm == 1) return 0;
   const uint32_t nq = (uint32_t)n_q;
   const uint32_t packets = (nq + 63) / 64;
-  if (algorithm == 1) {
-    if (mode == MODE_UNSIGNED && sign_src == SIGN_XRAY_ALL) launch_brute<false, MODE_UNSIGNED, SIGN_XRAY_ALL>(st, mesh, g, d_queries, nq, nullptr, d_out, d_err, packets);
-    else if (mode == MODE_UNSIGNED && sign_src == SIGN_RAYS3) launch_brute<false, MODE_UNSIGNED, SIGN_RAYS3>(st, mesh, g, d_queries, nq, nullptr, d_out, d_err, packets);
-    else if (mode == MODE_UNSIGNED) launch_brute<false, MODE_UNSIGNED, SIGN_NONE>(st, mesh, g, d_queries, nq, nullptr, d_out, d_err, packets);
-    else if (mode == MODE_NORMAL_FOLD) launch_brute<false, MODE_NORMAL_FOLD, SIGN_NONE>(st, mesh, g, d_queries, nq, nullptr, d_out, d_err, packets);
-    else launch_brute<false, MODE_NEAREST_NORMAL, SIGN_NONE>(st, mesh, g, d_queries, nq, nullptr, d_out, d_err, packets);
-    M2S_HIP_CHECK(hipGetLastError());
-    return 0;
-  }
   // Morton order
   int* qb = ws.take<int>(8 + 6 * QB_BLOCKS);
   uint32_t* keys = ws.take<uint32_t>(n_q);
@@ -1895,21 +1902,25 @@ int launch_query_distance(Arena& ws, hipStream_t st, const DeviceMesh& mesh, con
     set_error("internal: query workspace too small");
     return M2S_ERR_HIP_INTERNAL;
   }
+  // key bits that matter: cells of ~8 queries at the finest level, whole Morton triples, 12 ... 30 (M2S_QUERY_KEY_BITS overrides)
+  uint32_t bits = 12;
+  while (bits < (uint32_t)QKEY_BITS && (1ull << bits) * 8ull < (unsigned long long)n_q) bits += 3;
+  if (getenv("M2S_QUERY_KEY_BITS")) bits = (uint32_t)std::min(QKEY_BITS, std::max(3, atoi(getenv("M2S_QUERY_KEY_BITS")) / 3 * 3));
+  const uint32_t drop = (uint32_t)QKEY_BITS - bits;
   const unsigned B = 256, nb = (nq + B - 1) / B;
   const unsigned qblocks = nb < QB_BLOCKS ? nb : QB_BLOCKS;
   hipLaunchKernelGGL(k_qbounds, dim3(qblocks), dim3(B), 0, st, d_queries, nq, qb + 8);
   hipLaunchKernelGGL(k_qbounds_final, dim3(1), dim3(B), 0, st, qb + 8, qblocks, qb);
-  hipLaunchKernelGGL(k_qkeys, dim3(nb), dim3(B), 0, st, d_queries, nq, qb, keys, vals);
-  M2S_HIP_CHECK(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, keys2, vals, perm, n_q, 0, QKEY_BITS, st));
-  hipLaunchKernelGGL(k_qgather, dim3(nb), dim3(B), 0, st, d_queries, perm, nq, sorted);
+  hipLaunchKernelGGL(k_qkeys, dim3(nb), dim3(B), 0, st, d_queries, nq, qb, keys, vals, drop);
+  M2S_HIP_CHECK(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, keys2, vals, perm, n_q, drop, QKEY_BITS, st));
   // Sparse query sets take the lane walk (k_lane_q).  Measured crossover, uniform queries in the extended box (lane / packet walk,
   // RtreeBvh): blob-100k 100 k queries 1.36 / 3.65 ms, 1 M 2.70 / 3.45, 3 M 5.00 / 4.38, 10 M 12.3 / 6.7 (crossover ~2 M);
   // blob-1M 1 M 6.3 / 12.8 ms, 10 M 26.4 / 22.4 (~7 M).  Below it the packet walk lasts as long as its worst packet's chain of
   // dependent loads (2.7 ms), above it the lane walk's divergence costs more than the packets' union.  n* ~ 3500 T^0.55 fits both.
   const int lane_env = getenv("M2S_LANE_WALK") ? atoi(getenv("M2S_LANE_WALK")) : -1;   // -1 auto, 0 never, 1 always (read per call: the tests switch it)
   const double lane_coeff = getenv("M2S_QUERY_LANE_COEFF") ? atof(getenv("M2S_QUERY_LANE_COEFF")) : 3500.0;
-  const bool lane_walk = mesh.n_tris && sign_src != SIGN_XRAY_ALL &&
-                         (lane_env >= 0 ? lane_env == 1 : (double)n_q < lane_coeff * pow((double)mesh.n_tris, 0.55));
+  const bool lane_walk = n_tris && sign_src != SIGN_XRAY_ALL &&
+                         (lane_env >= 0 ? lane_env == 1 : (double)n_q < lane_coeff * pow((double)n_tris, 0.55));
   // packets = leaves of the bucket k-d tree over the sorted keys (k_qcells); the launch has room for twice the consecutive
   // count, and k_qtable_mode falls back to consecutive packets should there be more
   const uint32_t* table = nullptr;
@@ -1929,11 +1940,51 @@ int launch_query_distance(Arena& ws, hipStream_t st, const DeviceMesh& mesh, con
     hipLaunchKernelGGL(k_qtable_mode, dim3(1), dim3(1), 0, st, tb, nq, launched);
     table = tb;
   }
+  static const bool use_seeds = !(getenv("M2S_SEEDS") && atoi(getenv("M2S_SEEDS")) == 0);
+  const bool seeds = use_seeds && n_tris && packets >= 8;
+  // cut lists, one per packet (k_cut<false>): they need the packets' centres, and the kernel that finds those gathers the queries too
+  const uint32_t qcut_min = getenv("M2S_QUERY_CUT_MIN") ? (uint32_t)atoi(getenv("M2S_QUERY_CUT_MIN")) : 20000u;
+  static const int cut_env = getenv("M2S_CUT") ? atoi(getenv("M2S_CUT")) : 1;
+  float4* centres = nullptr;
+  if (table != nullptr && seeds && cut_env > 0 && packets >= qcut_min) {
+    centres = ws.take<float4>(launched);
+    if (!centres) { set_error("internal: query workspace too small"); return M2S_ERR_HIP_INTERNAL; }
+    hipLaunchKernelGGL(k_qpacket_bounds, dim3((launched + 3) / 4), dim3(256), 0, st, sorted, table, nq, launched, centres, d_queries, (const uint32_t*)perm);
+  } else {
+    hipLaunchKernelGGL(k_qgather, dim3(nb), dim3(B), 0, st, d_queries, perm, nq, sorted);
+  }
+  M2S_HIP_CHECK(hipGetLastError());
+  plan->qb = qb; plan->perm = perm; plan->sorted = sorted; plan->table = table; plan->centres = centres;
+  plan->launched = launched; plan->lane_walk = lane_walk; plan->seeds = seeds;
+  return 0;
+}
+
+int launch_query_walk(Arena& ws, hipStream_t st, const DeviceMesh& mesh, const float* d_queries, const QueryPlan& plan,
+                      int mode, int sign_src, int algorithm, float* d_out, int* d_err) {
+  const size_t n_q = plan.n_q;
+  if (n_q == 0) return 0;
+  GridParams g{};
+  const uint32_t nq = (uint32_t)n_q;
+  const uint32_t packets = (nq + 63) / 64;
+  if (algorithm == 1) {
+    if (mode == MODE_UNSIGNED && sign_src == SIGN_XRAY_ALL) launch_brute<false, MODE_UNSIGNED, SIGN_XRAY_ALL>(st, mesh, g, d_queries, nq, nullptr, d_out, d_err, packets);
+    else if (mode == MODE_UNSIGNED && sign_src == SIGN_RAYS3) launch_brute<false, MODE_UNSIGNED, SIGN_RAYS3>(st, mesh, g, d_queries, nq, nullptr, d_out, d_err, packets);
+    else if (mode == MODE_UNSIGNED) launch_brute<false, MODE_UNSIGNED, SIGN_NONE>(st, mesh, g, d_queries, nq, nullptr, d_out, d_err, packets);
+    else if (mode == MODE_NORMAL_FOLD) launch_brute<false, MODE_NORMAL_FOLD, SIGN_NONE>(st, mesh, g, d_queries, nq, nullptr, d_out, d_err, packets);
+    else launch_brute<false, MODE_NEAREST_NORMAL, SIGN_NONE>(st, mesh, g, d_queries, nq, nullptr, d_out, d_err, packets);
+    M2S_HIP_CHECK(hipGetLastError());
+    return 0;
+  }
+  const int* qb = plan.qb;
+  const uint32_t* perm = plan.perm;
+  const float4* sorted = plan.sorted;
+  const uint32_t* table = plan.table;
+  const uint32_t launched = plan.launched;
+  const bool lane_walk = plan.lane_walk;
   // seeds: jump flooding over a QL^3 lattice on the query bounding box (as for the grid path)
   const uint32_t* seeds = nullptr;
   const GridParams* d_lat = nullptr;
-  static const bool use_seeds = !(getenv("M2S_SEEDS") && atoi(getenv("M2S_SEEDS")) == 0);
-  if (use_seeds && mesh.n_tris && packets >= 8) {
+  if (plan.seeds && mesh.n_tris) {
     const size_t cells = (size_t)QL * QL * QL;
     GridParams* lat = ws.take<GridParams>(1);
     unsigned long long* k64 = ws.take<unsigned long long>(cells);
@@ -1955,23 +2006,18 @@ int launch_query_distance(Arena& ws, hipStream_t st, const DeviceMesh& mesh, con
     seeds = ids;
     d_lat = lat;
   }
-  // cut lists, one per packet (k_cut<false>): the top of the tree is walked once per 64 neighbouring packets
   CutList cut = {nullptr, 0, 0, 0, 0, nullptr};
-  const uint32_t qcut_min = getenv("M2S_QUERY_CUT_MIN") ? (uint32_t)atoi(getenv("M2S_QUERY_CUT_MIN")) : 20000u;
-  static const int cut_env = getenv("M2S_CUT") ? atoi(getenv("M2S_CUT")) : 1;
-  if (table != nullptr && seeds != nullptr && cut_env > 0 && packets >= qcut_min) {
-    float4* centres = ws.take<float4>(launched);
+  if (plan.centres != nullptr && seeds != nullptr) {
     uint32_t* lists = ws.take<uint32_t>((size_t)launched * CUT_WORDS);
-    if (!centres || !lists) { set_error("internal: query workspace too small"); return M2S_ERR_HIP_INTERNAL; }
+    if (!lists) { set_error("internal: query workspace too small"); return M2S_ERR_HIP_INTERNAL; }
     const float emit_near = getenv("M2S_CUT_NEAR") ? (float)atof(getenv("M2S_CUT_NEAR")) : 2.0f;
     const float emit_far = getenv("M2S_CUT_FAR") ? (float)atof(getenv("M2S_CUT_FAR")) : 1.0f / 16.0f;
     uint32_t depth = 1;
     while ((1ull << depth) < (unsigned long long)mesh.n_tris + 1ull) ++depth;
     const uint32_t wave_cap = getenv("M2S_CUT_WAVE_CAP") ? (uint32_t)atoi(getenv("M2S_CUT_WAVE_CAP")) : std::max(120u, 20u * depth);
-    hipLaunchKernelGGL(k_qpacket_bounds, dim3((launched + 3) / 4), dim3(256), 0, st, sorted, table, nq, launched, centres);
     hipLaunchKernelGGL(k_cut<false>, dim3((launched + 63) / 64), dim3(64), 0, st, mesh, g, seeds, 0u, 0u, 0u, launched, 1u, 1u, lists,
-                       emit_near, emit_far, 100000u, wave_cap, (const float4*)centres, table, d_lat);
-    cut = {lists, 0, 0, 0, 0, centres};
+                       emit_near, emit_far, 100000u, wave_cap, (const float4*)plan.centres, table, d_lat);
+    cut = {lists, 0, 0, 0, 0, plan.centres};
   }
   if (lane_walk) {
     const unsigned lb = (nq + 255u) / 256u;
@@ -1989,6 +2035,14 @@ int launch_query_distance(Arena& ws, hipStream_t st, const DeviceMesh& mesh, con
   else launch_packet<false, MODE_NEAREST_NORMAL, SIGN_NONE>(st, mesh, g, sorted, perm, nq, table, d_out, d_err, launched, seeds, 0, 0, 0, d_lat, cut);
   M2S_HIP_CHECK(hipGetLastError());
   return 0;
+}
+
+int launch_query_distance(Arena& ws, hipStream_t st, const DeviceMesh& mesh, const float* d_queries, size_t n_q,
+                          int mode, int sign_src, int algorithm, float* d_out, int* d_err) {
+  QueryPlan plan;
+  const int rc = prepare_query_walk(ws, st, d_queries, n_q, mesh.n_tris, sign_src, algorithm, &plan);
+  if (rc) return rc;
+  return launch_query_walk(ws, st, mesh, d_queries, plan, mode, sign_src, algorithm, d_out, d_err);
 }
 
 // m2s_warmup: the first launch of a kernel of this translation unit makes the runtime load its code object (all its kernels).
