@@ -1140,12 +1140,38 @@ int m2s_generate_sdf(const float* vertices, size_t n_vertices, const void* indic
     if (!st->qprep_done) M2S_HIP_CHECK(hipEventCreateWithFlags(&st->qprep_done, hipEventDisableTiming));
     M2S_HIP_CHECK(hipEventRecord(st->fork_ev, c.stream));                 // the queries are on the device
     M2S_HIP_CHECK(hipStreamWaitEvent(st->side_stream, st->fork_ev, 0));
-    rc = prepare_query_walk(ws, st->side_stream, d_q, n_queries, n_tris, sign_src, algorithm, &qplan);
+    if (!st->qlat_done) M2S_HIP_CHECK(hipEventCreateWithFlags(&st->qlat_done, hipEventDisableTiming));
+    rc = prepare_query_walk(ws, st->side_stream, d_q, n_queries, n_tris, sign_src, algorithm, &qplan, st->qlat_done);
     if (rc) return rc;
     M2S_HIP_CHECK(hipEventRecord(st->qprep_done, st->side_stream));
   }
+  // ... and the seed lattice needs the centroids only: flooded on the third stream from the input-order centroids while the tree is
+  // built (the ids are translated to sorted slots behind the build, as on the grid path)
+  QuerySeeds qseeds;
+  bool seeds_beside = false;
+  const std::function<int(const float4*, const TriRec*, int)> seeds_beside_build = [&](const float4* cen_raw, const TriRec*, int phase) -> int {
+    if (!beside || !qplan.seeds) return 0;
+    if (phase == 0) {                                                     // the centroid kernel is enqueued: mark that point
+      if (!st->seeds_done) {
+        M2S_HIP_CHECK(hipEventCreateWithFlags(&st->seeds_done, hipEventDisableTiming));
+        M2S_HIP_CHECK(hipEventCreateWithFlags(&st->seeds_fork, hipEventDisableTiming));
+      }
+      M2S_HIP_CHECK(hipEventRecord(st->seeds_fork, c.stream));
+      return 0;
+    }
+    // phase 1: the caller's stream holds the keys, the sort and the hierarchy by now — the host's time for these twelve launches
+    if (!st->side_stream2) { if (const int prc = create_side_stream(&st->side_stream2)) return prc; }
+    M2S_HIP_CHECK(hipStreamWaitEvent(st->side_stream2, st->seeds_fork, 0));
+    M2S_HIP_CHECK(hipStreamWaitEvent(st->side_stream2, st->qlat_done, 0));
+    const int r = launch_query_seeds(ws, st->side_stream2, cen_raw, (uint32_t)n_tris, qplan, true, &qseeds);
+    if (r) return r;
+    M2S_HIP_CHECK(hipEventRecord(st->seeds_done, st->side_stream2));
+    seeds_beside = true;
+    return 0;
+  };
   DeviceMesh mesh;
-  rc = build_device_mesh(ws, c.stream, sm.d_verts, n_vertices, sm.d_indices, n_indices, index_bytes, topology, n_tris, d_err, &mesh);
+  rc = build_device_mesh(ws, c.stream, sm.d_verts, n_vertices, sm.d_indices, n_indices, index_bytes, topology, n_tris, d_err, &mesh,
+                         &seeds_beside_build, false);
   if (rc) return rc;
   hc.lap("build enqueued (code objects on a first call)");
   M2S_HIP_CHECK(hipEventRecord(st->ev[1], c.stream));
@@ -1155,11 +1181,12 @@ int m2s_generate_sdf(const float* vertices, size_t n_vertices, const void* indic
   if (rc) return rc;
   if (beside) {
     M2S_HIP_CHECK(hipStreamWaitEvent(c.stream, st->qprep_done, 0));
+    if (seeds_beside) M2S_HIP_CHECK(hipStreamWaitEvent(c.stream, st->seeds_done, 0));
   } else {
     rc = prepare_query_walk(ws, c.stream, d_q, n_queries, n_tris, sign_src, algorithm, &qplan);
     if (rc) return rc;
   }
-  rc = launch_query_walk(ws, c.stream, mesh, d_q, qplan, mode, sign_src, algorithm, d_out, d_err);
+  rc = launch_query_walk(ws, c.stream, mesh, d_q, qplan, mode, sign_src, algorithm, d_out, d_err, seeds_beside ? &qseeds : nullptr);
   if (rc) return rc;
   M2S_HIP_CHECK(hipEventRecord(st->ev[3], c.stream));
   rc = stats_end(c.stream, d_stats);

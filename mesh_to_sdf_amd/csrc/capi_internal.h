@@ -41,6 +41,7 @@ struct DeviceState {
   SeedLattice raw_seeds;
   hipEvent_t seeds_done = nullptr, seeds_fork = nullptr;
   bool have_raw_seeds = false;
+  hipEvent_t qlat_done = nullptr;     // ... and its bounding box + seed-lattice description are enqueued
   hipEvent_t qprep_done = nullptr;    // one-shot query calls: the query preparation (sort, packets) on the side stream has finished
   int* h_err = nullptr;  // pinned
   char* spare_mesh = nullptr;  // last destroyed m2s_mesh block, recycled by the next m2s_mesh_create

@@ -285,12 +285,20 @@ struct QueryPlan {
   const float4* sorted = nullptr;   // queries in Morton order
   const uint32_t* table = nullptr;  // packet table (k_qcells), nullptr: 64 consecutive queries per packet
   const float4* centres = nullptr;  // (centre, radius) per packet when cut lists will be used
+  const GridParams* lat = nullptr;  // seed lattice description (QL^3 cells over the queries' bounding box) when seeds will be used
   uint32_t launched = 0;
   bool lane_walk = false, seeds = false;
 };
-int prepare_query_walk(Arena& ws, hipStream_t st, const float* d_queries, size_t n_q, size_t n_tris, int sign_src, int algorithm, QueryPlan* plan);
+struct QuerySeeds {
+  uint32_t* ids = nullptr;          // one triangle per lattice cell
+  bool raw = false;                 // ids name input triangles (computed while the mesh was being built): translate through slot_of
+};
+// `after_lattice` (optional): recorded on `st` once the bounding box and the lattice description are enqueued (what launch_query_seeds needs)
+int prepare_query_walk(Arena& ws, hipStream_t st, const float* d_queries, size_t n_q, size_t n_tris, int sign_src, int algorithm, QueryPlan* plan,
+                       hipEvent_t after_lattice = nullptr);
+int launch_query_seeds(Arena& ws, hipStream_t st, const float4* cen, uint32_t n_tris, const QueryPlan& plan, bool raw, QuerySeeds* out);
 int launch_query_walk(Arena& ws, hipStream_t st, const DeviceMesh& mesh, const float* d_queries, const QueryPlan& plan,
-                      int mode, int sign_src, int algorithm, float* d_out, int* d_err);
+                      int mode, int sign_src, int algorithm, float* d_out, int* d_err, const QuerySeeds* pre = nullptr);
 int launch_query_distance(Arena& ws, hipStream_t st, const DeviceMesh& mesh, const float* d_queries, size_t n_q,
                           int mode, int sign_src, int algorithm, float* d_out, int* d_err);
 

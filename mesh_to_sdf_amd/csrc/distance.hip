@@ -1882,7 +1882,8 @@ size_t query_workspace_bytes(size_t n_q) {
 // packets' centres and the gather into sorted order — so a one-shot call runs it on a side stream BESIDE the LBVH build (capi.hip:
 // 0.8 ms of bandwidth-bound passes next to 0.24 ms of latency-bound launches for 10 M queries x 100 k triangles); launch_query_walk
 // needs the tree: seed lattice, cut lists, walk.  launch_query_distance is both on one stream (persistent meshes, asynchronous calls).
-int prepare_query_walk(Arena& ws, hipStream_t st, const float* d_queries, size_t n_q, size_t n_tris, int sign_src, int algorithm, QueryPlan* plan) {
+int prepare_query_walk(Arena& ws, hipStream_t st, const float* d_queries, size_t n_q, size_t n_tris, int sign_src, int algorithm, QueryPlan* plan,
+                       hipEvent_t after_lattice) {
   *plan = QueryPlan{};
   plan->n_q = n_q;
   if (n_q == 0 || algorithm == 1) return 0;
@@ -1911,6 +1912,15 @@ int prepare_query_walk(Arena& ws, hipStream_t st, const float* d_queries, size_t
   const unsigned qblocks = nb < QB_BLOCKS ? nb : QB_BLOCKS;
   hipLaunchKernelGGL(k_qbounds, dim3(qblocks), dim3(B), 0, st, d_queries, nq, qb + 8);
   hipLaunchKernelGGL(k_qbounds_final, dim3(1), dim3(B), 0, st, qb + 8, qblocks, qb);
+  static const bool use_seeds = !(getenv("M2S_SEEDS") && atoi(getenv("M2S_SEEDS")) == 0);
+  const bool seeds = use_seeds && n_tris && packets >= 8;
+  if (seeds) {                                   // the seed lattice's description: QL^3 cells over the queries' bounding box
+    GridParams* lat = ws.take<GridParams>(1);
+    if (!lat) { set_error("internal: query workspace too small"); return M2S_ERR_HIP_INTERNAL; }
+    hipLaunchKernelGGL(k_qlattice, dim3(1), dim3(64), 0, st, qb, lat);
+    plan->lat = lat;
+  }
+  if (after_lattice) M2S_HIP_CHECK(hipEventRecord(after_lattice, st));
   hipLaunchKernelGGL(k_qkeys, dim3(nb), dim3(B), 0, st, d_queries, nq, qb, keys, vals, drop);
   M2S_HIP_CHECK(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, keys2, vals, perm, n_q, drop, QKEY_BITS, st));
   // Sparse query sets take the lane walk (k_lane_q).  Measured crossover, uniform queries in the extended box (lane / packet walk,
@@ -1940,8 +1950,6 @@ int prepare_query_walk(Arena& ws, hipStream_t st, const float* d_queries, size_t
     hipLaunchKernelGGL(k_qtable_mode, dim3(1), dim3(1), 0, st, tb, nq, launched);
     table = tb;
   }
-  static const bool use_seeds = !(getenv("M2S_SEEDS") && atoi(getenv("M2S_SEEDS")) == 0);
-  const bool seeds = use_seeds && n_tris && packets >= 8;
   // cut lists, one per packet (k_cut<false>): they need the packets' centres, and the kernel that finds those gathers the queries too
   const uint32_t qcut_min = getenv("M2S_QUERY_CUT_MIN") ? (uint32_t)atoi(getenv("M2S_QUERY_CUT_MIN")) : 20000u;
   static const int cut_env = getenv("M2S_CUT") ? atoi(getenv("M2S_CUT")) : 1;
@@ -1959,8 +1967,40 @@ int prepare_query_walk(Arena& ws, hipStream_t st, const float* d_queries, size_t
   return 0;
 }
 
+// Seed lattice of a query set: jump flooding over the QL^3 cells of plan.lat from the centroids `cen` (the sorted array of the finished
+// mesh, or the input-order array while the mesh is being built: `ids` then name input triangles and launch_query_walk translates them).
+int launch_query_seeds(Arena& ws, hipStream_t st, const float4* cen, uint32_t n_tris, const QueryPlan& plan, bool raw, QuerySeeds* out) {
+  *out = QuerySeeds{};
+  if (!plan.seeds || plan.lat == nullptr || n_tris == 0) return 0;
+  DeviceMesh mesh{};
+  mesh.cen = cen;
+  mesh.n_tris = n_tris;
+  GridParams g{};
+  const size_t cells = (size_t)QL * QL * QL;
+  unsigned long long* k64 = ws.take<unsigned long long>(cells);
+  uint32_t* ids = ws.take<uint32_t>(cells);
+  float4* la = ws.take<float4>(cells);
+  float4* lb = ws.take<float4>(cells);
+  if (!k64 || !ids || !la || !lb) { set_error("internal: query workspace too small"); return M2S_ERR_HIP_INTERNAL; }
+  const GridParams* lat = plan.lat;
+  M2S_HIP_CHECK(hipMemsetAsync(k64, 0xff, cells * 8, st));
+  hipLaunchKernelGGL(k_jfa_splat, dim3((n_tris + 255) / 256), dim3(256), 0, st, mesh, g, lat, k64);
+  const unsigned nbl = (unsigned)((cells + 255) / 256);
+  hipLaunchKernelGGL(k_jfa_load, dim3(nbl), dim3(256), 0, st, mesh, k64, cells, la);
+  float4 *src = la, *dst = lb;
+  for (int step = QL / 2; step >= 1; step /= 2) {
+    hipLaunchKernelGGL(k_jfa_pass, dim3(nbl), dim3(256), 0, st, g, lat, src, dst, step, nullptr);
+    float4* t = src; src = dst; dst = t;
+  }
+  hipLaunchKernelGGL(k_jfa_pass, dim3(nbl), dim3(256), 0, st, g, lat, src, dst, 1, ids);
+  M2S_HIP_CHECK(hipGetLastError());
+  out->ids = ids;
+  out->raw = raw;
+  return 0;
+}
+
 int launch_query_walk(Arena& ws, hipStream_t st, const DeviceMesh& mesh, const float* d_queries, const QueryPlan& plan,
-                      int mode, int sign_src, int algorithm, float* d_out, int* d_err) {
+                      int mode, int sign_src, int algorithm, float* d_out, int* d_err, const QuerySeeds* pre) {
   const size_t n_q = plan.n_q;
   if (n_q == 0) return 0;
   GridParams g{};
@@ -1981,30 +2021,21 @@ int launch_query_walk(Arena& ws, hipStream_t st, const DeviceMesh& mesh, const f
   const uint32_t* table = plan.table;
   const uint32_t launched = plan.launched;
   const bool lane_walk = plan.lane_walk;
-  // seeds: jump flooding over a QL^3 lattice on the query bounding box (as for the grid path)
+  // seeds: jump flooding over a QL^3 lattice on the query bounding box (as for the grid path) — here, or beside the build (`pre`)
   const uint32_t* seeds = nullptr;
   const GridParams* d_lat = nullptr;
   if (plan.seeds && mesh.n_tris) {
-    const size_t cells = (size_t)QL * QL * QL;
-    GridParams* lat = ws.take<GridParams>(1);
-    unsigned long long* k64 = ws.take<unsigned long long>(cells);
-    uint32_t* ids = ws.take<uint32_t>(cells);
-    float4* la = ws.take<float4>(cells);
-    float4* lb = ws.take<float4>(cells);
-    if (!lat || !k64 || !ids || !la || !lb) { set_error("internal: query workspace too small"); return M2S_ERR_HIP_INTERNAL; }
-    hipLaunchKernelGGL(k_qlattice, dim3(1), dim3(64), 0, st, qb, lat);
-    M2S_HIP_CHECK(hipMemsetAsync(k64, 0xff, cells * 8, st));
-    hipLaunchKernelGGL(k_jfa_splat, dim3((mesh.n_tris + 255) / 256), dim3(256), 0, st, mesh, g, lat, k64);
-    const unsigned nbl = (unsigned)((cells + 255) / 256);
-    hipLaunchKernelGGL(k_jfa_load, dim3(nbl), dim3(256), 0, st, mesh, k64, cells, la);
-    float4 *src = la, *dst = lb;
-    for (int step = QL / 2; step >= 1; step /= 2) {
-      hipLaunchKernelGGL(k_jfa_pass, dim3(nbl), dim3(256), 0, st, g, lat, src, dst, step, nullptr);
-      float4* t = src; src = dst; dst = t;
+    QuerySeeds own;
+    if (pre == nullptr || pre->ids == nullptr) {
+      const int rc = launch_query_seeds(ws, st, mesh.cen, mesh.n_tris, plan, false, &own);
+      if (rc) return rc;
+      pre = &own;
+    } else if (pre->raw) {
+      const size_t cells = (size_t)QL * QL * QL;
+      hipLaunchKernelGGL(k_seed_remap, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, st, pre->ids, cells, mesh.slot_of, mesh.n_tris);
     }
-    hipLaunchKernelGGL(k_jfa_pass, dim3(nbl), dim3(256), 0, st, g, lat, src, dst, 1, ids);
-    seeds = ids;
-    d_lat = lat;
+    seeds = pre->ids;
+    d_lat = plan.lat;
   }
   CutList cut = {nullptr, 0, 0, 0, 0, nullptr};
   if (plan.centres != nullptr && seeds != nullptr) {
@@ -2040,9 +2071,9 @@ int launch_query_walk(Arena& ws, hipStream_t st, const DeviceMesh& mesh, const f
 int launch_query_distance(Arena& ws, hipStream_t st, const DeviceMesh& mesh, const float* d_queries, size_t n_q,
                           int mode, int sign_src, int algorithm, float* d_out, int* d_err) {
   QueryPlan plan;
-  const int rc = prepare_query_walk(ws, st, d_queries, n_q, mesh.n_tris, sign_src, algorithm, &plan);
+  const int rc = prepare_query_walk(ws, st, d_queries, n_q, mesh.n_tris, sign_src, algorithm, &plan, nullptr);
   if (rc) return rc;
-  return launch_query_walk(ws, st, mesh, d_queries, plan, mode, sign_src, algorithm, d_out, d_err);
+  return launch_query_walk(ws, st, mesh, d_queries, plan, mode, sign_src, algorithm, d_out, d_err, nullptr);
 }
 
 // m2s_warmup: the first launch of a kernel of this translation unit makes the runtime load its code object (all its kernels).
