@@ -2015,7 +2015,6 @@ int launch_query_walk(Arena& ws, hipStream_t st, const DeviceMesh& mesh, const f
     M2S_HIP_CHECK(hipGetLastError());
     return 0;
   }
-  const int* qb = plan.qb;
   const uint32_t* perm = plan.perm;
   const float4* sorted = plan.sorted;
   const uint32_t* table = plan.table;
