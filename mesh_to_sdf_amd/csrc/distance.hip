@@ -959,26 +959,100 @@ __global__ __launch_bounds__(256) void k_jfa_pass(GridParams g0, const GridParam
   uint32_t best = 0xffffffffu;
   float4 bc = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0xffffffffu));
   float bd = __builtin_inff();
+  // Nine records per x-plane are requested TOGETHER (clamped addresses, validity as a flag) and only then compared.  Written with a
+  // `continue` per out-of-range or empty neighbour the loop was a chain of 27 dependent memory round trips per point — 56 us per pass of
+  // the 512^3 call's lattice, 400 us for 1024^3, whatever the cache hit rate (an LDS-tiled form was no faster for the same reason).
+  const int n0 = (int)g.n[0], n1 = (int)g.n[1], n2 = (int)g.n[2];
+#pragma unroll
   for (int dx = -1; dx <= 1; ++dx) {
     const int xx = x + dx * step;
-    if (xx < 0 || xx >= (int)g.n[0]) continue;
-    for (int dy = -1; dy <= 1; ++dy) {
-      const int yy = y + dy * step;
-      if (yy < 0 || yy >= (int)g.n[1]) continue;
-      for (int dz = -1; dz <= 1; ++dz) {
-        const int zz = z + dz * step;
-        if (zz < 0 || zz >= (int)g.n[2]) continue;
-        const float4 c = in[((size_t)xx * g.n[1] + yy) * g.n[2] + zz];
-        const uint32_t cand = __float_as_uint(c.w);
-        if (cand == 0xffffffffu) continue;
-        const float ex = p.x - c.x, ey = p.y - c.y, ez = p.z - c.z;
-        const float d = __builtin_fmaf(ex, ex, __builtin_fmaf(ey, ey, ez * ez));
-        if (d < bd || (d == bd && cand < best)) { bd = d; best = cand; bc = c; }
-      }
+    const bool okx = xx >= 0 && xx < n0;
+    const size_t xbase = (size_t)min(max(xx, 0), n0 - 1) * (size_t)n1;
+    float4 c[9];
+    bool ok[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      const int yy = y + (k / 3 - 1) * step, zz = z + (k % 3 - 1) * step;
+      ok[k] = okx && yy >= 0 && yy < n1 && zz >= 0 && zz < n2;
+      c[k] = in[(xbase + (size_t)min(max(yy, 0), n1 - 1)) * (size_t)n2 + (size_t)min(max(zz, 0), n2 - 1)];
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      const uint32_t cand = __float_as_uint(c[k].w);
+      const float ex = p.x - c[k].x, ey = p.y - c[k].y, ez = p.z - c[k].z;
+      const float d = __builtin_fmaf(ex, ex, __builtin_fmaf(ey, ey, ez * ez));
+      const bool take = ok[k] && cand != 0xffffffffu && (d < bd || (d == bd && cand < best));
+      bd = take ? d : bd;
+      best = take ? cand : best;
+      bc.x = take ? c[k].x : bc.x;
+      bc.y = take ? c[k].y : bc.y;
+      bc.z = take ? c[k].z : bc.z;
+      bc.w = take ? c[k].w : bc.w;
     }
   }
   out[i] = bc;
   if (ids_out) ids_out[i] = best;
+}
+
+// The pass for lattices of fewer than 2^31 points, written for the VALU: the kernel above spends ~900 vector instructions per point —
+// 64-bit index arithmetic per neighbour, three compares and six selects per candidate — and is bound by exactly that (an LDS-tiled form
+// and one with all 27 loads in flight took the same 56 us per pass of the 512^3 call's lattice, 390 us for 1024^3).  Here a neighbour's
+// index is the point's own 32-bit index plus a wave-uniform offset, (distance bits, id) is one 64-bit key so that "nearer, or as near
+// with the smaller id" is one unsigned compare, only the key and the neighbour's number are carried (the winner's record is fetched
+// again at the end), and out-of-range neighbours are bits of a precomputed mask.  Same candidates, same tie rule: the same seeds.
+__global__ __launch_bounds__(256) void k_jfa_pass32(GridParams g, const float4* __restrict__ in, float4* __restrict__ out, int step,
+                                                    uint32_t* __restrict__ ids_out) {
+  const uint32_t n0 = g.n[0], n1 = g.n[1], n2 = g.n[2];
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= n0 * n1 * n2) return;
+  const uint32_t z = i % n2, xy = i / n2, y = xy % n1, x = xy / n1;
+  const f3 p = lattice_point(g, x, y, z);
+  const uint32_t s = (uint32_t)step;
+  // bit (3 a + b) of m[axis]... one flag per axis and direction: is the neighbour at -step / 0 / +step inside the lattice?
+  const bool okx[3] = {x >= s, true, x + s < n0}, oky[3] = {y >= s, true, y + s < n1}, okz[3] = {z >= s, true, z + s < n2};
+  const int sx = (int)(s * n1 * n2), sy = (int)(s * n2), sz = (int)s;
+  unsigned long long key = 0x7f800000ffffffffull;             // (+inf, no triangle)
+  uint32_t kbest = 13u;                                      // the point itself
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    float4 c[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      const bool ok = okx[a] && oky[k / 3] && okz[k % 3];
+      const int off = (a - 1) * sx + (k / 3 - 1) * sy + (k % 3 - 1) * sz;
+      c[k] = in[ok ? (uint32_t)((int)i + off) : i];            // an out-of-range neighbour reads the point's own record and is masked below
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      const bool ok = okx[a] && oky[k / 3] && okz[k % 3];
+      const uint32_t cand = __float_as_uint(c[k].w);
+      const float ex = p.x - c[k].x, ey = p.y - c[k].y, ez = p.z - c[k].z;
+      const float d = __builtin_fmaf(ex, ex, __builtin_fmaf(ey, ey, ez * ez));
+      // d >= +0 orders like its bit pattern; NaN (bits above +inf's) never wins, as `d < bd || d == bd` never held for it
+      const unsigned long long kk = ((unsigned long long)__float_as_uint(d) << 32) | cand;
+      const bool take = ok && cand != 0xffffffffu && kk < key;
+      key = take ? kk : key;
+      kbest = take ? (uint32_t)(9 * a + k) : kbest;
+    }
+  }
+  const uint32_t best = (uint32_t)key;
+  float4 bc = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0xffffffffu));
+  if (best != 0xffffffffu) {
+    const int a = (int)(kbest / 9u), k = (int)(kbest % 9u);
+    bc = in[(uint32_t)((int)i + (a - 1) * sx + (k / 3 - 1) * sy + (k % 3 - 1) * sz)];
+  }
+  out[i] = bc;
+  if (ids_out) ids_out[i] = best;
+}
+// One flooding pass over the lattice g (M2S_JFA32=0: always the general kernel).
+static void launch_jfa_pass(hipStream_t st, const GridParams& g, const float4* in, float4* out, int step, uint32_t* ids) {
+  static const bool fast = !(getenv("M2S_JFA32") && atoi(getenv("M2S_JFA32")) == 0);
+  const size_t total = (size_t)g.n[0] * g.n[1] * g.n[2];
+  const unsigned nb = (unsigned)((total + 255) / 256);
+  if (fast && total < (1ull << 30) && (unsigned long long)step * g.n[1] * g.n[2] < (1ull << 30))
+    hipLaunchKernelGGL(k_jfa_pass32, dim3(nb), dim3(256), 0, st, g, in, out, step, ids);
+  else
+    hipLaunchKernelGGL(k_jfa_pass, dim3(nb), dim3(256), 0, st, g, (const GridParams*)nullptr, in, out, step, ids);
 }
 
 // ---- k_lane_q: the lane walk for generic queries ---------------------------------------------
@@ -1660,12 +1734,11 @@ int launch_grid_seeds(Arena& ws, hipStream_t st, const float4* cen, uint32_t n_t
   int step = 1;
   while ((uint32_t)step * 2 < maxdim) step *= 2;
   float4 *src = la, *dst = lb;
-  const unsigned nb = (unsigned)((points1 + 255) / 256);
   for (; step >= 1; step /= 2) {
-    hipLaunchKernelGGL(k_jfa_pass, dim3(nb), dim3(256), 0, st, g1, nullptr, src, dst, step, nullptr);
+    launch_jfa_pass(st, g1, src, dst, step, nullptr);
     float4* t = src; src = dst; dst = t;
   }
-  hipLaunchKernelGGL(k_jfa_pass, dim3(nb), dim3(256), 0, st, g1, nullptr, src, dst, 1, ids);   // "JFA+1": one more unit pass; leaves the ids
+  launch_jfa_pass(st, g1, src, dst, 1, ids);   // "JFA+1": one more unit pass; leaves the ids
   uint32_t* dst_ids = ids;
   out->ids = dst_ids;
   out->ny = g1.n[1];
