@@ -1799,7 +1799,7 @@ int prepare_grid_walk(Arena& ws, hipStream_t st, const DeviceMesh& mesh, const G
   if (!brute && !lane_walk && seed1 != nullptr && cut_env > 0 && packets >= cut_min_packets) {
     // emission radius of a list entry: emit_near brick radii next to the surface, emit_far of the distance far from it
     const float emit_near = getenv("M2S_CUT_NEAR") ? (float)atof(getenv("M2S_CUT_NEAR")) : 2.0f;
-    const float emit_far = getenv("M2S_CUT_FAR") ? (float)atof(getenv("M2S_CUT_FAR")) : 1.0f / 16.0f;
+    const float emit_far = getenv("M2S_CUT_FAR") ? (float)atof(getenv("M2S_CUT_FAR")) : 1.0f / 32.0f;   // re-tuned at the end of round 3 (1/16 before): headline 9.19 -> 9.11 ms, 1024^3 x sheet-100k 92.95 -> 89.33 ms
     // A wave that has visited this many nodes lets its bricks emit whatever they meet next: the long union walks of the
     // regions with many near-ties (deep inside a round body) are the tail of the launch — on the 64-layer slab of an 8-GPU
     // rank, 4 waves per SIMD, they WERE its duration (0.39 -> 0.19 ms; 512^3: flat between 300 and 450, 200 costs the
@@ -2114,7 +2114,7 @@ int launch_query_walk(Arena& ws, hipStream_t st, const DeviceMesh& mesh, const f
     uint32_t* lists = ws.take<uint32_t>((size_t)launched * CUT_WORDS);
     if (!lists) { set_error("internal: query workspace too small"); return M2S_ERR_HIP_INTERNAL; }
     const float emit_near = getenv("M2S_CUT_NEAR") ? (float)atof(getenv("M2S_CUT_NEAR")) : 2.0f;
-    const float emit_far = getenv("M2S_CUT_FAR") ? (float)atof(getenv("M2S_CUT_FAR")) : 1.0f / 16.0f;
+    const float emit_far = getenv("M2S_CUT_FAR") ? (float)atof(getenv("M2S_CUT_FAR")) : 1.0f / 32.0f;   // re-tuned at the end of round 3 (1/16 before): headline 9.19 -> 9.11 ms, 1024^3 x sheet-100k 92.95 -> 89.33 ms
     uint32_t depth = 1;
     while ((1ull << depth) < (unsigned long long)mesh.n_tris + 1ull) ++depth;
     const uint32_t wave_cap = getenv("M2S_CUT_WAVE_CAP") ? (uint32_t)atoi(getenv("M2S_CUT_WAVE_CAP")) : std::max(120u, 20u * depth);
