@@ -1794,7 +1794,7 @@ int prepare_grid_walk(Arena& ws, hipStream_t st, const DeviceMesh& mesh, const G
   // gains, 512^3 gains 1.3 ms.  Read per call: the tests lower it to cover small grids.
   // (asynchronous calls are the pieces of a caller who pipelines them on two streams: k_cut then runs under the previous
   // piece's walk and pays from about half that size)
-  const uint32_t cut_min_packets = getenv("M2S_CUT_MIN_PACKETS") ? (uint32_t)atoi(getenv("M2S_CUT_MIN_PACKETS")) : (pipelined ? 100000u : 200000u);
+  const uint32_t cut_min_packets = getenv("M2S_CUT_MIN_PACKETS") ? (uint32_t)atoi(getenv("M2S_CUT_MIN_PACKETS")) : 100000u;   // (round 2: 200 000 for synchronous calls; re-measured with the 64-byte lists: 224^3 2.88 -> 2.75 ms, 192^3 2.41 -> 2.38, 160^3 2.04 -> 2.07)
   static const int cut_env = getenv("M2S_CUT") ? atoi(getenv("M2S_CUT")) : 1;   // 0 = off
   if (!brute && !lane_walk && seed1 != nullptr && cut_env > 0 && packets >= cut_min_packets) {
     // emission radius of a list entry: emit_near brick radii next to the surface, emit_far of the distance far from it
