@@ -382,7 +382,8 @@ __global__ __launch_bounds__(256) void k_packet(DeviceMesh mesh, GridParams g, c
                                                 const GridParams* __restrict__ seed_lattice, CutList cut, PeerOut peers, float mix_thr) {
   const int lane = threadIdx.x & 63;
   const uint32_t block = xcd_remap(blockIdx.x, chunk);
-  const uint32_t packet = block * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  // wave-uniform, and said so: the brick decode below (two divisions by multiplication, shifts, bounds) then runs on the scalar unit
+  const uint32_t packet = (uint32_t)__builtin_amdgcn_readfirstlane((int)(block * (blockDim.x >> 6) + (threadIdx.x >> 6)));
   if (packet >= n_packets) return;
 
   f3 p;
