@@ -49,7 +49,7 @@ extern "C" {
 #endif
 
 #define M2S_VERSION_MAJOR 0
-#define M2S_VERSION_MINOR 4   /* 0.4: + m2s_warmup, m2s_peer_bandwidth, m2s_balanced_slabs, M2S_PART_ADAPTIVE, m2s_multi_opts.partition_used / slabs (additive) */
+#define M2S_VERSION_MINOR 5   /* 0.5: + m2s_tuning_set, m2s_tuning_describe; 0.4: + m2s_warmup, m2s_peer_bandwidth, m2s_balanced_slabs, M2S_PART_ADAPTIVE, m2s_multi_opts.partition_used / slabs (additive) */
 
 /* Return codes.  The reference panics where this ABI returns a negative code; the Rust shim
  * turns a negative code back into panic!(m2s_last_error()). */
@@ -416,6 +416,14 @@ int m2s_device_count(void);          /* HIP devices visible; 0 if none (every co
 const char* m2s_last_error(void);    /* thread-local message of the last failing call on this thread */
 /* Drops the cached per-device workspace (device memory is otherwise kept between calls). */
 void m2s_release_workspace(void);
+/* Run-time knobs (mesh_to_sdf_amd/csrc/tuning.h lists them; DESIGN.md §9 says what each default rests on).  They are read from the
+ * environment variables of the same names ONCE, at the library's first use; m2s_tuning_set changes one afterwards (value NULL or "" =
+ * back to the default) and returns M2S_ERR_BAD_ARG for an unknown name or an unparsable value.  None of them changes a result — they
+ * choose between code paths that produce the same bits, which is what the tests use them for.  Not synchronised with calls in flight
+ * on other threads.  m2s_tuning_describe writes "NAME=value" lines (NUL-terminated, truncated to `capacity`) and returns the length
+ * the full text needs. */
+int m2s_tuning_set(const char* name, const char* value);
+int m2s_tuning_describe(char* buffer, int capacity);
 
 #ifdef __cplusplus
 }

@@ -161,6 +161,8 @@ EXPORTS = [
     "m2s_ipc_export",
     "m2s_ipc_open",
     "m2s_ipc_close",
+    "m2s_tuning_set",
+    "m2s_tuning_describe",
 ]
 
 
@@ -171,6 +173,57 @@ def build(force=False):
         args.append("-B")
     subprocess.check_call(args)
     return SO_PATH
+
+
+def _prototypes():
+    """name -> (restype, argtypes) of every symbol include/m2s.h declares."""
+    return {
+        "m2s_generate_sdf": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(M2SOpts)]),
+        "m2s_generate_grid_sdf": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.POINTER(M2SGrid), C.c_int, C.c_void_p, C.POINTER(M2SOpts)]),
+        "m2s_grid_from_bounding_box": (None, [C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_uint64), C.POINTER(M2SGrid)]),
+        "m2s_grid_cell_center": (None, [C.POINTER(M2SGrid), C.POINTER(C.c_uint64), C.POINTER(C.c_float)]),
+        "m2s_grid_cell_idx": (C.c_uint64, [C.POINTER(M2SGrid), C.POINTER(C.c_uint64)]),
+        "m2s_triangle_count": (C.c_size_t, [C.c_size_t, C.c_size_t, C.c_int, C.c_int]),
+        "m2s_warmup": (C.c_int, [C.c_int, C.c_size_t, C.c_size_t]),
+        "m2s_version": (C.c_int, []),
+        "m2s_device_count": (C.c_int, []),
+        "m2s_last_error": (C.c_char_p, []),
+        "m2s_release_workspace": (None, []),
+        "m2s_mesh_create": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.POINTER(M2SOpts), C.POINTER(C.c_void_p)]),
+        "m2s_mesh_destroy": (None, [C.c_void_p]),
+        "m2s_mesh_triangle_count": (C.c_size_t, [C.c_void_p]),
+        "m2s_mesh_generate_grid_sdf": (C.c_int, [C.c_void_p, C.POINTER(M2SGrid), C.c_int, C.c_void_p, C.POINTER(M2SOpts)]),
+        "m2s_mesh_generate_sdf": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(M2SOpts)]),
+        "m2s_mesh_drain_timings": (C.c_int, [C.c_void_p, C.POINTER(M2STimings)]),
+        "m2s_sdf_grid_encoded_size": (C.c_size_t, [C.POINTER(M2SGrid), C.c_size_t]),
+        "m2s_sdf_generic_encoded_size": (C.c_size_t, [C.c_size_t, C.c_size_t]),
+        "m2s_sdf_encode_grid": (C.c_int, [C.POINTER(M2SGrid), C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(M2SOpts)]),
+        "m2s_sdf_encode_generic": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(M2SOpts)]),
+        "m2s_sdf_probe": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(M2SSdfInfo), C.POINTER(M2SOpts)]),
+        "m2s_sdf_decode": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.POINTER(M2SOpts)]),
+        "m2s_sdf_save_grid": (C.c_int, [C.c_char_p, C.POINTER(M2SGrid), C.c_void_p, C.c_size_t, C.POINTER(M2SOpts)]),
+        "m2s_sdf_save_generic": (C.c_int, [C.c_char_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(M2SOpts)]),
+        "m2s_sdf_probe_file": (C.c_int, [C.c_char_p, C.POINTER(M2SSdfInfo)]),
+        "m2s_sdf_read_file": (C.c_int, [C.c_char_p, C.c_void_p, C.c_void_p, C.POINTER(M2SOpts)]),
+        "m2s_order_cells_by_distance": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_float), C.POINTER(M2SOpts)]),
+        "m2s_merge_instances": (C.c_int, [C.POINTER(M2SInstance), C.c_size_t, C.c_void_p, C.c_void_p, C.POINTER(C.c_float), C.POINTER(M2SOpts)]),
+        "m2s_gltf_open": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(M2SGltfInfo)]),
+        "m2s_gltf_instances": (C.c_int, [C.c_void_p, C.POINTER(M2SInstance), C.c_size_t]),
+        "m2s_gltf_close": (None, [C.c_void_p]),
+        "m2s_generate_grid_sdf_multi": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.POINTER(M2SGrid), C.c_int, C.POINTER(C.c_void_p), C.POINTER(M2SMultiOpts)]),
+        "m2s_generate_sdf_multi": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(M2SMultiOpts)]),
+        "m2s_slab_bounds": (None, [C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+        "m2s_peer_bandwidth": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_uint32, C.c_size_t, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+        "m2s_balanced_slabs": (C.c_int, [C.c_uint64, C.c_int, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_float), C.POINTER(C.c_uint64)]),
+        "m2s_interleaved_slab": (C.c_int, [C.POINTER(M2SGrid), C.c_int, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+        "m2s_shared_alloc": (C.c_int, [C.c_size_t, C.c_int, C.POINTER(C.c_void_p)]),
+        "m2s_shared_free": (C.c_int, [C.c_void_p, C.c_int]),
+        "m2s_ipc_export": (C.c_int, [C.c_void_p, C.c_char_p]),
+        "m2s_ipc_open": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]),
+        "m2s_ipc_close": (C.c_int, [C.c_void_p, C.c_int]),
+        "m2s_tuning_set": (C.c_int, [C.c_char_p, C.c_char_p]),
+        "m2s_tuning_describe": (C.c_int, [C.c_char_p, C.c_int]),
+    }
 
 
 _lib = None
@@ -192,103 +245,58 @@ def lib():
         except ImportError:
             pass
         L = C.CDLL(SO_PATH)
-        L.m2s_generate_sdf.restype = C.c_int
-        L.m2s_generate_sdf.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p,
-                                       C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(M2SOpts)]
-        L.m2s_generate_grid_sdf.restype = C.c_int
-        L.m2s_generate_grid_sdf.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_int,
-                                            C.POINTER(M2SGrid), C.c_int, C.c_void_p, C.POINTER(M2SOpts)]
-        L.m2s_grid_from_bounding_box.restype = None
-        L.m2s_grid_from_bounding_box.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_uint64), C.POINTER(M2SGrid)]
-        L.m2s_grid_cell_center.restype = None
-        L.m2s_grid_cell_center.argtypes = [C.POINTER(M2SGrid), C.POINTER(C.c_uint64), C.POINTER(C.c_float)]
-        L.m2s_grid_cell_idx.restype = C.c_uint64
-        L.m2s_grid_cell_idx.argtypes = [C.POINTER(M2SGrid), C.POINTER(C.c_uint64)]
-        L.m2s_triangle_count.restype = C.c_size_t
-        L.m2s_triangle_count.argtypes = [C.c_size_t, C.c_size_t, C.c_int, C.c_int]
-        if os.environ.get("M2S_LIB") and not hasattr(L, "m2s_warmup"):
-            # an A/B build of an OLDER library (tools/exp_ab.py): it lacks the entry points added since; the old ones are all the A/B uses
-            _lib = L
-            return L
-        L.m2s_warmup.restype = C.c_int
-        L.m2s_warmup.argtypes = [C.c_int, C.c_size_t, C.c_size_t]
-        L.m2s_version.restype = C.c_int
-        L.m2s_device_count.restype = C.c_int
-        L.m2s_last_error.restype = C.c_char_p
-        L.m2s_release_workspace.restype = None
-        L.m2s_mesh_create.restype = C.c_int
-        L.m2s_mesh_create.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.POINTER(M2SOpts),
-                                      C.POINTER(C.c_void_p)]
-        L.m2s_mesh_destroy.restype = None
-        L.m2s_mesh_destroy.argtypes = [C.c_void_p]
-        L.m2s_mesh_triangle_count.restype = C.c_size_t
-        L.m2s_mesh_triangle_count.argtypes = [C.c_void_p]
-        L.m2s_mesh_generate_grid_sdf.restype = C.c_int
-        L.m2s_mesh_generate_grid_sdf.argtypes = [C.c_void_p, C.POINTER(M2SGrid), C.c_int, C.c_void_p, C.POINTER(M2SOpts)]
-        L.m2s_mesh_generate_sdf.restype = C.c_int
-        L.m2s_mesh_generate_sdf.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p,
-                                            C.POINTER(C.c_size_t), C.POINTER(M2SOpts)]
-        L.m2s_mesh_drain_timings.restype = C.c_int
-        L.m2s_mesh_drain_timings.argtypes = [C.c_void_p, C.POINTER(M2STimings)]
-        L.m2s_sdf_grid_encoded_size.restype = C.c_size_t
-        L.m2s_sdf_grid_encoded_size.argtypes = [C.POINTER(M2SGrid), C.c_size_t]
-        L.m2s_sdf_generic_encoded_size.restype = C.c_size_t
-        L.m2s_sdf_generic_encoded_size.argtypes = [C.c_size_t, C.c_size_t]
-        L.m2s_sdf_encode_grid.restype = C.c_int
-        L.m2s_sdf_encode_grid.argtypes = [C.POINTER(M2SGrid), C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
-                                          C.POINTER(C.c_size_t), C.POINTER(M2SOpts)]
-        L.m2s_sdf_encode_generic.restype = C.c_int
-        L.m2s_sdf_encode_generic.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
-                                             C.POINTER(C.c_size_t), C.POINTER(M2SOpts)]
-        L.m2s_sdf_probe.restype = C.c_int
-        L.m2s_sdf_probe.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(M2SSdfInfo), C.POINTER(M2SOpts)]
-        L.m2s_sdf_decode.restype = C.c_int
-        L.m2s_sdf_decode.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.POINTER(M2SOpts)]
-        L.m2s_sdf_save_grid.restype = C.c_int
-        L.m2s_sdf_save_grid.argtypes = [C.c_char_p, C.POINTER(M2SGrid), C.c_void_p, C.c_size_t, C.POINTER(M2SOpts)]
-        L.m2s_sdf_save_generic.restype = C.c_int
-        L.m2s_sdf_save_generic.argtypes = [C.c_char_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(M2SOpts)]
-        L.m2s_sdf_probe_file.restype = C.c_int
-        L.m2s_sdf_probe_file.argtypes = [C.c_char_p, C.POINTER(M2SSdfInfo)]
-        L.m2s_sdf_read_file.restype = C.c_int
-        L.m2s_sdf_read_file.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.POINTER(M2SOpts)]
-        L.m2s_order_cells_by_distance.restype = C.c_int
-        L.m2s_order_cells_by_distance.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_float), C.POINTER(M2SOpts)]
-        L.m2s_merge_instances.restype = C.c_int
-        L.m2s_merge_instances.argtypes = [C.POINTER(M2SInstance), C.c_size_t, C.c_void_p, C.c_void_p, C.POINTER(C.c_float),
-                                          C.POINTER(M2SOpts)]
-        L.m2s_gltf_open.restype = C.c_int
-        L.m2s_gltf_open.argtypes = [C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(M2SGltfInfo)]
-        L.m2s_gltf_instances.restype = C.c_int
-        L.m2s_gltf_instances.argtypes = [C.c_void_p, C.POINTER(M2SInstance), C.c_size_t]
-        L.m2s_gltf_close.restype = None
-        L.m2s_gltf_close.argtypes = [C.c_void_p]
-        L.m2s_generate_grid_sdf_multi.restype = C.c_int
-        L.m2s_generate_grid_sdf_multi.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_int,
-                                                  C.POINTER(M2SGrid), C.c_int, C.POINTER(C.c_void_p), C.POINTER(M2SMultiOpts)]
-        L.m2s_generate_sdf_multi.restype = C.c_int
-        L.m2s_generate_sdf_multi.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_size_t,
-                                             C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(M2SMultiOpts)]
-        L.m2s_slab_bounds.restype = None
-        L.m2s_slab_bounds.argtypes = [C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
-        L.m2s_peer_bandwidth.restype = C.c_int
-        L.m2s_peer_bandwidth.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_uint32, C.c_size_t, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]
-        L.m2s_balanced_slabs.restype = C.c_int
-        L.m2s_balanced_slabs.argtypes = [C.c_uint64, C.c_int, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_float), C.POINTER(C.c_uint64)]
-        L.m2s_interleaved_slab.restype = C.c_int
-        L.m2s_interleaved_slab.argtypes = [C.POINTER(M2SGrid), C.c_int, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
-        L.m2s_shared_alloc.restype = C.c_int
-        L.m2s_shared_alloc.argtypes = [C.c_size_t, C.c_int, C.POINTER(C.c_void_p)]
-        L.m2s_shared_free.restype = C.c_int
-        L.m2s_shared_free.argtypes = [C.c_void_p, C.c_int]
-        L.m2s_ipc_export.restype = C.c_int
-        L.m2s_ipc_export.argtypes = [C.c_void_p, C.c_char_p]
-        L.m2s_ipc_open.restype = C.c_int
-        L.m2s_ipc_open.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]
-        L.m2s_ipc_close.restype = C.c_int
-        L.m2s_ipc_close.argtypes = [C.c_void_p, C.c_int]
+        older = bool(os.environ.get("M2S_LIB"))   # an A/B build of an OLDER library (tools/exp_ab.py) may lack the newest entry points
+        for name, (restype, argtypes) in _prototypes().items():
+            if older and not hasattr(L, name):
+                continue                      # only the missing symbol is skipped: everything the old library has keeps its types
+            fn = getattr(L, name)
+            fn.restype = restype
+            fn.argtypes = argtypes
         _lib = L
     return _lib
+
+
+def set_knob(name, value=None):
+    """m2s_tuning_set: one of the run-time knobs of csrc/tuning.h (value None = back to its default).  The library reads the
+    environment only once, at its first use; the tests and tools that switch walk flavours between calls go through here."""
+    L = lib()
+    if not hasattr(L, "m2s_tuning_set"):              # an older A/B library reads its knobs from the environment per call
+        if value is None:
+            os.environ.pop(name, None)
+        else:
+            os.environ[name] = str(value)
+        return
+    rc = L.m2s_tuning_set(name.encode(), None if value is None else str(value).encode())
+    if rc != M2S_OK:
+        raise ValueError(last_error())
+
+
+class knobs:
+    """with knobs(M2S_LANE_WALK=1, M2S_BRUTE_MAX=0): ...   — sets the knobs, puts the previous values back afterwards (nests)."""
+
+    def __init__(self, **kw):
+        self.kw = kw
+        self.before = {}
+
+    def __enter__(self):
+        if self.kw and hasattr(lib(), "m2s_tuning_describe"):
+            now = describe_knobs()
+            self.before = {k: now.get(k) for k in self.kw}
+        for k, v in self.kw.items():
+            set_knob(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        for k in self.kw:
+            set_knob(k, self.before.get(k))
+        return False
+
+
+def describe_knobs():
+    L = lib()
+    buf = C.create_string_buffer(4096)
+    L.m2s_tuning_describe(buf, 4096)
+    return dict(line.split("=", 1) for line in buf.value.decode().splitlines() if "=" in line)
 
 
 def last_error():

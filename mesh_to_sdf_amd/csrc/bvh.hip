@@ -6,12 +6,14 @@
 // only select candidates, the kernels in distance.hip take the exact minimum.
 //
 // Pipeline (all on the call's stream, no host round trip):
-//   k_tri_setup   : indices -> (a,b,c), degeneracy class, padded box (geo.rs:4-22), scene bounds
-//   k_morton      : 63-bit Morton key of the box centre
+//   k_tri_setup     : indices -> (a,b,c), degeneracy class, padded box (geo.rs:4-22), scene bounds
+//   k_morton_keys   : 63-bit Morton key of the box centre
 //   rocprim radix sort (key,value)            — library sort, not on the parity path
-//   k_karras      : Karras 2012 hierarchy over the sorted keys (ranges, children, parents)
-//   k_seg_level   : segment tree of leaf boxes, one launch per level (fence-free refit)
-//   k_emit        : node boxes by range query, pre-order index = 2*first + #left-turns, skip links
+//   k_roots_from_keys, k_treelet_lanes : sweep-split treelets of <= 64 triangles (their keys rewritten as path codes)
+//   k_karras        : Karras 2012 hierarchy over the sorted keys (ranges, children, parents)
+//   k_seg_build     : segment tree of leaf boxes (fence-free refit)
+//   k_emit          : node boxes by range query, pre-order index = 2*first + #left-turns, skip links
+//   k_node_ext      : oriented bound (disc-shaped slab) of every node
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
@@ -24,6 +26,7 @@
 #include "../../include/m2s.h"
 #include "common.h"
 #include "geo.hip.h"
+#include "tuning.h"
 
 namespace m2s {
 
@@ -97,7 +100,7 @@ __global__ __launch_bounds__(256) void k_tri_setup(const float* __restrict__ ver
     for (int k = 0; k < 3; ++k)
       if (cen[k] == cen[k] && fabsf(cen[k]) < 3.0e38f) { lo[k] = ord(cen[k]); hi[k] = lo[k]; }
   }
-  // block reduce (wave shuffles, then LDS); one partial per block, folded by k_scene_reduce:
+  // block reduce (wave shuffles, then LDS); one partial per block, folded by k_morton_keys:
   // no atomics, no serialisation on six hot addresses
   __shared__ int part[6][4];
   const int wv = threadIdx.x >> 6;
@@ -118,46 +121,6 @@ __global__ __launch_bounds__(256) void k_tri_setup(const float* __restrict__ ver
   }
 }
 
-// Folds the per-block partials into scene[0..5] (order-encoded min xyz / max xyz of the box centres).
-__global__ __launch_bounds__(256) void k_scene_reduce(int* __restrict__ scene, uint32_t n_blocks) {
-  __shared__ int part[6][4];
-  int lo[3] = {INT32_MAX, INT32_MAX, INT32_MAX}, hi[3] = {INT32_MIN, INT32_MIN, INT32_MIN};
-  for (uint32_t b = threadIdx.x; b < n_blocks; b += 256)
-    for (int k = 0; k < 3; ++k) {
-      lo[k] = min(lo[k], scene[6 + b * 6 + k]);
-      hi[k] = max(hi[k], scene[6 + b * 6 + 3 + k]);
-    }
-  const int wv = threadIdx.x >> 6;
-  for (int k = 0; k < 3; ++k) {
-    int l = lo[k], h = hi[k];
-    for (int off = 32; off > 0; off >>= 1) {
-      l = min(l, __shfl_xor(l, off));
-      h = max(h, __shfl_xor(h, off));
-    }
-    if ((threadIdx.x & 63) == 0) { part[k][wv] = l; part[3 + k][wv] = h; }
-  }
-  __syncthreads();
-  __shared__ int fin[6];
-  if (threadIdx.x < 6) {
-    const int k = threadIdx.x;
-    int v = part[k][0];
-    for (int w = 1; w < 4; ++w) v = k < 3 ? min(v, part[k][w]) : max(v, part[k][w]);
-    scene[k] = v;
-    fin[k] = v;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {   // scene[6]: largest finite |coordinate| as float bits (mesh_scale); the partials are dead now
-    float s = 0.0f;
-    for (int k = 0; k < 6; ++k) {
-      const int i = fin[k];
-      const float f = __int_as_float(i >= 0 ? i : i ^ 0x7fffffff);
-      if (f == f && fabsf(f) < 3.0e38f) s = fmaxf(s, fabsf(f));
-    }
-    scene[6] = __float_as_int(s);
-    scene[7] = 0;                          // number of treelet roots (k_treelet_roots counts into it)
-  }
-}
-
 __device__ __forceinline__ uint64_t expand21(uint32_t v) {
   uint64_t x = v & 0x1fffffu;
   x = (x | x << 32) & 0x1f00000000ffffull;
@@ -166,24 +129,6 @@ __device__ __forceinline__ uint64_t expand21(uint32_t v) {
   x = (x | x << 4) & 0x10c30c30c30c30c3ull;
   x = (x | x << 2) & 0x1249249249249249ull;
   return x;
-}
-
-__global__ __launch_bounds__(256) void k_morton(const Box* __restrict__ boxes, uint32_t n_tris,
-                                                const int* __restrict__ scene, uint64_t* __restrict__ keys,
-                                                uint32_t* __restrict__ vals) {
-  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= n_tris) return;
-  const Box bx = boxes[t];
-  const float c[3] = {0.5f * (bx.mnx + bx.mxx), 0.5f * (bx.mny + bx.mxy), 0.5f * (bx.mnz + bx.mxz)};
-  uint32_t q[3];
-  for (int k = 0; k < 3; ++k) {
-    const float lo = unord(scene[k]), hi = unord(scene[3 + k]);
-    float u = (c[k] - lo) / (hi - lo);
-    u = (u == u) ? fminf(fmaxf(u, 0.0f), 1.0f) : 0.0f;
-    q[k] = min((uint32_t)(u * 2097152.0f), 2097151u);
-  }
-  keys[t] = (expand21(q[0]) << 2) | (expand21(q[1]) << 1) | expand21(q[2]);
-  vals[t] = t;
 }
 
 // Karras 2012.  Keys may repeat; ties are broken by position, which keeps the tree well formed.
@@ -226,55 +171,6 @@ __global__ __launch_bounds__(256) void k_karras(const uint64_t* __restrict__ key
 __device__ __forceinline__ Box box_union(Box a, Box b) {
   return {fminf(a.mnx, b.mnx), fminf(a.mny, b.mny), fminf(a.mnz, b.mnz),
           fmaxf(a.mxx, b.mxx), fmaxf(a.mxy, b.mxy), fmaxf(a.mxz, b.mxz)};
-}
-
-// Level 0 of the segment tree: leaf boxes in sorted order.
-__global__ __launch_bounds__(256) void k_seg_level0(const Box* __restrict__ boxes, const uint32_t* __restrict__ order,
-                                                    int n, Box* __restrict__ seg) {
-  const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k < n) seg[k] = boxes[order[k]];
-}
-// Builds levels l+1, l+2, l+3 of the segment tree from level l in one launch: thread j owns entry j of
-// level l+3 = the union of (up to) 8 entries of level l, and writes the intermediate entries on the way.
-// LEAVES: level l is level 0 and does not exist yet — its entries are the leaf boxes in sorted order (boxes[order[k]]), written here too.
-template <bool LEAVES>
-__global__ __launch_bounds__(256) void k_seg_level3(Box* __restrict__ seg, uint32_t off0, uint32_t n0, uint32_t off1,
-                                                    uint32_t n1, uint32_t off2, uint32_t n2, uint32_t off3, uint32_t n3,
-                                                    const Box* __restrict__ boxes, const uint32_t* __restrict__ order) {
-  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;   // index at level l+3 (or the deepest level present)
-  Box b1[4];
-  bool have1[4];
-  for (uint32_t a = 0; a < 4; ++a) {
-    const uint32_t i1 = 4 * j + a;          // entry at level l+1
-    have1[a] = i1 < n1;
-    if (!have1[a]) continue;
-    Box b, c;
-    if (LEAVES) { b = boxes[order[2 * i1]]; seg[off0 + 2 * i1] = b; }
-    else b = seg[off0 + 2 * i1];
-    if (2 * i1 + 1 < n0) {
-      if (LEAVES) { c = boxes[order[2 * i1 + 1]]; seg[off0 + 2 * i1 + 1] = c; }
-      else c = seg[off0 + 2 * i1 + 1];
-      b = box_union(b, c);
-    }
-    b1[a] = b;
-    seg[off1 + i1] = b;
-  }
-  if (n2 == 0) return;
-  Box b2[2];
-  bool have2[2];
-  for (uint32_t a = 0; a < 2; ++a) {
-    const uint32_t i2 = 2 * j + a;          // entry at level l+2
-    have2[a] = i2 < n2;
-    if (!have2[a]) continue;
-    Box b = b1[2 * a];
-    if (have1[2 * a + 1]) b = box_union(b, b1[2 * a + 1]);
-    b2[a] = b;
-    seg[off2 + i2] = b;
-  }
-  if (n3 == 0 || j >= n3) return;
-  Box b = b2[0];
-  if (have2[1]) b = box_union(b, b2[1]);
-  seg[off3 + j] = b;
 }
 
 struct SegLevels {
@@ -541,172 +437,16 @@ __global__ __launch_bounds__(256) void k_node_ext(const NodeRec* __restrict__ no
 }
 
 // ---- treelet pass ---------------------------------------------------------------------------------------
-// The LBVH's top is fine, what costs node tests is how groups of 16-512 triangles are partitioned (DESIGN.md §4,
-// tools/exp_tree.py: LBVH splits down to nodes of <= 64 triangles with sweep splits inside them make the walk 5 % shorter).
-// k_treelet_roots lists the maximal LBVH nodes of at most TREELET_MAX triangles; k_treelet rebuilds each with one wave:
-// top-down, every segment split along the widest axis of its triangle-box centres at the position that minimises
-// (sum of box extents) x (triangle count) over both sides.  The triangles of the node are reordered inside its range
-// of the sorted arrays and their keys keep the node's Morton prefix followed by the path in the new treelet (prefix-free
-// codes), so the radix tree over the keys (k_karras, run again) is the old tree above the node and the new one inside.
-#ifndef M2S_TREELET_MAX
-#define M2S_TREELET_MAX 64
-#endif
-constexpr int TREELET_MAX = M2S_TREELET_MAX;
+// The LBVH's top is fine, what costs node tests is how groups of 16-512 triangles are partitioned (LBVH splits
+// down to nodes of <= 64 triangles with sweep splits inside them make the walk 5 % shorter).  k_roots_from_keys lists the maximal
+// LBVH nodes of at most TREELET_MAX triangles; k_treelet_lanes rebuilds each with one wave: top-down, every segment split along the
+// widest axis of its triangle-box centres at the position that minimises (sum of box extents) x (triangle count) over both sides.
+// The triangles of the node are reordered inside its range of the sorted arrays and their keys keep the node's Morton prefix
+// followed by the path in the new treelet (prefix-free codes), so the radix tree over the keys (k_karras) is the LBVH above the
+// node and the new treelet inside.
+constexpr int TREELET_MAX = 64;   // one wave holds a treelet's items in its lanes
 
-__global__ __launch_bounds__(256) void k_treelet_roots(int n, const int2* __restrict__ range, const int* __restrict__ parent,
-                                                        int2* __restrict__ roots, int* __restrict__ n_roots) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n - 1) return;
-  const int2 r = range[i];
-  const int cnt = r.y - r.x + 1;
-  if (cnt > TREELET_MAX || cnt < 3) return;
-  const int p = parent[i];
-  bool is_root = p == INT32_MIN;
-  if (!is_root) {
-    const int pi = p >= 0 ? p : -p - 2;
-    const int2 pr = range[pi];
-    is_root = pr.y - pr.x + 1 > TREELET_MAX;
-  }
-  if (is_root) roots[atomicAdd(n_roots, 1)] = make_int2(r.x, cnt);
-}
-// The same list with ONE atomic per block (40 000 device-scope atomics on one word took 151 us for 1 M triangles): the block's
-// roots are counted by ballots, one lane reserves the block's slots.  The order of the list is arbitrary either way.
-__global__ __launch_bounds__(256) void k_treelet_roots_block(int n, const int2* __restrict__ range, const int* __restrict__ parent,
-                                                             int2* __restrict__ roots, int* __restrict__ n_roots) {
-  __shared__ int s_wcnt[4], s_base;
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  bool is_root = false;
-  int2 r = make_int2(0, 0);
-  int cnt = 0;
-  if (i < n - 1) {
-    r = range[i];
-    cnt = r.y - r.x + 1;
-    if (cnt <= TREELET_MAX && cnt >= 3) {
-      const int p = parent[i];
-      is_root = p == INT32_MIN;
-      if (!is_root) {
-        const int pi = p >= 0 ? p : -p - 2;
-        const int2 pr = range[pi];
-        is_root = pr.y - pr.x + 1 > TREELET_MAX;
-      }
-    }
-  }
-  const unsigned long long bal = __ballot(is_root);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (lane == 0) s_wcnt[wave] = __popcll(bal);
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const int total = s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
-    s_base = total ? atomicAdd(n_roots, total) : 0;
-  }
-  __syncthreads();
-  if (is_root) {
-    int off = s_base + (int)__popcll(bal & ((1ull << lane) - 1ull));
-    for (int w = 0; w < wave; ++w) off += s_wcnt[w];
-    roots[off] = make_int2(r.x, cnt);
-  }
-}
-
-__global__ __launch_bounds__(TREELET_MAX) void k_treelet(const int2* __restrict__ roots, const int* __restrict__ n_roots,
-                                                const Box* __restrict__ boxes, uint64_t* __restrict__ keys,
-                                                uint32_t* __restrict__ order) {
-  // the treelet's items by POSITION (a segment is a contiguous range of positions, so a lane loops over its own segment only:
-  // the trip counts halve from level to level instead of staying at the treelet size)
-  __shared__ float s_box[6][TREELET_MAX];
-  __shared__ float s_cen[3][TREELET_MAX];
-  __shared__ int s_key[TREELET_MAX], s_rank[TREELET_MAX], s_cost[TREELET_MAX];
-  if ((int)blockIdx.x >= *n_roots) return;
-  const int2 root = roots[blockIdx.x];
-  const int first = root.x, m = root.y, lane = threadIdx.x;
-  const bool live = lane < m;
-  const uint64_t k_first = keys[first], k_last = keys[first + m - 1];
-  if (k_first == k_last) return;                                  // identical centres: no room below the prefix
-  const int prefix = __clzll((long long)(k_first ^ k_last));      // bits the node's keys share
-  const int room = 64 - prefix;                                   // bits left for the path inside the treelet
-  const uint32_t tri = live ? order[first + lane] : 0u;
-  const uint64_t old_key = live ? keys[first + lane] : 0ull;
-  Box b = {0, 0, 0, 0, 0, 0};
-  if (live) b = boxes[tri];
-  const float cen[3] = {0.5f * (b.mnx + b.mxx), 0.5f * (b.mny + b.mxy), 0.5f * (b.mnz + b.mxz)};
-  const int ck[3] = {ord(cen[0]), ord(cen[1]), ord(cen[2])};      // total order, NaN included
-  int pos = lane, s = 0, e = live ? m : 0;                        // my position; my segment [s, e) of positions
-  uint64_t code = 0;
-  int depth = 0;
-  for (int level = 0; level < 64; ++level) {
-    const bool open = live && e - s > 1 && depth < room;
-    if (__syncthreads_or(open ? 1 : 0) == 0) break;
-    if (live) {
-      s_box[0][pos] = b.mnx; s_box[1][pos] = b.mny; s_box[2][pos] = b.mnz; s_box[3][pos] = b.mxx; s_box[4][pos] = b.mxy; s_box[5][pos] = b.mxz;
-      s_cen[0][pos] = cen[0]; s_cen[1][pos] = cen[1]; s_cen[2][pos] = cen[2];
-    }
-    __syncthreads();
-    // widest axis of the centres of my segment
-    int axis = 2;
-    if (open) {
-      float mn0 = __builtin_inff(), mn1 = mn0, mn2 = mn0, mx0 = -mn0, mx1 = -mn0, mx2 = -mn0;
-      for (int j = s; j < e; ++j) {
-        const float ox = s_cen[0][j], oy = s_cen[1][j], oz = s_cen[2][j];
-        mn0 = fminf(mn0, ox); mx0 = fmaxf(mx0, ox); mn1 = fminf(mn1, oy); mx1 = fmaxf(mx1, oy); mn2 = fminf(mn2, oz); mx2 = fmaxf(mx2, oz);
-      }
-      const float e0 = mx0 - mn0, e1 = mx1 - mn1, e2 = mx2 - mn2;
-      axis = (e0 >= e1 && e0 >= e2) ? 0 : (e1 >= e2 ? 1 : 2);   // NaN extents: comparisons false -> axis 2; any axis is valid
-    }
-    const int key = axis == 0 ? ck[0] : (axis == 1 ? ck[1] : ck[2]);
-    if (live) s_key[pos] = key;
-    __syncthreads();
-    // my rank inside my segment along that axis (strict order by (key, position))
-    int rank = pos;
-    if (open) {
-      rank = s;
-      for (int j = s; j < e; ++j) {
-        const int oj = s_key[j];
-        rank += (oj < key || (oj == key && j < pos)) ? 1 : 0;
-      }
-    }
-    if (live) s_rank[pos] = rank;
-    __syncthreads();
-    // the split after me: boxes of the triangles up to my rank and of the rest
-    int cost_key = INT32_MAX;
-    if (open) {
-      float l0 = __builtin_inff(), l1 = l0, l2 = l0, l3 = -l0, l4 = -l0, l5 = -l0;
-      float r0 = l0, r1 = l0, r2 = l0, r3 = -l0, r4 = -l0, r5 = -l0;
-      for (int j = s; j < e; ++j) {
-        const bool left = s_rank[j] <= rank;
-        const float a0 = s_box[0][j], a1 = s_box[1][j], a2 = s_box[2][j], a3 = s_box[3][j], a4 = s_box[4][j], a5 = s_box[5][j];
-        if (left) { l0 = fminf(l0, a0); l1 = fminf(l1, a1); l2 = fminf(l2, a2); l3 = fmaxf(l3, a3); l4 = fmaxf(l4, a4); l5 = fmaxf(l5, a5); }
-        else { r0 = fminf(r0, a0); r1 = fminf(r1, a1); r2 = fminf(r2, a2); r3 = fmaxf(r3, a3); r4 = fmaxf(r4, a4); r5 = fmaxf(r5, a5); }
-      }
-      const int n_left = rank - s + 1, n_right = e - rank - 1;
-      const float cost = ((l3 - l0) + (l4 - l1) + (l5 - l2)) * (float)n_left + ((r3 - r0) + (r4 - r1) + (r5 - r2)) * (float)n_right;
-      if (n_right > 0) cost_key = ord(cost);                      // the last rank is not a split
-    }
-    if (live) s_cost[pos] = cost_key;
-    __syncthreads();
-    if (open) {
-      // the best split of my segment: smallest (cost, rank)
-      int best_cost = INT32_MAX, best_rank = s + (e - s) / 2 - 1;   // fallback (cannot be needed: a segment of 2+ has a valid split)
-      for (int j = s; j < e; ++j) {
-        const int cj = s_cost[j], rj = s_rank[j];
-        if (cj < best_cost || (cj == best_cost && cj != INT32_MAX && rj < best_rank)) { best_cost = cj; best_rank = rj; }
-      }
-      const bool right = rank > best_rank;
-      pos = rank;
-      code = (code << 1) | (right ? 1ull : 0ull);
-      ++depth;
-      if (right) s = best_rank + 1; else e = best_rank + 1;
-    }
-  }
-  if (live) {
-    // Morton prefix of the node, then the path inside the treelet, left aligned (depth <= room)
-    const uint64_t mask = ~0ull << room;
-    const uint64_t path = depth ? code << (room - depth) : 0ull;
-    keys[first + pos] = (old_key & mask) | path;
-    order[first + pos] = tri;
-  }
-}
-
-// The treelet roots straight from the sorted keys, without the hierarchy (lean build: replaces the first k_karras and the roots
-// kernel).  The radix tree over the keys (ties broken by position, as k_karras does: the common prefix of two EQUAL keys j < j' is
+// The treelet roots straight from the sorted keys, without the hierarchy.  The radix tree over the keys (ties broken by position, as k_karras does: the common prefix of two EQUAL keys j < j' is
 // 64 + clz(j ^ j')) has the property that the common prefix of any two positions is the minimum of the ADJACENT prefixes between
 // them, so the nodes that contain position p are found by growing [l, r] from [p, p]: the next node up shares c = max(d[l - 1], d[r])
 // bits and reaches as far as the adjacent prefixes stay >= c.  The largest such node of at most TREELET_MAX triangles is p's
@@ -762,16 +502,15 @@ __global__ __launch_bounds__(256) void k_roots_from_keys(const uint64_t* __restr
   }
 }
 
-// The same treelets with the items held BY POSITION IN THE LANES of one wave instead of in LDS arrays that every lane loops over.
-// k_treelet's four loops per level run over the lane's whole segment — O(m^2) LDS reads per level, one LDS round trip per
-// iteration: 62 us for 100 k triangles (every wave waiting on its own chain) and 290 us for 1 M (the LDS pipes saturated).  Here a
+// The items of a treelet are held BY POSITION IN THE LANES of one wave.  (Round 2 kept them in LDS arrays that every lane looped over —
+// O(m^2) LDS reads per level, one LDS round trip per iteration: 62 us for 100 k triangles, 290 us for 1 M.)  A
 // segment is a run of consecutive lanes, so its reductions are log-step scans bounded by the segment's ends ([s, e) is known to
 // every lane, no head flags): extents of the centres, prefix / suffix boxes in rank order, the best (cost, rank).  The scan steps
 // are DPP moves on the VALU (row_shr / row_shl inside a row of 16 lanes, row_bcast across rows for the prefixes; the suffixes
 // cross rows with two lane reads) — a first version on ds_bpermute throughout was no faster than the loops (47 / 306 us): a lane
 // permute occupies the LDS pipe like the reads it replaced.  The items move to their rank with seven lane permutes per level; only
 // the rank itself is still counted by looking at every other item of the segment (one lane read each, four in flight).  Same
-// splits, same arithmetic for the cost, same tie rules: the same keys and order as k_treelet, bit for bit.
+// splits, same arithmetic for the cost, same tie rules as the LDS form: the same keys and order, bit for bit.
 template <int CTRL, int ROWS>
 __device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, ROWS, 0xf, false); }   // lanes without a source keep v
 template <int CTRL, int ROWS>
@@ -921,64 +660,49 @@ __global__ __launch_bounds__(64) void k_treelet_lanes(const int2* __restrict__ r
   }
 }
 
-__global__ void k_init_scene(int* scene, int* parent, int n_nodes) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < 3) scene[i] = INT32_MAX;
-  else if (i < 6) scene[i] = INT32_MIN;
-  if (i < n_nodes) parent[i] = INT32_MIN;
+// ======== the lean build ==========================================================================================
+// The build is the part of a multi-GPU rank's step that does not shard, so it is a few FULL launches rather than many small ones
+// (round 2: ~45 launch-bound kernels, 0.36 ms for 100 k triangles; tests/golden/build_digests.json pins the tree that sequence and
+// this one both produced, byte for byte):
+//   k_tri_setup + k_clear_aux   records, boxes, centroids, per-block scene partials; counters and parent markers
+//   k_morton_keys               every block folds the scene partials itself and writes its tile's keys
+//   rocPRIM radix_sort_pairs    (a block sort + merges at these sizes; three own LSD sorts lost to it)
+//   k_roots_from_keys           treelet roots straight from the sorted keys
+//   k_treelet_lanes             sweep-split treelets, one wave each, items in lanes
+//   k_karras                    the hierarchy, once, over the rewritten keys
+//   k_seg_build                 ten segment-tree levels per block in LDS, the last block to finish adds the top levels
+//   k_emit, k_node_ext          pre-order records, oriented bounds
+constexpr int KEY_THREADS = 512, KEY_CHUNK = KEY_THREADS * 8;
+constexpr uint32_t KEY_MAX_TILES = 128;
+// Tiles of the key kernel: at most KEY_MAX_TILES blocks (each folds all scene partials), each a whole number of 4096-triangle chunks.
+__host__ __device__ inline uint32_t key_tile_pairs(size_t n) {
+  const size_t chunks = (n + KEY_CHUNK - 1) / KEY_CHUNK;
+  return (uint32_t)((chunks + KEY_MAX_TILES - 1) / KEY_MAX_TILES) * KEY_CHUNK;
 }
-
-
-// ======== round 3: the lean build ====================================================================================
-// The round-2 build was ~45 launch-bound kernels (0.36 ms for 100 k triangles, 1.4 ms for 1 M) on every rank of a multi-GPU
-// run — the part of a rank's step that does not shard.  The lean build keeps the TREE bit for bit and spends fewer, fuller
-// launches on it:
-//   k_tri_setup       also clears the sort's counters and the parent markers          (was + k_init_scene)
-//   k_morton_hist     folds the scene partials itself, writes the keys and all seven digit histograms
-//                                                                                      (was k_scene_reduce + k_morton)
-//   k_sort_pass x 7   own LSD radix sort, 9 bits per pass, one kernel per pass with a decoupled look-back
-//                                                                                      (was rocPRIM: 9 / 22 kernels)
-//   k_seg_build       ten segment-tree levels per block in LDS, the last block to finish adds the top levels
-//                                                                                      (was 6 launches of k_seg_level3)
-// M2S_BUILD=0 selects the round-2 sequence (A/B and tests/test_gpu_build.py, which compares the two trees byte for byte).
-constexpr int SORT_DIGIT = 9, SORT_BINS = 1 << SORT_DIGIT, SORT_PASSES = 7;        // 7 x 9 = the 63 bits of a key
-#ifndef M2S_SORT_KPT
-#define M2S_SORT_KPT 8
-#endif
-constexpr int SORT_THREADS = 512, SORT_KPT = M2S_SORT_KPT, SORT_CHUNK = SORT_THREADS * SORT_KPT;
-constexpr uint32_t SORT_MAX_TILES = 128;
-// The sort's tiles: at most SORT_MAX_TILES of them (all resident at once: a block only ever waits for blocks with lower
-// indices, which the dispatcher started before it), each a whole number of chunks, one block per tile and pass.
-__host__ __device__ inline uint32_t sort_tile_pairs(size_t n) {
-  const size_t chunks = (n + SORT_CHUNK - 1) / SORT_CHUNK;
-  return (uint32_t)((chunks + SORT_MAX_TILES - 1) / SORT_MAX_TILES) * SORT_CHUNK;
-}
-__host__ __device__ inline uint32_t sort_tiles(size_t n) {
-  const uint32_t tp = sort_tile_pairs(n);
+__host__ __device__ inline uint32_t key_tiles(size_t n) {
+  const uint32_t tp = key_tile_pairs(n);
   return tp ? (uint32_t)((n + tp - 1) / tp) : 0u;
 }
-// Words of sort workspace: the seven digit histograms, 16 counters ([0]: k_seg_build's finished blocks), the (tile, digit) words
-// the tiles of a pass publish for each other.
-__host__ __device__ inline size_t sort_aux_words(size_t n) { return (size_t)SORT_PASSES * SORT_BINS + 16 + (size_t)sort_tiles(n) * SORT_BINS; }
+constexpr size_t AUX_WORDS = 16;   // [0]: k_seg_build's finished blocks
 
-// Clears the sort's tables and writes the "no parent yet" markers (what k_init_scene and a memset did).
+// Clears the build's counters and writes the "no parent yet" markers.
 __global__ __launch_bounds__(256) void k_clear_aux(uint32_t* __restrict__ aux, size_t words, int* __restrict__ parent, int n_nodes) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
   for (size_t k = i; k < words; k += stride) aux[k] = 0u;
   for (size_t k = i; k < (size_t)n_nodes; k += stride) parent[k] = INT32_MIN;
 }
 
-// Keys + the seven digit histograms.  One block per sort tile; every block folds the scene partials of k_tri_setup itself.
-__global__ __launch_bounds__(SORT_THREADS) void k_morton_hist(const Box* __restrict__ boxes, uint32_t n_tris, int* __restrict__ scene,
-                                                               uint32_t n_partials, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals,
-                                                               uint32_t* __restrict__ hist, uint32_t tile_pairs) {
-  __shared__ uint32_t s_hist[SORT_PASSES * SORT_BINS];
-  __shared__ int s_part[6][SORT_THREADS / 64];
+// 63-bit Morton key of every triangle's box centre (21 bits per axis over the scene's box of centres) and the identity permutation.
+// One block per tile; every block folds the per-block scene partials of k_tri_setup itself, block 0 publishes the final values
+// (scene[0..5]: order-encoded min xyz / max xyz; scene[6]: largest finite |coordinate| as float bits; scene[7]: treelet root counter).
+__global__ __launch_bounds__(KEY_THREADS) void k_morton_keys(const Box* __restrict__ boxes, uint32_t n_tris, int* __restrict__ scene,
+                                                              uint32_t n_partials, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals,
+                                                              uint32_t tile_pairs) {
+  __shared__ int s_part[6][KEY_THREADS / 64];
   __shared__ int s_scene[6];
   const uint32_t tid = threadIdx.x;
-  // every block folds the per-block partials of k_tri_setup (scene[8 + 6 b + k]) itself: a few KB out of L2
   int lo[3] = {INT32_MAX, INT32_MAX, INT32_MAX}, hi[3] = {INT32_MIN, INT32_MIN, INT32_MIN};
-  for (uint32_t b = tid; b < n_partials; b += SORT_THREADS)
+  for (uint32_t b = tid; b < n_partials; b += KEY_THREADS)   // a few KB out of L2
     for (int k = 0; k < 3; ++k) {
       lo[k] = min(lo[k], scene[8 + b * 6 + k]);
       hi[k] = max(hi[k], scene[8 + b * 6 + 3 + k]);
@@ -991,15 +715,14 @@ __global__ __launch_bounds__(SORT_THREADS) void k_morton_hist(const Box* __restr
     }
     if ((tid & 63u) == 0) { s_part[k][tid >> 6] = l; s_part[3 + k][tid >> 6] = h; }
   }
-  for (uint32_t i = tid; i < (uint32_t)(SORT_PASSES * SORT_BINS); i += SORT_THREADS) s_hist[i] = 0u;
   __syncthreads();
   if (tid < 6) {
     int v = s_part[tid][0];
-    for (int w = 1; w < SORT_THREADS / 64; ++w) v = tid < 3 ? min(v, s_part[tid][w]) : max(v, s_part[tid][w]);
+    for (int w = 1; w < KEY_THREADS / 64; ++w) v = tid < 3 ? min(v, s_part[tid][w]) : max(v, s_part[tid][w]);
     s_scene[tid] = v;
   }
   __syncthreads();
-  if (blockIdx.x == 0 && tid == 0) {   // the final values for everybody after the build (k_scene_reduce's outputs)
+  if (blockIdx.x == 0 && tid == 0) {
     float s = 0.0f;
     for (int k = 0; k < 6; ++k) {
       scene[k] = s_scene[k];
@@ -1012,149 +735,23 @@ __global__ __launch_bounds__(SORT_THREADS) void k_morton_hist(const Box* __restr
   float slo[3], shi[3];
   for (int k = 0; k < 3; ++k) { slo[k] = unord(s_scene[k]); shi[k] = unord(s_scene[3 + k]); }
   const uint32_t base = blockIdx.x * tile_pairs, end = min(n_tris, base + tile_pairs);
-  for (uint32_t t = base + tid; t < end; t += SORT_THREADS) {
+  for (uint32_t t = base + tid; t < end; t += KEY_THREADS) {
     const Box bx = boxes[t];
     const float c[3] = {0.5f * (bx.mnx + bx.mxx), 0.5f * (bx.mny + bx.mxy), 0.5f * (bx.mnz + bx.mxz)};
     uint32_t q[3];
-    for (int k = 0; k < 3; ++k) {       // k_morton's arithmetic
+    for (int k = 0; k < 3; ++k) {
       float u = (c[k] - slo[k]) / (shi[k] - slo[k]);
       u = (u == u) ? fminf(fmaxf(u, 0.0f), 1.0f) : 0.0f;
       q[k] = min((uint32_t)(u * 2097152.0f), 2097151u);
     }
-    const uint64_t key = (expand21(q[0]) << 2) | (expand21(q[1]) << 1) | expand21(q[2]);
-    keys[t] = key;
+    keys[t] = (expand21(q[0]) << 2) | (expand21(q[1]) << 1) | expand21(q[2]);
     vals[t] = t;
-    for (int p = 0; p < SORT_PASSES; ++p) atomicAdd(&s_hist[p * SORT_BINS + (uint32_t)((key >> (SORT_DIGIT * p)) & (SORT_BINS - 1))], 1u);
   }
-  __syncthreads();
-  for (uint32_t i = tid; i < (uint32_t)(SORT_PASSES * SORT_BINS); i += SORT_THREADS) {
-    const uint32_t c = s_hist[i];
-    if (c) atomicAdd(&hist[i], c);
-  }
-}
-
-// One pass of the LSD sort: stable scatter of (key, value) by the 9-bit digit at `shift`.  One block per tile, all tiles resident.
-// Order of business, arranged so that nothing waits for anything it does not need (stamped on MI355X, 25 tiles of 4096):
-//   1. the tile's pairs into registers (wave w holds its eighth of the tile: 512 or 1024 consecutive pairs);
-//   2. the tile's digit counts by LDS atomics, PUBLISHED at once (`status`: [31:28] = pass + 1, so that words of earlier passes
-//      read as "not yet"; device-scope accesses — the tiles run on eight XCDs), and the words of the first sixteen earlier tiles
-//      requested right away: they arrive while the tile is ranked.  (Publishing after the ranks made the last tile wait 9 us for
-//      its neighbours: every tile spent 3 us ranking before anybody could see its counts.)
-//   3. ranks: a pair's rank among the pairs of its digit in (wave, round, lane) order — the input order: every pass is stable,
-//      as an LSD sort needs.  Match-any by nine ballots gives every lane its peers; the lowest peer adds the group's size to the
-//      wave's running digit count with ONE returning LDS atomic per round — the eight rounds' atomics are issued back to back
-//      (a wave's LDS operations execute in order) and collected with eight lane reads afterwards: two LDS latencies in all.
-//   4. a thread per digit stacks the waves, adds up the earlier tiles (any word still missing is re-requested, sixteen at a
-//      time), and the digit's start is the scan of the pass's histogram; every pair goes straight to its place.
-// A tile that waits ~1 s for a word gives up and flags ERRF_BUILD_TIMEOUT (a fault elsewhere must not hang the GPU).
-constexpr uint32_t SORT_COUNT_MASK = (1u << 28) - 1u;
-template <int CHUNKS>
-__global__ __launch_bounds__(SORT_THREADS) void k_sort_pass(const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
-                                                             uint64_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, uint32_t n,
-                                                             uint32_t shift, const uint32_t* __restrict__ hist, uint32_t* __restrict__ status,
-                                                             uint32_t gen, uint32_t tile_pairs, int* __restrict__ err, unsigned long long* __restrict__ stamps) {
-  constexpr int R = CHUNKS * SORT_KPT;                       // rounds of 64 pairs per wave
-  __shared__ uint32_t s_cnt[SORT_THREADS / 64][SORT_BINS];
-  __shared__ uint32_t s_hist[SORT_BINS];
-  __shared__ uint32_t s_base[SORT_BINS];
-  __shared__ uint32_t s_wsum[SORT_THREADS / 64];
-  const bool stamp = stamps != nullptr && threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1);
-  unsigned long long* sp = stamps + (blockIdx.x == 0 ? 0 : 8);
-  if (stamp) sp[0] = wall_clock64();
-  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, tile = blockIdx.x;
-  const uint32_t tile_begin = tile * tile_pairs, tile_end = min(n, tile_begin + tile_pairs);
-  const uint32_t first = tile_begin + wave * (R * 64u) + lane;
-  const uint32_t hist_d = hist[tid];
-  uint64_t key[R];
-  uint32_t val[R], rank[R];
-  for (int j = 0; j < R; ++j) {
-    const uint32_t idx = first + j * 64u;
-    key[j] = idx < tile_end ? keys_in[idx] : ~0ull;
-    val[j] = idx < tile_end ? vals_in[idx] : 0u;
-  }
-  for (uint32_t i = tid; i < (uint32_t)(SORT_THREADS / 64 * SORT_BINS); i += SORT_THREADS) (&s_cnt[0][0])[i] = 0u;
-  s_hist[tid] = 0u;
-  __syncthreads();
-  for (int j = 0; j < R; ++j)
-    if (first + j * 64u < tile_end) atomicAdd(&s_hist[(uint32_t)((key[j] >> shift) & (SORT_BINS - 1))], 1u);
-  __syncthreads();
-  if (stamp) sp[1] = wall_clock64();
-  __hip_atomic_store(status + (size_t)tile * SORT_BINS + tid, (gen << 28) | s_hist[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  uint32_t v[16];                                            // the first sixteen earlier tiles' words, requested before the ranking
-  for (uint32_t k = 0; k < 16u; ++k) v[k] = k < tile ? __hip_atomic_load(status + (size_t)k * SORT_BINS + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (gen << 28);
-  // ranks
-  {
-    uint32_t leader[R], group[R];
-    for (int j = 0; j < R; ++j) {
-      const bool valid = first + j * 64u < tile_end;
-      const uint32_t d = (uint32_t)((key[j] >> shift) & (SORT_BINS - 1));
-      unsigned long long mask = __ballot(valid);
-      for (int b = 0; b < SORT_DIGIT; ++b) {
-        const bool bit = (d >> b) & 1u;
-        const unsigned long long bal = __ballot(bit);
-        mask &= bit ? bal : ~bal;
-      }
-      rank[j] = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));   // peers below me
-      leader[j] = valid ? (uint32_t)(__ffsll((long long)mask) - 1) : lane;
-      group[j] = (uint32_t)__popcll(mask);
-    }
-    uint32_t old[R];
-    for (int j = 0; j < R; ++j) {
-      old[j] = 0u;
-      if (leader[j] == lane && first + j * 64u < tile_end)
-        old[j] = atomicAdd(&s_cnt[wave][(uint32_t)((key[j] >> shift) & (SORT_BINS - 1))], group[j]);
-    }
-    for (int j = 0; j < R; ++j) rank[j] += __shfl(old[j], (int)leader[j]);
-  }
-  __syncthreads();
-  if (stamp) sp[2] = wall_clock64();
-  {
-    // thread = digit: stack the waves, add up the earlier tiles, find the digit's start
-    uint32_t run = 0;
-    for (int w = 0; w < SORT_THREADS / 64; ++w) { const uint32_t c = s_cnt[w][tid]; s_cnt[w][tid] = run; run += c; }
-    uint32_t x = hist_d;
-    for (uint32_t o = 1; o < 64u; o <<= 1) {
-      const uint32_t y = __shfl_up(x, o);
-      if (lane >= o) x += y;
-    }
-    if (lane == 63u) s_wsum[wave] = x;
-    uint32_t before = 0;
-    bool timeout = false;
-    for (uint32_t t0 = 0; t0 < tile; t0 += 16u) {
-      if (t0) for (uint32_t k = 0; k < 16u; ++k) v[k] = t0 + k < tile ? __hip_atomic_load(status + (size_t)(t0 + k) * SORT_BINS + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (gen << 28);
-      for (uint32_t spins = 0;; ++spins) {
-        bool all = true;
-        for (uint32_t k = 0; k < 16u; ++k) all &= (v[k] >> 28) == gen;
-        if (all) break;
-        if (spins > 2000000u) { timeout = true; break; }
-        __builtin_amdgcn_s_sleep(4);
-        for (uint32_t k = 0; k < 16u; ++k)      // everything still missing again, together
-          if ((v[k] >> 28) != gen) v[k] = __hip_atomic_load(status + (size_t)(t0 + k) * SORT_BINS + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-      for (uint32_t k = 0; k < 16u; ++k) before += v[k] & SORT_COUNT_MASK;
-    }
-    if (timeout) atomicOr(err, ERRF_BUILD_TIMEOUT);
-    __syncthreads();
-    uint32_t wpre = 0;
-    for (uint32_t w = 0; w < wave; ++w) wpre += s_wsum[w];
-    s_base[tid] = wpre + x - hist_d + before;
-  }
-  __syncthreads();
-  if (stamp) sp[3] = wall_clock64();
-  for (int j = 0; j < R; ++j) {
-    const uint32_t idx = first + j * 64u;
-    if (idx >= tile_end) continue;
-    const uint32_t d = (uint32_t)((key[j] >> shift) & (SORT_BINS - 1));
-    const uint32_t pos = s_base[d] + s_cnt[wave][d] + rank[j];
-    keys_out[pos] = key[j];
-    vals_out[pos] = val[j];
-  }
-  if (stamp) sp[4] = wall_clock64();
 }
 
 // Segment tree of the leaf boxes in two steps inside ONE launch: every block builds the levels 0..SEG_LOCAL of its 512 leaves in
 // LDS, and the block that finishes last (a ticket behind a device-scope fence) adds the levels above from the blocks' tops.
-// Unions are min / max: any order gives the same boxes as k_seg_level3.
+// Unions are min / max: any order gives the same boxes.
 constexpr int SEG_LOCAL = 9;
 __global__ __launch_bounds__(256) void k_seg_build(const Box* __restrict__ boxes, const uint32_t* __restrict__ order, uint32_t n,
                                                    Box* __restrict__ seg, SegLevels lv, uint32_t* __restrict__ done) {
@@ -1237,7 +834,7 @@ size_t bvh_workspace_bytes(size_t n_tris) {
   size_t sort_tmp = 0;
   (void)rocprim::radix_sort_pairs(nullptr, sort_tmp, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr,
                             (uint32_t*)nullptr, n, 0, 64, (hipStream_t)0);
-  size_t b = sort_aux_words(n) * 4 + 256;
+  size_t b = AUX_WORDS * 4 + 256;
   b += n * sizeof(TriRec) * 2 + n * 16 + 256 + n * 16 + 256 + n * 4 + 256 + n * sizeof(TriPlanes) + 256 + n * sizeof(Box) * 3 + n * (8 + 4) * 2 + sort_tmp;
   b += n * (sizeof(int2) * 2) + 2 * n * sizeof(int) + 2 * n * sizeof(NodeRec) + 2 * n * (sizeof(NodeExt) + 4);
   return b + 64 * 256 + 4096 + 24 * ((n + 255) / 256) + 256;
@@ -1284,15 +881,7 @@ int build_device_mesh(Arena& ws, hipStream_t st, const float* d_verts, size_t n_
   NodeExt* ext = ws.take<NodeExt>(2 * n_tris);
   uint32_t* slot_first = ws.take<uint32_t>(2 * n_tris);
   int* scene = ws.take<int>(8 + 6 * ((n_tris + 255) / 256));
-  const int build_env = getenv("M2S_BUILD") ? atoi(getenv("M2S_BUILD")) : 1;   // 0 = the round-2 sequence (read per call: the tests switch it)
-  const bool lean = build_env != 0 && !getenv("M2S_KEYS_FILE");
-  unsigned long long* stamps = getenv("M2S_BUILD_STAMPS") ? ws.take<unsigned long long>(64) : nullptr;   // experiment: phase times of one sort pass
-  const size_t aux_words = sort_aux_words(n_tris);
-  const uint32_t sort_nt = sort_tiles(n_tris), sort_tp = sort_tile_pairs(n_tris);
-  uint32_t* aux = ws.take<uint32_t>(aux_words);
-  uint32_t* sort_hist = aux;                                       // [SORT_PASSES][SORT_BINS]
-  uint32_t* aux_counters = aux + SORT_PASSES * SORT_BINS;          // [0]: k_seg_build's finished blocks
-  uint32_t* sort_status = aux_counters + 16;                       // [tiles][SORT_BINS]
+  uint32_t* aux = ws.take<uint32_t>(AUX_WORDS);   // [0]: k_seg_build's finished blocks
   size_t sort_tmp = 0;
   (void)rocprim::radix_sort_pairs(nullptr, sort_tmp, keys, keys2, vals, order, n_tris, 0, 64, st);
   void* tmp = ws.take<char>(sort_tmp ? sort_tmp : 1);
@@ -1303,93 +892,41 @@ int build_device_mesh(Arena& ws, hipStream_t st, const float* d_verts, size_t n_
   }
 
   const unsigned B = 256;
-  static const uint32_t leaf_max = getenv("M2S_LEAF_MAX") ? std::max(1u, (uint32_t)atoi(getenv("M2S_LEAF_MAX"))) : 2u;
+  const uint32_t leaf_max = tuning().leaf_max;
+  hipLaunchKernelGGL(k_tri_setup, dim3(cdiv(n_tris, B)), dim3(B), 0, st, d_verts, (uint32_t)n_verts, d_indices,
+                     index_bytes, topology, (uint32_t)n_tris, raw, boxes, cen_raw, scene, 8, d_err);
   if (records_only) {
     // a tiny problem (grid_is_tiny): all voxels x all triangles needs the triangle records and nothing else — no keys, no sort, no tree
-    hipLaunchKernelGGL(k_tri_setup, dim3(cdiv(n_tris, B)), dim3(B), 0, st, d_verts, (uint32_t)n_verts, d_indices,
-                       index_bytes, topology, (uint32_t)n_tris, raw, boxes, cen_raw, scene, 8, d_err);
     M2S_HIP_CHECK(hipGetLastError());
     out->cen_raw = cen_raw;
     out->tris = raw;
     out->n_nodes = 0;
     return 0;
   }
-  if (lean) {
-    hipLaunchKernelGGL(k_tri_setup, dim3(cdiv(n_tris, B)), dim3(B), 0, st, d_verts, (uint32_t)n_verts, d_indices,
-                       index_bytes, topology, (uint32_t)n_tris, raw, boxes, cen_raw, scene, 8, d_err);
-    hipLaunchKernelGGL(k_clear_aux, dim3(std::min(1024u, cdiv(std::max(aux_words, 2 * n_tris), B))), dim3(B), 0, st, aux, aux_words, parent, 2 * n - 1);
-  } else {
-    hipLaunchKernelGGL(k_init_scene, dim3(cdiv(2 * n_tris, B)), dim3(B), 0, st, scene, parent, 2 * n - 1);
-    hipLaunchKernelGGL(k_tri_setup, dim3(cdiv(n_tris, B)), dim3(B), 0, st, d_verts, (uint32_t)n_verts, d_indices,
-                       index_bytes, topology, (uint32_t)n_tris, raw, boxes, cen_raw, scene, 6, d_err);
-    hipLaunchKernelGGL(k_scene_reduce, dim3(1), dim3(256), 0, st, scene, (uint32_t)cdiv(n_tris, B));
-  }
+  hipLaunchKernelGGL(k_clear_aux, dim3(std::min(1024u, cdiv(std::max(AUX_WORDS, 2 * n_tris), B))), dim3(B), 0, st, aux, AUX_WORDS, parent, 2 * n - 1);
   out->cen_raw = cen_raw;
   out->slot_of = slot_of;
   if (after_setup) {   // the caller's seed passes only need the centroids: they run beside the sort and the hierarchy
     const int rc = (*after_setup)(cen_raw, raw, 0);   // phase 0: mark this point of the stream (an event), launch nothing yet
     if (rc) return rc;
   }
-  if (lean) {
-    hipLaunchKernelGGL(k_morton_hist, dim3(sort_nt), dim3(SORT_THREADS), 0, st, boxes, (uint32_t)n_tris, scene, (uint32_t)cdiv(n_tris, B), keys, vals, sort_hist, sort_tp);
-    uint64_t *ka = keys, *kb = keys2;
-    uint32_t *va = vals, *vb = order;
-    const uint32_t chunks_per_tile = sort_tp / SORT_CHUNK;
-    const bool own_sort = getenv("M2S_SORT") && atoi(getenv("M2S_SORT")) == 1;   // experiment: the own LSD sort below (slower than rocPRIM's merge sort so far)
-    if (chunks_per_tile > 2 || !own_sort) {   // above 128 x 2 x 4096 = 1 M pairs a tile no longer fits the registers of its block: the library sort
-      M2S_HIP_CHECK(rocprim::radix_sort_pairs(tmp, sort_tmp, keys, keys2, vals, order, n_tris, 0, 64, st));
-    } else
-    for (int p = 0; p < SORT_PASSES; ++p) {                          // seven passes: the result lands in (keys2, order)
-      if (chunks_per_tile <= 1)
-        hipLaunchKernelGGL(k_sort_pass<1>, dim3(sort_nt), dim3(SORT_THREADS), 0, st, (const uint64_t*)ka, (const uint32_t*)va, kb, vb, (uint32_t)n_tris,
-                           (uint32_t)(SORT_DIGIT * p), (const uint32_t*)(sort_hist + p * SORT_BINS), sort_status, (uint32_t)(p + 1), sort_tp, d_err, p == 3 ? stamps : nullptr);
-      else
-        hipLaunchKernelGGL(k_sort_pass<2>, dim3(sort_nt), dim3(SORT_THREADS), 0, st, (const uint64_t*)ka, (const uint32_t*)va, kb, vb, (uint32_t)n_tris,
-                           (uint32_t)(SORT_DIGIT * p), (const uint32_t*)(sort_hist + p * SORT_BINS), sort_status, (uint32_t)(p + 1), sort_tp, d_err, p == 3 ? stamps : nullptr);
-      std::swap(ka, kb);
-      std::swap(va, vb);
-    }
-  } else {
-  hipLaunchKernelGGL(k_morton, dim3(cdiv(n_tris, B)), dim3(B), 0, st, boxes, (uint32_t)n_tris, scene, keys, vals);
-  if (const char* kf = getenv("M2S_KEYS_FILE")) {
-    // Experiment knob (tools/exp_tree.py): one 64-bit key per triangle from a file instead of the Morton keys.  The
-    // radix tree over prefix-free path codes IS the tree that produced them, so any binary tree of depth < 64 built
-    // elsewhere can be walked by the unchanged kernels.
-    std::vector<uint64_t> hk(n_tris);
-    FILE* f = fopen(kf, "rb");
-    const bool ok = f && fread(hk.data(), 8, n_tris, f) == n_tris;
-    if (f) fclose(f);
-    if (!ok) { set_error("M2S_KEYS_FILE: cannot read one key per triangle"); return M2S_ERR_BAD_ARG; }
-    M2S_HIP_CHECK(hipMemcpyAsync(keys, hk.data(), 8 * n_tris, hipMemcpyHostToDevice, st));
-    M2S_HIP_CHECK(hipStreamSynchronize(st));
-  }
+  hipLaunchKernelGGL(k_morton_keys, dim3(key_tiles(n_tris)), dim3(KEY_THREADS), 0, st, boxes, (uint32_t)n_tris, scene, (uint32_t)cdiv(n_tris, B), keys, vals, key_tile_pairs(n_tris));
   M2S_HIP_CHECK(rocprim::radix_sort_pairs(tmp, sort_tmp, keys, keys2, vals, order, n_tris, 0, 64, st));
-  }
-  static const bool treelets = !(getenv("M2S_TREELETS") && atoi(getenv("M2S_TREELETS")) == 0);
-  const bool treelet_pass = n > 2 && treelets && !getenv("M2S_KEYS_FILE");
-  // lean build: the treelet roots come straight from the sorted keys (k_roots_from_keys), so the hierarchy is derived ONCE, after the treelets
-  const bool roots_from_keys = lean && treelet_pass && TREELET_MAX == 64 && !(getenv("M2S_ROOTS_FROM_KEYS") && atoi(getenv("M2S_ROOTS_FROM_KEYS")) == 0);
-  if (n > 1 && !roots_from_keys) hipLaunchKernelGGL(k_karras, dim3(cdiv(n_tris - 1, B)), dim3(B), 0, st, keys2, n, range, child, parent);
   if (after_setup) {
-    // phase 1: `st` now holds ~100 us of work (keys, sort, hierarchy) — the time the host needs to enqueue the side
-    // work (the seed passes, behind the phase-0 mark).  Launching it at phase 0 left `st` idle for those ~100 us (a
-    // launch costs the host ~8 us, and the thin slab of a multi-GPU rank has nothing to hide that behind); launching it
-    // after the whole build serialised the passes of a 512^3 lattice (0.5 ms) behind the build instead of beside it.
+    // phase 1: `st` now holds ~100 us of work (keys, sort) — the time the host needs to enqueue the side work (the seed
+    // passes, behind the phase-0 mark).  Launching it at phase 0 left `st` idle for those ~100 us (a launch costs the host ~8 us,
+    // and the thin slab of a multi-GPU rank has nothing to hide that behind); launching it after the whole build serialised the
+    // passes of a 512^3 lattice (0.5 ms) behind the build instead of beside it.
     const int rc = (*after_setup)(cen_raw, raw, 1);
     if (rc) return rc;
   }
-  if (treelet_pass) {
-    // treelet pass: the nodes of at most TREELET_MAX triangles are rebuilt by sweep splits, then the hierarchy is derived again
-    int2* roots = reinterpret_cast<int2*>(child);   // child[] is not used by the kernels below and is rewritten by the second k_karras
-    if (roots_from_keys) hipLaunchKernelGGL(k_roots_from_keys, dim3(cdiv(n_tris, B)), dim3(B), 0, st, (const uint64_t*)keys2, n, roots, scene + 7);
-    else if (lean) hipLaunchKernelGGL(k_treelet_roots_block, dim3(cdiv(n_tris - 1, B)), dim3(B), 0, st, n, range, parent, roots, scene + 7);
-    else hipLaunchKernelGGL(k_treelet_roots, dim3(cdiv(n_tris - 1, B)), dim3(B), 0, st, n, range, parent, roots, scene + 7);
-    if (lean && TREELET_MAX == 64 && !(getenv("M2S_TREELET_LANES") && atoi(getenv("M2S_TREELET_LANES")) == 0))
-      hipLaunchKernelGGL(k_treelet_lanes, dim3((unsigned)std::min<size_t>((n_tris + 2) / 3, 8192)), dim3(64), 0, st, roots, scene + 7, boxes, keys2, order);
-    else
-      hipLaunchKernelGGL(k_treelet, dim3((unsigned)((n_tris + 2) / 3)), dim3(TREELET_MAX), 0, st, roots, scene + 7, boxes, keys2, order);
-    hipLaunchKernelGGL(k_karras, dim3(cdiv(n_tris - 1, B)), dim3(B), 0, st, keys2, n, range, child, parent);
+  if (n > 2) {
+    // treelet pass: the nodes of at most TREELET_MAX triangles are rebuilt by sweep splits (their keys rewritten), then the hierarchy is derived
+    int2* roots = reinterpret_cast<int2*>(child);   // child[] is not used by the kernels below before k_karras rewrites it
+    hipLaunchKernelGGL(k_roots_from_keys, dim3(cdiv(n_tris, B)), dim3(B), 0, st, (const uint64_t*)keys2, n, roots, scene + 7);
+    hipLaunchKernelGGL(k_treelet_lanes, dim3((unsigned)std::min<size_t>((n_tris + 2) / 3, 8192)), dim3(64), 0, st, roots, scene + 7, boxes, keys2, order);
   }
+  if (n > 1) hipLaunchKernelGGL(k_karras, dim3(cdiv(n_tris - 1, B)), dim3(B), 0, st, keys2, n, range, child, parent);
 
   SegLevels lv;
   lv.levels = 0;
@@ -1404,36 +941,12 @@ int build_device_mesh(Arena& ws, hipStream_t st, const float* d_verts, size_t n_
       cnt = (cnt + 1) / 2;
     }
   }
-  if (lean) {
-    hipLaunchKernelGGL(k_seg_build, dim3(cdiv(n_tris, 512)), dim3(B), 0, st, (const Box*)boxes, (const uint32_t*)order, (uint32_t)n_tris, seg, lv, aux_counters);
-  } else {
-  if (lv.levels == 1) hipLaunchKernelGGL(k_seg_level0, dim3(cdiv(n_tris, B)), dim3(B), 0, st, boxes, order, n, seg);   // a single triangle
-  for (int l = 0; l + 1 < lv.levels; l += 3) {
-    const uint32_t n1 = lv.cnt[l + 1];
-    const uint32_t n2 = l + 2 < lv.levels ? lv.cnt[l + 2] : 0, n3 = l + 3 < lv.levels ? lv.cnt[l + 3] : 0;
-    const uint32_t o2 = l + 2 < lv.levels ? lv.off[l + 2] : 0, o3 = l + 3 < lv.levels ? lv.off[l + 3] : 0;
-    const uint32_t threads = (n1 + 3) / 4;
-    if (l == 0)   // the leaf level is gathered by the launch that consumes it
-      hipLaunchKernelGGL(k_seg_level3<true>, dim3(cdiv(threads, B)), dim3(B), 0, st, seg, lv.off[l], lv.cnt[l], lv.off[l + 1], n1, o2,
-                         n2, o3, n3, (const Box*)boxes, (const uint32_t*)order);
-    else
-      hipLaunchKernelGGL(k_seg_level3<false>, dim3(cdiv(threads, B)), dim3(B), 0, st, seg, lv.off[l], lv.cnt[l], lv.off[l + 1], n1, o2,
-                         n2, o3, n3, (const Box*)nullptr, (const uint32_t*)nullptr);
-  }
-  }
+  hipLaunchKernelGGL(k_seg_build, dim3(cdiv(n_tris, 512)), dim3(B), 0, st, (const Box*)boxes, (const uint32_t*)order, (uint32_t)n_tris, seg, lv, aux);
   hipLaunchKernelGGL(k_emit, dim3(cdiv(2 * n_tris - 1, B)), dim3(B), 0, st, n, range, parent, seg, lv, order, raw,
                      nodes, tris, slot_first, cen, planes, leaf_max, slot_of, d_err);
   hipLaunchKernelGGL(k_node_ext, dim3(cdiv(2 * n_tris - 1, B)), dim3(B), 0, st, nodes, slot_first, tris,
                      (uint32_t)(2 * n_tris - 1), ext);
   M2S_HIP_CHECK(hipGetLastError());
-  if (stamps) {
-    unsigned long long h[16];
-    M2S_HIP_CHECK(hipStreamSynchronize(st));
-    M2S_HIP_CHECK(hipMemcpy(h, stamps, sizeof(h), hipMemcpyDeviceToHost));
-    for (int b = 0; b < 2; ++b)
-      fprintf(stderr, "[m2s build stamps] sort pass 3, %s tile (10 ns units from its start): counts published %llu, ranked %llu, looked back %llu, scattered %llu; first tile started %lld before\n",
-              b ? "last" : "first", h[8 * b + 1] - h[8 * b], h[8 * b + 2] - h[8 * b], h[8 * b + 3] - h[8 * b], h[8 * b + 4] - h[8 * b], (long long)(h[8 * b] - h[0]));
-  }
   out->tris = tris;
   out->cen = cen;
   out->planes = planes;
@@ -1451,9 +964,9 @@ void warm_bvh(hipStream_t st) {
   const void* fns[] = {
       (const void*)k_tri_setup,
       (const void*)k_clear_aux,
-      (const void*)k_morton_hist,
+      (const void*)k_morton_keys,
+      (const void*)k_roots_from_keys,
       (const void*)k_karras,
-      (const void*)k_treelet_roots_block,
       (const void*)k_treelet_lanes,
       (const void*)k_seg_build,
       (const void*)k_emit,

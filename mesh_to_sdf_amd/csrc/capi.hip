@@ -15,6 +15,7 @@
 #include "../../include/m2s.h"
 #include "capi_internal.h"
 #include "common.h"
+#include "tuning.h"
 
 namespace m2s {
 
@@ -50,7 +51,7 @@ int fail(int code, const char* fmt, ...) {
 // M2S_HOST_TIMES=1: where the host time of a call goes (first calls especially: runtime start, code objects, workspace, pinned ring).
 struct HostClock {
   std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now(), last = t0;
-  bool on = getenv("M2S_HOST_TIMES") != nullptr;
+  bool on = tuning().host_times != 0;
   char line[512] = "";
   void lap(const char* what) {
     if (!on) return;
@@ -221,18 +222,16 @@ int stage_mesh(Arena& ws, const CallCtx& c, const float* vertices, size_t n_vert
 }
 
 // Stream the sign planes of this call are built on: the device's side stream (ordered after everything enqueued on the
-// caller's stream so far), or the caller's stream itself with M2S_SIGN_OVERLAP=0.
+// caller's stream so far), or the caller's stream itself for an asynchronous call.
 static bool side_stream_wanted(bool synchronous_call) {
-  static const bool overlap = !(getenv("M2S_SIGN_OVERLAP") && atoi(getenv("M2S_SIGN_OVERLAP")) == 0);
   // asynchronous calls are the pieces of a caller who overlaps them on streams of its own: leave the hardware queues to those
-  return overlap && synchronous_call;
+  return synchronous_call;
 }
 // Side work (seed passes, sign planes) runs BESIDE the build on streams of the LOWEST priority: the build is a chain of ~30 small,
 // latency-bound kernels on the caller's stream and is what the cut lists wait for; the wide flooding passes should take the CUs it leaves.
 static int create_side_stream(hipStream_t* s) {
   int lo = 0, hi = 0;
-  static const bool prio = !(getenv("M2S_SIDE_PRIORITY") && atoi(getenv("M2S_SIDE_PRIORITY")) == 0);
-  if (prio && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo != hi) {   // lo = numerically greatest = lowest priority
+  if (hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo != hi) {   // lo = numerically greatest = lowest priority
     if (hipStreamCreateWithPriority(s, hipStreamNonBlocking, lo) == hipSuccess) return 0;
     (void)hipGetLastError();
   }
@@ -316,11 +315,11 @@ static std::vector<std::pair<uint32_t, uint32_t>> slab_chunks(const GridParams& 
 // M2S_STATS: traversal counters of the packet walk (a counting variant of k_packet), printed on stderr.
 static int stats_begin(Arena& ws, hipStream_t stream, DeviceMesh* mesh, unsigned long long** d_stats) {
   *d_stats = nullptr;
-  if (!getenv("M2S_STATS")) return 0;
+  if (!tuning().stats) return 0;
   *d_stats = ws.take<unsigned long long>(80);
   if (!*d_stats) return fail(M2S_ERR_HIP, "internal: workspace");
   unsigned long long init[80] = {0};
-  init[7] = (unsigned long long)atoi(getenv("M2S_STATS"));
+  init[7] = (unsigned long long)tuning().stats;
   M2S_HIP_CHECK(hipMemcpyAsync(*d_stats, init, sizeof(init), hipMemcpyHostToDevice, stream));
   M2S_HIP_CHECK(hipStreamSynchronize(stream));
   mesh->stats = *d_stats;
@@ -372,7 +371,7 @@ int run_grid_distance_push(Arena& ws, const CallCtx& c, DeviceState& st, const D
                            int sign_method, const uint32_t* plane, float* d_out, int* d_err, uint32_t* pieces_out) {
   const uint64_t row = (uint64_t)g.n[1] * g.n[2];
   const uint32_t layers = g.xe - g.xb;
-  static const uint32_t want_pieces = getenv("M2S_PUSH_PIECES") ? (uint32_t)std::max(1, atoi(getenv("M2S_PUSH_PIECES"))) : 4u;
+  const uint32_t want_pieces = tuning().push_pieces;
   const uint64_t bx = 2ull << g.bl[0];                              // whole cut-list blocks (2 bricks) along x
   uint64_t lpp = (layers + want_pieces - 1) / want_pieces;
   if (g.chunk_log < 31u) lpp = 1ull << g.chunk_log;                // interleaved slab: a piece = a chunk (contiguous in the grid; a multiple of 4 bricks)
@@ -426,8 +425,7 @@ int run_grid_distance_push(Arena& ws, const CallCtx& c, DeviceState& st, const D
 int run_grid_distance_trail(Arena& ws, const CallCtx& c, DeviceState& st, const DeviceMesh& mesh, const GridParams& g0,
                             int sign_method, const uint32_t* plane, float* d_out, int* d_err) {
   GridParams g = g0;
-  static const int dbg = getenv("M2S_TRAIL_DEBUG") ? atoi(getenv("M2S_TRAIL_DEBUG")) : 0;   // experiment: 1 = no copy kernel, 2 = default packet order
-  g.xl_cap = (dbg & 2) ? 0u : trail_unit_log(g) + 1u;
+  g.xl_cap = trail_unit_log(g) + 1u;
   set_super_brick_magic(g);
   if (!st.copy_stream) M2S_HIP_CHECK(hipStreamCreateWithFlags(&st.copy_stream, hipStreamNonBlocking));
   while (st.piece_events.size() < 2) {
@@ -467,7 +465,7 @@ int run_grid_distance_trail(Arena& ws, const CallCtx& c, DeviceState& st, const 
     push.rows = walk_peers.rows;
     push.units = walk_peers.units;
     M2S_HIP_CHECK(hipStreamWaitEvent(st.copy_stream, st.piece_events[0], 0));
-    if (!(dbg & 1)) rc = launch_push_trailing(st.copy_stream, d_out, push, g, d_err);
+    rc = launch_push_trailing(st.copy_stream, d_out, push, g, d_err);
   } else {
     M2S_HIP_CHECK(hipStreamWaitEvent(st.copy_stream, st.ev[3], 0));
     for (const auto& ch : slab_chunks(g)) {
@@ -521,9 +519,7 @@ int fill_grid_params(const m2s_grid* grid, const m2s_opts* opts, GridParams* g, 
   g->xl_cap = 0;
   g->chunk_log = 31;
   g->period = 0;
-  static const bool cube_only = getenv("M2S_BRICK_CUBE") && atoi(getenv("M2S_BRICK_CUBE")) != 0;
-  if (cube_only) g->bl[0] = g->bl[1] = g->bl[2] = 2;
-  else choose_brick_shape(g->size, g->bl);
+  choose_brick_shape(g->size, g->bl);
   uint64_t layers = xe - xb;
   const uint64_t period = (opts && opts->struct_size >= sizeof(m2s_opts)) ? opts->x_period : 0;
   if (period != 0 && layers != 0) {
@@ -603,7 +599,7 @@ int run_grid_distance_to_host(Arena& ws, const CallCtx& c, DeviceState& st, cons
                               uint32_t* pieces_out) {
   const uint64_t row = (uint64_t)g.n[1] * g.n[2];
   const uint32_t layers = g.xe - g.xb;
-  static const size_t piece_mb = getenv("M2S_HOST_PIECE_MB") ? (size_t)atoi(getenv("M2S_HOST_PIECE_MB")) : 32;   // 16: 15.5, 32: 13.7, 64: 14.4, 128: 15.9 ms for the 512^3 call
+  const size_t piece_mb = tuning().host_piece_mb;   // 32 MiB; 16: 15.5, 32: 13.7, 64: 14.4, 128: 15.9 ms for the 512^3 call
   uint64_t lpp = row ? std::max<uint64_t>(1, (piece_mb << 20) / 4 / row) : layers;
   if ((uint64_t)layers * row * 4 >= (16u << 20)) lpp = std::min<uint64_t>(lpp, (layers + 3) / 4);   // >= 4 pieces: something to overlap
   const uint64_t bx = 2ull << g.bl[0];
@@ -854,9 +850,7 @@ int m2s_interleaved_slab(const m2s_grid* grid, int n, int k, uint64_t* x_begin, 
   if (!grid || n < 2 || k < 0 || k >= n || nx % (2ull * (uint64_t)n) != 0) return 0;
   const uint64_t C = nx / (2ull * (uint64_t)n);
   uint32_t bl[3];
-  static const bool cube_only = getenv("M2S_BRICK_CUBE") && atoi(getenv("M2S_BRICK_CUBE")) != 0;
-  if (cube_only) bl[0] = bl[1] = bl[2] = 2;
-  else choose_brick_shape(grid->cell_size, bl);
+  choose_brick_shape(grid->cell_size, bl);
   if ((C & (C - 1)) != 0 || C % (4ull << bl[0]) != 0) return 0;   // whole cut-list waves / push pieces per chunk (fill_grid_params checks the same)
   *x_begin = (uint64_t)k * C; *x_end = (uint64_t)(k + 1) * C; *x_period = (uint64_t)n * C;
   return 1;
@@ -979,13 +973,12 @@ int m2s_generate_grid_sdf(const float* vertices, size_t n_vertices, const void* 
   // the first kernels of the build; its 0.5 ms of small dependent kernels then run on the side stream while the caller's
   // stream sorts, derives the hierarchy and fits the bounds (0.3 ms).  The ids are translated to sorted slots afterwards.
   st->have_raw_seeds = false;
-  static const bool seed_overlap = !(getenv("M2S_SEED_OVERLAP") && atoi(getenv("M2S_SEED_OVERLAP")) == 0);
   const uint32_t* plane = nullptr;
   st->early_planes = false;
-  static const bool early_sign = !(getenv("M2S_EARLY_SIGN") && atoi(getenv("M2S_EARLY_SIGN")) == 0);
   // tiny problems (cells x triangles small): all voxels against all triangles, no tree (distance.hip k_brute_split)
-  const bool tiny = grid_is_tiny(g, n_tris, c.algorithm) && !getenv("M2S_STATS");
-  const bool beside = !tiny && seed_overlap && c.algorithm == 0 && !getenv("M2S_STATS") && grid_walk_wants_seeds(g, n_tris, c.algorithm);
+  const bool stats = tuning().stats != 0;
+  const bool tiny = grid_is_tiny(g, n_tris, c.algorithm) && !stats;
+  const bool beside = !tiny && c.algorithm == 0 && !stats && grid_walk_wants_seeds(g, n_tris, c.algorithm);
   const std::function<int(const float4*, const TriRec*, int)> seeds_beside_build = [&](const float4* cen_raw, const TriRec* raw, int phase) -> int {
     if (!side_stream_wanted(c.sync)) return 0;               // no side stream for this call: seeds as part of the walk's preparation
     if (phase == 0) {                                        // the centroid / record kernels are enqueued: mark that point
@@ -995,7 +988,7 @@ int m2s_generate_grid_sdf(const float* vertices, size_t n_vertices, const void* 
       }
       M2S_HIP_CHECK(hipEventRecord(st->seeds_fork, c.stream));
     }
-    if (phase == 1 && sign_method == M2S_SIGN_RAYCAST && early_sign && n_tris) {
+    if (phase == 1 && sign_method == M2S_SIGN_RAYCAST && n_tris) {
       // The Raycast sign planes need nothing but the triangles themselves (marking is triangle-parallel and XOR is
       // commutative, so the input order serves as well as the sorted one): a third stream builds them beside the rest of
       // the build and the seed passes.  After the build they were the last thing the walk of a thin slab waited for
@@ -1049,7 +1042,7 @@ int m2s_generate_grid_sdf(const float* vertices, size_t n_vertices, const void* 
   } else {
     M2S_HIP_CHECK(hipEventRecord(st->ev[2], c.stream));
   }
-  if (c.mem_kind == M2S_MEM_HOST && !getenv("M2S_STATS")) {
+  if (c.mem_kind == M2S_MEM_HOST && !stats) {
     uint32_t pieces = 1;
     rc = run_grid_distance_to_host(ws, c, *st, mesh, g, sign_method, plane, d_slab, d_err, out + (size_t)xb * ny * nz, &pieces);
     if (rc) return rc;
@@ -1059,7 +1052,7 @@ int m2s_generate_grid_sdf(const float* vertices, size_t n_vertices, const void* 
     hc.done("m2s_generate_grid_sdf (host result)");
     return rc;
   }
-  if (c.peers.n && c.peer_mode != M2S_PEER_STORE && !getenv("M2S_STATS")) {
+  if (c.peers.n && c.peer_mode != M2S_PEER_STORE && !stats) {
     uint32_t pieces = 1;
     rc = c.peer_mode == M2S_PEER_TRAIL ? run_grid_distance_trail(ws, c, *st, mesh, g, sign_method, plane, d_out, d_err)
                                        : run_grid_distance_push(ws, c, *st, mesh, g, sign_method, plane, d_out, d_err, &pieces);
@@ -1130,10 +1123,9 @@ int m2s_generate_sdf(const float* vertices, size_t n_vertices, const void* indic
   }
   M2S_HIP_CHECK(hipEventRecord(st->ev[0], c.stream));
   // What the queries need before the walk — bounding box, Morton keys, sort, packet table, gather (distance.hip prepare_query_walk) — does
-  // not need the tree: a synchronous call runs it on the side stream beside the build (M2S_QUERY_OVERLAP=0: behind it, as round 2 did)
+  // not need the tree: a synchronous call runs it on the side stream beside the build
   QueryPlan qplan;
-  static const bool q_overlap = !(getenv("M2S_QUERY_OVERLAP") && atoi(getenv("M2S_QUERY_OVERLAP")) == 0);
-  const bool beside = q_overlap && algorithm == 0 && n_tris != 0 && n_queries >= 32768 && side_stream_wanted(c.sync) && !getenv("M2S_STATS");
+  const bool beside = algorithm == 0 && n_tris != 0 && n_queries >= 32768 && side_stream_wanted(c.sync) && !tuning().stats;
   if (beside) {
     rc = ensure_side_stream(*st);
     if (rc) return rc;
@@ -1412,7 +1404,8 @@ int m2s_mesh_generate_grid_sdf(m2s_mesh* m, const m2s_grid* grid, int sign_metho
     plane = m->plane;
   }
   if (!built_planes) M2S_HIP_CHECK(hipEventRecord(st->ev[2], c.stream));
-  if (c.mem_kind == M2S_MEM_HOST && !getenv("M2S_STATS")) {   // host result: x-pieces stream out while the next computes
+  const bool stats = tuning().stats != 0;
+  if (c.mem_kind == M2S_MEM_HOST && !stats) {   // host result: x-pieces stream out while the next computes
     uint32_t pieces = 1;
     rc = run_grid_distance_to_host(ws, c, *st, m->dm, g, sign_method, plane, d_slab, d_err, out + (size_t)xb * ny * nz, &pieces);
     if (rc) return rc;
@@ -1421,9 +1414,9 @@ int m2s_mesh_generate_grid_sdf(m2s_mesh* m, const m2s_grid* grid, int sign_metho
     return rc;
   }
   uint32_t walk_launches = 1;
-  if (c.peers.n && c.peer_mode == M2S_PEER_TRAIL && !getenv("M2S_STATS"))
+  if (c.peers.n && c.peer_mode == M2S_PEER_TRAIL && !stats)
     rc = run_grid_distance_trail(ws, c, *st, m->dm, g, sign_method, plane, d_out, d_err);
-  else if (c.peers.n && c.peer_mode == M2S_PEER_PUSH && !getenv("M2S_STATS"))
+  else if (c.peers.n && c.peer_mode == M2S_PEER_PUSH && !stats)
     rc = run_grid_distance_push(ws, c, *st, m->dm, g, sign_method, plane, d_out, d_err, &walk_launches);
   else
     rc = run_grid_distance(ws, c, *st, m->dm, g, sign_method, plane, d_out, d_err);
@@ -1589,6 +1582,13 @@ int m2s_peer_bandwidth(const float* src, float* const* peers, uint32_t n_peers, 
 // Test hook (not part of include/m2s.h): FNV-1a digests of the resident arrays of a mesh — triangle records, pre-test planes,
 // box nodes, oriented bounds, centroids, slot table, scene words.  tests/test_gpu_build.py compares two builds of one mesh
 // (M2S_BUILD=0 / 1) with it: the lean build must leave the same tree, byte for byte.
+int m2s_tuning_set(const char* name, const char* value) {
+  clear_error();
+  if (tuning_set(name, value) != 0) return fail(M2S_ERR_BAD_ARG, "m2s_tuning_set: unknown knob or unparsable value: %s=%s", name ? name : "(null)", value ? value : "(default)");
+  return M2S_OK;
+}
+int m2s_tuning_describe(char* buffer, int capacity) { return tuning_describe(buffer, capacity); }
+
 int m2s_debug_mesh_digest(m2s_mesh* m, uint64_t out[8]) {
   g_err[0] = 0;
   if (!m || !out) return fail(M2S_ERR_BAD_ARG, "NULL argument");

@@ -234,6 +234,20 @@ int build_grid_sign_plane(Arena& ws, hipStream_t st, const DeviceMesh& mesh, con
 
 // distance.hip
 size_t grid_distance_workspace_bytes(const GridParams& g);
+// Split walk (distance.hip): a packet still walking when the launch runs dry hands the rest of its pre-order ranges to other waves.
+// `cnt`: [0] suspended packets (= accumulator slots taken), [1 + r] items in the list of follow-up round r (r = 1 ..), [8 + r] the
+// "somebody has run out of work" flag of round r (r = 0: the packet launch itself); all cleared per launch by k_split_init.
+constexpr uint32_t SPLIT_MAX_ROUNDS = 6;
+struct SplitCtl {
+  uint32_t* cnt = nullptr;          // nullptr: no splitting
+  uint32_t* slot_packet = nullptr;  // accumulator slot -> packet (0xffffffff: the packet finished by itself after all)
+  uint32_t* acc = nullptr;          // per slot: 64 x d2 bits, then (Normal fold) 64 x d2pos bits — merged with atomic minima
+  uint4* items = nullptr;           // lists of the follow-up rounds, cap_items each: (packet, first byte, end byte, slot)
+  uint32_t cap_slots = 0, cap_items = 0;
+  uint32_t grace = 0;               // work units a walk gets before it may be suspended
+  uint32_t ways = 8;                // pieces an unfinished walk is cut into
+  uint32_t rounds = 3;              // follow-up launches; the last one walks to the end
+};
 // What a grid walk needs besides the mesh: the seed lattice and the cut lists of a slab (device pointers into the call's arena).
 struct GridWalkPlan {
   const uint32_t* seeds = nullptr;
@@ -241,6 +255,8 @@ struct GridWalkPlan {
   const uint32_t* cut_lists = nullptr;
   uint32_t cut_log = 0, cut_ny = 0, cut_nz = 0;
   bool lane_walk = false;
+  SplitCtl split;                  // packet walk only
+  bool split_forced = false;       // M2S_SPLIT=2: the flags start raised (tests)
   uint32_t* brute_acc = nullptr;   // tiny problems (grid_is_tiny): per-voxel minima of k_brute_split; no seeds, no lists, no tree
 };
 bool grid_is_tiny(const GridParams& g, size_t n_tris, int algorithm);

@@ -24,6 +24,7 @@
 
 #include "common.h"
 #include "geo.hip.h"
+#include "tuning.h"
 
 namespace m2s {
 
@@ -132,17 +133,14 @@ __device__ __forceinline__ GridBrick grid_lane_voxel_plain(const GridParams& g, 
   return v;
 }
 
-// XCD-aware work order: the dispatcher places block b on XCD b % 8.  Each XCD works through runs of consecutive
-// packets (its private L2 keeps seeing the same part of the BVH), and the runs are dealt out round-robin:
-// chunk has bit 31 set: interleaved mode — XCD x takes the runs x, x+8, x+16, ... of 2^run_log blocks (run_log in
-// the low bits): every XCD still works through whole super-bricks, but the static split no longer hands one XCD the
-// expensive eighth of the grid (matters most for the thin multi-GPU pieces, which have few runs).
-__device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t chunk) {
-  if (chunk & 0x80000000u) {
-    const uint32_t run_log = chunk & 31u, i = b >> 3, x = b & 7u;
-    return ((((i >> run_log) << 3) + x) << run_log) | (i & ((1u << run_log) - 1u));
-  }
-  return chunk ? (b & 7u) * chunk + (b >> 3) : b;   // chunk == 0: plain order (M2S_XCD_REMAP=0)
+// XCD-aware work order: the dispatcher places block b on XCD b % 8.  Each XCD works through runs of 2^XCD_RUN_LOG consecutive
+// packets (its private L2 keeps seeing the same part of the BVH), and the runs are dealt out round-robin — XCD x takes the runs
+// x, x+8, x+16, ...: every XCD still works through whole super-bricks, and no XCD is handed the expensive eighth of the grid, as
+// one contiguous eighth per XCD did (matters most for the thin multi-GPU pieces, which have few runs).
+constexpr uint32_t XCD_RUN_LOG = 8;   // 7 is as fast, 8 re-fetches less (L2 misses 363 -> 263 MB on the headline)
+__device__ __forceinline__ uint32_t xcd_remap(uint32_t b) {
+  const uint32_t i = b >> 3, x = b & 7u;
+  return ((((i >> XCD_RUN_LOG) << 3) + x) << XCD_RUN_LOG) | (i & ((1u << XCD_RUN_LOG) - 1u));
 }
 
 // ---- per-lane search state -----------------------------------------------------------------
@@ -366,24 +364,178 @@ __device__ __forceinline__ uint32_t query_lattice_cell(const GridParams& L, floa
   return (cell[0] * L.n[1] + cell[1]) * L.n[2] + cell[2];
 }
 
+// ---- the packet walk ------------------------------------------------------------------------
+// Wave-uniform counters of one packet's walk (SGPRs; only the M2S_STATS variant keeps them).
+struct WalkStats {
+  uint32_t box = 0, ext = 0, leaf = 0, pruned = 0, slab = 0, sphere = 0, pairs = 0;
+};
+
+// ---- split walk -------------------------------------------------------------------------------
+// A launch whose packets are all resident at once lasts as long as its heaviest packet: blob-100k in 128^3 has one wave doing 2 103
+// node tests + 1 289 exact evaluations against 293 + 85 on average, blob-1M's heaviest packet (4 004 + 2 220) is 3.4 ms alone on a
+// SIMD and bounds every thin slab of an 8-GPU run — while most of the chip has already run out of packets.  So a walk may be
+// SUSPENDED: the pre-order ranges it has not walked yet are cut into pieces, every piece becomes an item of a follow-up launch in
+// which any wave may take it, starting from the bests the packet had reached (the seed is within 10 % of a perfect bound, so a
+// piece loses little by not seeing what the others find), and the pieces' minima are merged with atomic minima on per-voxel words
+// (non-negative floats order like their bit patterns; min is associative and commutative: the same bits as one walk).  Any record
+// may start a piece (walk_range says why).  k_split_finish turns the merged minima into signed distances.
+//
+// WHEN to suspend needs no model of the work: the last workgroup of a launch to be dispatched raises a flag ("the dispatcher has
+// run dry": from here on, wave slots fall idle), a walk looks at the flag every CHECK_EVERY work units (one device-scope load,
+// requested one check ahead), and once it is up every walk that has spent its `grace` is suspended at its next check.  The
+// follow-up rounds work through their items with a fixed set of waves striding the list; the first wave to run out raises that
+// round's flag.  The last round walks to the end.  Work unit: one node test or leaf pre-test = 1, one exact evaluation = 4
+// (25 : 20 : 140 vector instructions).
+constexpr uint32_t SPLIT_CHECK_EVERY = 64;
+constexpr uint32_t SPLIT_MIN_PIECE = 16u * (uint32_t)sizeof(NodeExt);   // bytes: pieces shorter than 16 records are not worth an item
+struct SplitState {
+  uint32_t units = 0, next_check = 0xffffffffu;   // work done so far; next look at the flag (never, unless armed)
+  uint32_t flag = 0;                              // the flag as loaded one check ago (VGPR; wave-uniform value)
+  const uint32_t* flag_addr = nullptr;
+  bool suspended = false;
+};
+__device__ __forceinline__ uint32_t split_flag_load(const uint32_t* addr) {   // written by waves on other XCDs: past this XCD's L2
+  return __hip_atomic_load(addr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void split_arm(SplitState& sp, const SplitCtl& ctl, uint32_t round, bool may_suspend) {
+  if (ctl.cnt == nullptr || !may_suspend) return;
+  sp.flag_addr = ctl.cnt + 8 + round;
+  sp.flag = split_flag_load(sp.flag_addr);        // arrives while the seed is evaluated
+  sp.next_check = ctl.grace;
+}
+
+// The pre-order records [off, end) of the oriented-bound tree for the 64 points of a wave: position wave-uniform (SGPR), node
+// records and pre-test planes through scalar loads, a subtree left when no lane's bound reaches it.  BUDGET: the walk may stop
+// early (sp.suspended, off = the first record not yet looked at).
+template <int MODE, bool STATS, bool BUDGET>
+__device__ __forceinline__ void walk_span(const DeviceMesh& mesh, f3 p, float slack, Best<MODE>& best, float& thr, uint32_t& off,
+                                          uint32_t end, WalkStats& st, SplitState& sp) {
+  // The walk addresses NodeExt by BYTE offset (its skip links are stored that way): the scalar loads then take
+  // the offset operand directly and the loop carries no address arithmetic.
+  constexpr uint32_t NB = (uint32_t)sizeof(NodeExt);
+  while (off < end) {
+    off = __builtin_amdgcn_readfirstlane(off);
+    if (BUDGET && sp.units >= sp.next_check) {
+      if (__builtin_amdgcn_readfirstlane((int)sp.flag) != 0) { sp.suspended = true; return; }
+      sp.flag = split_flag_load(sp.flag_addr);    // for the next check
+      sp.next_check = sp.units + SPLIT_CHECK_EVERY;
+    }
+    const NodeExt nr = *reinterpret_cast<const NodeExt*>(reinterpret_cast<const char*>(mesh.ext) + off);
+    if (STATS) ++st.box;
+    if (BUDGET) ++sp.units;
+    const float ed2 = ext_dist2(p, nr);
+    if (STATS && __ballot(!(ed2 > thr)) == 0ull) {
+      ++st.pruned;
+      const float vx = p.x - nr.cx, vy = p.y - nr.cy, vz = p.z - nr.cz;
+      const float t = nr.nz * vz + nr.ny * vy + nr.nx * vx, sl = fmaxf(fabsf(t - nr.mid) - nr.half, 0.0f);
+      if (__ballot(!(sl * sl > thr)) == 0ull) ++st.slab;
+      const float rs = __builtin_amdgcn_sqrtf(nr.R * nr.R + (fabsf(nr.mid) + nr.half) * (fabsf(nr.mid) + nr.half));
+      const float sq = fmaxf(__builtin_amdgcn_sqrtf(vx * vx + vy * vy + vz * vz) - rs, 0.0f);
+      if (__ballot(!(sq * sq > thr)) == 0ull) ++st.sphere;
+    }
+    if (__ballot(!(ed2 > thr)) == 0ull) { off = nr.skip; continue; }   // a NaN bound keeps the node
+    if (nr.tri >= 0) {
+      const uint32_t cnt = (nr.skip - off + NB) / (2u * NB);    // triangles of this (possibly collapsed) leaf
+      for (uint32_t k = 0; k < cnt; ++k) {
+        if (STATS) ++st.ext;
+        if (BUDGET) ++sp.units;
+        const TriPlanes tp = record_at(mesh.planes, (uint32_t)nr.tri + k);   // scalar: small, needed for every leaf triangle
+        const bool reach = !(planes_dist2(p, tp) > thr);
+        if (__ballot(reach) != 0ull) {   // some lane's bound reaches the triangle itself
+          if (STATS) { ++st.leaf; st.pairs += (uint32_t)__popcll(__ballot(reach)); }
+          if (BUDGET) sp.units += 4u;
+          const TriRec tr = record_at_vec(mesh.tris, (uint32_t)nr.tri + k);
+          eval_triangle_leaf<MODE>(best, p, tr, reach);
+          thr = prune_bound(best.d2, slack);
+        }
+      }
+      off = nr.skip;
+    } else {
+      off = off + NB;
+    }
+  }
+}
+
+// Appends the pieces of the unfinished byte ranges to list `round` (lane L <= 15 holds range L - 1 in (s, e); lanes without one
+// hold s == e).  Returns false when the list is full (the caller then walks on by itself); entries below the cap that this wave had
+// already reserved are written as empty items.  Wave-uniform control flow.
+__device__ __forceinline__ bool split_append(const SplitCtl& ctl, uint32_t round, uint32_t packet, uint32_t slot, uint32_t s, uint32_t e) {
+  constexpr uint32_t NB = (uint32_t)sizeof(NodeExt);
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t len = (lane < 16u && e > s) ? e - s : 0u;
+  uint32_t total = len;
+  for (int o = 8; o >= 1; o >>= 1) total += __shfl_xor(total, o);          // over the 16 lanes that may hold a range
+  total = __builtin_amdgcn_readfirstlane(total);
+  uint32_t piece = (total / ctl.ways + NB - 1u) / NB * NB;                 // bytes per piece, whole records
+  piece = max(piece, SPLIT_MIN_PIECE);
+  const uint32_t mine = (len + piece - 1u) / piece;
+  uint32_t before = mine;                                                  // exclusive prefix over the lanes
+  for (uint32_t o = 1; o < 16u; o <<= 1) {
+    const uint32_t t = __shfl_up(before, o);
+    if ((lane & 15u) >= o) before += t;
+  }
+  const uint32_t n_items = __builtin_amdgcn_readfirstlane(__shfl(before, 15));
+  before -= mine;
+  uint32_t base = 0;
+  if (lane == 0u) base = atomicAdd(&ctl.cnt[1u + round], n_items);
+  base = __builtin_amdgcn_readfirstlane(base);
+  const bool fits = base + n_items <= ctl.cap_items;
+  uint4* list = ctl.items + (size_t)(round - 1u) * ctl.cap_items;
+  if (lane < 16u)
+    for (uint32_t j = 0; j < mine; ++j) {
+      const uint32_t i = base + before + j;
+      if (i >= ctl.cap_items) break;
+      const uint32_t first = s + j * piece;
+      list[i] = fits ? make_uint4(packet, first, min(e, first + piece), slot) : make_uint4(packet, 0u, 0u, slot);
+    }
+  return fits;
+}
+
+// The value of one voxel / query, stored the way the call's delivery asks for (plain, peer stores, trailing push).
+__device__ __forceinline__ void store_grid_result(float* __restrict__ out, size_t out_index, float result, bool store, const GridParams& g,
+                                                  const GridBrick& vox, const PeerOut& peers, int lane) {
+  if (peers.progress != nullptr) {
+    // M2S_PEER_TRAIL: the copy kernel that trails this walk runs on other XCDs, whose L2s are separate.  The values are
+    // stored write-through at device scope (no L2 write-back fence: a release fence per wave — buffer_wbl2 — made the walk ten
+    // times slower), the wave waits until the store has been acknowledged, and only then counts the packet.
+    if (store) __hip_atomic_store(&out[out_index], result, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // one counter per (unit, brick row): thousands of device-scope atomics on ONE address serialise at the memory side
+    // and the packet that completes a row counts the row on the unit's own counter, the only address the copy kernel polls
+    if (lane == 0) {
+      const uint32_t unit = vox.bx >> peers.unit_log;
+      const uint32_t nbx = bricks_along(g.xe - g.xb, g.bl[0]), nbz = bricks_along(g.n[2], g.bl[2]);
+      const uint32_t bricks = min((unit + 1u) << peers.unit_log, nbx) - (unit << peers.unit_log);
+      const uint32_t old = __hip_atomic_fetch_add(&peers.progress[peers.units + unit * peers.rows + vox.by], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (old + 1u == bricks * nbz) __hip_atomic_fetch_add(&peers.progress[unit], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return;
+  }
+  if (store) out[out_index] = result;
+  // M2S_PEER_STORE: the same value into every peer's whole-grid buffer (indices are whole-grid there)
+  if (peers.n != 0u && store) {
+    const size_t gi = out_index + (size_t)g.out_off;
+    for (uint32_t i = 0; i < peers.n; ++i) peers.p[i][gi] = result;
+  }
+}
+
 // ---- k_packet -------------------------------------------------------------------------------
 // `seed_in` (one TriRec slot per 2^seed_shift bricks per axis, may be null) replaces the greedy descent:
 // the packet starts from a triangle near its own centre (jump-flooding seed pass below).
-// STAGE (experiment, M2S_LDS_STAGE=1): a cut range of at most STAGE_CAP bytes is copied into LDS by the whole wave (16 B per
-// lane and instruction) before it is walked, and its node records are then read from LDS instead of through the scalar cache.
-constexpr uint32_t STAGE_CAP = 3072;   // 64 node records
-template <bool GRID, int MODE, int SIGN, bool STATS, bool STAGE = false>
-__global__ __launch_bounds__(256) void k_packet(DeviceMesh mesh, GridParams g, const float4* __restrict__ qsorted,
-                                                const uint32_t* __restrict__ perm, uint32_t n_q,
-                                                const uint32_t* __restrict__ plane, float* __restrict__ out,
-                                                int* __restrict__ err, uint32_t n_packets, uint32_t chunk,
-                                                const uint32_t* __restrict__ seed_in, uint32_t seed_shift,
-                                                uint32_t seed_ny, uint32_t seed_nz,
-                                                const GridParams* __restrict__ seed_lattice, CutList cut, PeerOut peers, float mix_thr) {
+template <bool GRID, int MODE, int SIGN, bool STATS, bool SPLIT>
+__global__ __launch_bounds__(64) void k_packet(DeviceMesh mesh, GridParams g, const float4* __restrict__ qsorted,
+                                               const uint32_t* __restrict__ perm, uint32_t n_q,
+                                               const uint32_t* __restrict__ plane, float* __restrict__ out,
+                                               int* __restrict__ err, uint32_t n_packets,
+                                               const uint32_t* __restrict__ seed_in, uint32_t seed_shift,
+                                               uint32_t seed_ny, uint32_t seed_nz,
+                                               const GridParams* __restrict__ seed_lattice, CutList cut, PeerOut peers, SplitCtl split) {
   const int lane = threadIdx.x & 63;
-  const uint32_t block = xcd_remap(blockIdx.x, chunk);
+  // the last workgroup to be dispatched says so: from here on wave slots fall idle (split walk)
+  if (SPLIT && blockIdx.x == gridDim.x - 1u && lane == 0) __hip_atomic_store(&split.cnt[8], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const uint32_t block = xcd_remap(blockIdx.x);
   // wave-uniform, and said so: the brick decode below (two divisions by multiplication, shifts, bounds) then runs on the scalar unit
-  const uint32_t packet = (uint32_t)__builtin_amdgcn_readfirstlane((int)(block * (blockDim.x >> 6) + (threadIdx.x >> 6)));
+  const uint32_t packet = (uint32_t)__builtin_amdgcn_readfirstlane((int)block);   // one packet per single-wave workgroup: the slot is free as soon as the walk ends (4 waves per group: +3.8 %)
   if (packet >= n_packets) return;
 
   f3 p;
@@ -409,17 +561,20 @@ __global__ __launch_bounds__(256) void k_packet(DeviceMesh mesh, GridParams g, c
   }
 
   Best<MODE> best;
-  uint32_t st_box = 0, st_ext = 0, st_leaf = 0;   // wave-uniform traversal counters (SGPRs)
-  uint32_t st_pruned = 0, st_slab = 0, st_sphere = 0, st_ranges = 0, st_band = 0, st_pairs = 0, st_rbytes = 0, st_rmax = 0;
+  WalkStats st;
+  uint32_t st_ranges = 0, st_band = 0, st_rbytes = 0;
   if (mesh.n_nodes) {
     const float scale = fmaxf(mesh_scale(mesh), fmaxf(fabsf(p.x), fmaxf(fabsf(p.y), fabsf(p.z))));
     const float slack = 4.0e-6f * scale + (MODE == MODE_NORMAL_FOLD ? 2.5e-6f : 0.0f);
+    SplitState sp;
+    if (SPLIT) split_arm(sp, split, 0u, true);
 
     // pre-order ranges to walk: the brick's cut list (grid path), or the whole tree.  The list is 64 bytes that nobody has
     // touched before (written by k_cut, read once): it is requested here, in front of the seed evaluation, so that the ~1 us of
     // the miss passes under its 120 instructions instead of in front of the walk.
+    constexpr uint32_t NB = (uint32_t)sizeof(NodeExt);
     const uint32_t* cl = nullptr;
-    uint32_t n_ranges = 1, cut_off_v = 0, cut_end_v = 0;
+    uint32_t n_ranges = 1, cut_off_v = 0, cut_end_v = (lane == 1) ? mesh.n_nodes * NB : 0u;   // no list: lane 1 holds the whole tree
     if (cut.lists != nullptr) {
       const uint32_t cb = GRID ? __builtin_amdgcn_readfirstlane((((vox.bx + cut.bx_off) >> cut.log) * cut.ny + (vox.by >> cut.log)) * cut.nz + (vox.bz >> cut.log))
                                : packet;
@@ -431,8 +586,8 @@ __global__ __launch_bounds__(256) void k_packet(DeviceMesh mesh, GridParams g, c
       const uint32_t cw = cl[(uint32_t)lane & 15u];
       const uint32_t cS = cut_start_bits(mesh.n_nodes), cfirst = cw & ((1u << cS) - 1u);
       const uint32_t clen = ((cw >> cS) & ((1u << (27u - cS)) - 1u)) << (cw >> 27);
-      cut_off_v = cfirst * (uint32_t)sizeof(NodeExt);
-      cut_end_v = min(cfirst + clen, mesh.n_nodes) * (uint32_t)sizeof(NodeExt);
+      cut_off_v = cfirst * NB;
+      cut_end_v = min(cfirst + clen, mesh.n_nodes) * NB;
       n_ranges = __builtin_amdgcn_readfirstlane(cw);
     }
     if (seed_in != nullptr) {
@@ -473,9 +628,6 @@ __global__ __launch_bounds__(256) void k_packet(DeviceMesh mesh, GridParams g, c
       eval_triangle<MODE>(best, p, tr);
     }
 
-    // M2S_MIX_CELLS (experiment): packets whose first voxel is nearer to its seed triangle than mix_thr are left to the lane walk
-    // (k_lane, launched beside this kernel with the complementary test)
-    if (GRID && mix_thr > 0.0f && __shfl(best.d2, 0) < mix_thr * mix_thr) return;
     float thr = prune_bound(best.d2, slack);
     if (STATS && GRID) {
       const float cells = __shfl(__builtin_amdgcn_sqrtf(best.d2), 0) / fabsf(g.size[0]);
@@ -485,91 +637,68 @@ __global__ __launch_bounds__(256) void k_packet(DeviceMesh mesh, GridParams g, c
     // M2S_STATS=2: a second, counting-only traversal that starts from the final bound ("perfect seed")
     const int passes = (STATS && mesh.stats != nullptr && mesh.stats[7] == 2ull) ? 2 : 1;
     for (int pass = 0; pass < passes; ++pass) {
-    if (pass == 1) { st_box = 0; st_ext = 0; st_leaf = 0; }
-    // The walk addresses NodeExt by BYTE offset (its skip links are stored that way): the scalar loads then take
-    // the offset operand directly and the loop carries no address arithmetic.
-    constexpr uint32_t NB = (uint32_t)sizeof(NodeExt);
-    if (STATS) st_ranges = n_ranges;
-
-    for (uint32_t range = 0; range < n_ranges; ++range) {
-    // (a rounded-up range may reach into the next one: those records are then walked twice, which changes no minimum)
-    uint32_t off = cl ? (uint32_t)__builtin_amdgcn_readlane((int)cut_off_v, (int)(1u + range)) : 0u;
-    const uint32_t end = cl ? (uint32_t)__builtin_amdgcn_readlane((int)cut_end_v, (int)(1u + range)) : mesh.n_nodes * NB;
-    if (STATS) { st_rbytes += end - off; st_rmax = max(st_rmax, end - off); }
-    extern __shared__ float4 stage_lds[];
-    const uint32_t stage_base = off;
-    bool staged = false;
-    char* stage_bytes = nullptr;
-    if (STAGE) {
-      stage_bytes = reinterpret_cast<char*>(stage_lds) + (threadIdx.x >> 6) * STAGE_CAP;
-      const uint32_t bytes = end - off;
-      staged = bytes <= STAGE_CAP;
-      if (staged) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");          // the previous range's reads are done
-        for (uint32_t o = (uint32_t)lane * 16u; o < bytes; o += 1024u)
-          *reinterpret_cast<float4*>(stage_bytes + o) = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(mesh.ext) + off + o);
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-      }
-    }
-    while (off < end) {
-      off = __builtin_amdgcn_readfirstlane(off);
-      NodeExt nr;
-      if (STAGE && staged) nr = *reinterpret_cast<const NodeExt*>(stage_bytes + (off - stage_base));
-      else nr = *reinterpret_cast<const NodeExt*>(reinterpret_cast<const char*>(mesh.ext) + off);
-      if (STATS) ++st_box;
-      const float ed2 = ext_dist2(p, nr);
-      if (STATS && __ballot(!(ed2 > thr)) == 0ull) {
-        ++st_pruned;
-        const float vx = p.x - nr.cx, vy = p.y - nr.cy, vz = p.z - nr.cz;
-        const float t = nr.nz * vz + nr.ny * vy + nr.nx * vx, sl = fmaxf(fabsf(t - nr.mid) - nr.half, 0.0f);
-        if (__ballot(!(sl * sl > thr)) == 0ull) ++st_slab;
-        const float rs = __builtin_amdgcn_sqrtf(nr.R * nr.R + (fabsf(nr.mid) + nr.half) * (fabsf(nr.mid) + nr.half));
-        const float sp = fmaxf(__builtin_amdgcn_sqrtf(vx * vx + vy * vy + vz * vz) - rs, 0.0f);
-        if (__ballot(!(sp * sp > thr)) == 0ull) ++st_sphere;
-      }
-      if (__ballot(!(ed2 > thr)) == 0ull) { off = nr.skip; continue; }   // a NaN bound keeps the node
-      if (nr.tri >= 0) {
-        const uint32_t cnt = (nr.skip - off + NB) / (2u * NB);    // triangles of this (possibly collapsed) leaf
-        for (uint32_t k = 0; k < cnt; ++k) {
-          if (STATS) ++st_ext;
-          const TriPlanes tp = record_at(mesh.planes, (uint32_t)nr.tri + k);   // scalar: small, needed for every leaf triangle
-          const bool reach = !(planes_dist2(p, tp) > thr);
-          if (__ballot(reach) != 0ull) {   // some lane's bound reaches the triangle itself
-            if (STATS) { ++st_leaf; st_pairs += (uint32_t)__popcll(__ballot(reach)); }
-            const TriRec tr = record_at_vec(mesh.tris, (uint32_t)nr.tri + k);
-            eval_triangle_leaf<MODE>(best, p, tr, reach);
-            thr = prune_bound(best.d2, slack);
+      if (pass == 1) { st.box = 0; st.ext = 0; st.leaf = 0; }
+      if (STATS) st_ranges = n_ranges;
+      for (uint32_t range = 0; range < n_ranges; ++range) {
+        // (a rounded-up range may reach into the next one: those records are then walked twice, which changes no minimum)
+        uint32_t off = (uint32_t)__builtin_amdgcn_readlane((int)cut_off_v, (int)(1u + range));
+        const uint32_t end = (uint32_t)__builtin_amdgcn_readlane((int)cut_end_v, (int)(1u + range));
+        if (STATS) st_rbytes += end - off;
+        for (;;) {
+          walk_span<MODE, STATS, SPLIT>(mesh, p, slack, best, thr, off, end, st, sp);
+          if (!SPLIT || !sp.suspended) break;
+          // hand over what is left — [off, end) of this range and the ranges behind it — with the bests reached so far
+          uint32_t slot = 0;
+          if (lane == 0) slot = atomicAdd(&split.cnt[0], 1u);
+          slot = __builtin_amdgcn_readfirstlane(slot);
+          bool handed = slot < split.cap_slots;
+          if (handed) {
+            const uint32_t l = (uint32_t)lane;
+            const bool live = l >= 1u + range && l <= n_ranges;               // lane L holds range L - 1
+            const uint32_t s = live ? (l == 1u + range ? off : cut_off_v) : 0u, e = live ? cut_end_v : 0u;
+            handed = split_append(split, 1u, packet, slot, s, e);
+            if (lane == 0) split.slot_packet[slot] = handed ? packet : 0xffffffffu;
           }
+          if (handed) {
+            constexpr uint32_t AW = MODE == MODE_NORMAL_FOLD ? 128u : 64u;
+            uint32_t* acc = split.acc + (size_t)slot * AW;
+            acc[lane] = __float_as_uint(best.d2);
+            if (MODE == MODE_NORMAL_FOLD) {
+              acc[64 + lane] = __float_as_uint(best.d2pos);
+              if (best.nan) atomicOr(err, ERRF_NAN);
+            }
+            return;                                                            // k_split_finish writes this packet's voxels
+          }
+          sp.suspended = false;                                                // no room in the lists: walk on, never to be suspended again
+          sp.next_check = 0xffffffffu;
         }
-        off = nr.skip;
-      } else {
-        off = off + NB;
       }
-    }
-    }
     }
   }
 
   if (STATS && mesh.stats != nullptr && lane == 0) {
-    atomicAdd(&mesh.stats[0], (unsigned long long)st_box);
-    atomicAdd(&mesh.stats[1], (unsigned long long)st_ext);
-    atomicAdd(&mesh.stats[2], (unsigned long long)st_leaf);
+    atomicAdd(&mesh.stats[0], (unsigned long long)st.box);
+    atomicAdd(&mesh.stats[1], (unsigned long long)st.ext);
+    atomicAdd(&mesh.stats[2], (unsigned long long)st.leaf);
     atomicAdd(&mesh.stats[3], 1ull);
-    atomicAdd(&mesh.stats[4], (unsigned long long)st_pruned);
-    atomicAdd(&mesh.stats[5], (unsigned long long)st_slab);
-    atomicAdd(&mesh.stats[6], (unsigned long long)st_sphere);
-    atomicMax(&mesh.stats[72], (unsigned long long)st_box);
-    atomicMax(&mesh.stats[73], (unsigned long long)st_leaf);
+    atomicAdd(&mesh.stats[4], (unsigned long long)st.pruned);
+    atomicAdd(&mesh.stats[5], (unsigned long long)st.slab);
+    atomicAdd(&mesh.stats[6], (unsigned long long)st.sphere);
+    atomicMax(&mesh.stats[72], (unsigned long long)st.box);
+    atomicMax(&mesh.stats[73], (unsigned long long)st.leaf);
+    atomicMax(&mesh.stats[74], (unsigned long long)(st.box + st.ext + 4u * st.leaf));
     unsigned long long* q = mesh.stats + 8 + 8 * st_band;
-    atomicAdd(&q[0], (unsigned long long)st_box);
-    atomicAdd(&q[1], (unsigned long long)st_ext);
-    atomicAdd(&q[2], (unsigned long long)st_leaf);
+    atomicAdd(&q[0], (unsigned long long)st.box);
+    atomicAdd(&q[1], (unsigned long long)st.ext);
+    atomicAdd(&q[2], (unsigned long long)st.leaf);
     atomicAdd(&q[3], 1ull);
     atomicAdd(&q[4], (unsigned long long)st_ranges);
-    atomicAdd(&q[5], (unsigned long long)st_pairs);
+    atomicAdd(&q[5], (unsigned long long)st.pairs);
     atomicAdd(&q[6], (unsigned long long)st_rbytes);
     atomicAdd(&q[7], (unsigned long long)(st_rbytes <= 4096u ? 1u : 0u));
+    // histogram of the packets' work units (node tests + pre-tests + 4 x exact evaluations) in octaves: stats[80 + log2]
+    const uint32_t units = st.box + st.ext + 4u * st.leaf;
+    atomicAdd(&mesh.stats[80 + (31 - __builtin_clz(units | 1u))], 1ull);
   }
 
   bool negate = false;
@@ -589,29 +718,85 @@ __global__ __launch_bounds__(256) void k_packet(DeviceMesh mesh, GridParams g, c
   }
   if (MODE == MODE_NORMAL_FOLD && best.nan) atomicOr(err, ERRF_NAN);
   const float result = finish<MODE>(best, negate);
-  if (GRID && peers.progress != nullptr) {
-    // M2S_PEER_TRAIL: the copy kernel that trails this walk runs on other XCDs, whose L2s are separate.  The values are
-    // stored write-through at device scope (no L2 write-back fence: a release fence per wave — buffer_wbl2 — made the walk ten
-    // times slower), the wave waits until the store has been acknowledged, and only then counts the packet.
-    if (store) __hip_atomic_store(&out[out_index], result, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    // one counter per (unit, brick row): thousands of device-scope atomics on ONE address serialise at the memory side
-    // and the packet that completes a row counts the row on the unit's own counter, the only address the copy kernel polls
-    if (lane == 0) {
-      const uint32_t unit = vox.bx >> peers.unit_log;
-      const uint32_t nbx = bricks_along(g.xe - g.xb, g.bl[0]), nbz = bricks_along(g.n[2], g.bl[2]);
-      const uint32_t bricks = min((unit + 1u) << peers.unit_log, nbx) - (unit << peers.unit_log);
-      const uint32_t old = __hip_atomic_fetch_add(&peers.progress[peers.units + unit * peers.rows + vox.by], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (old + 1u == bricks * nbz) __hip_atomic_fetch_add(&peers.progress[unit], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (GRID) store_grid_result(out, out_index, result, store, g, vox, peers, lane);
+  else if (store) out[out_index] = result;
+}
+
+// One follow-up round of the split walk (grid path): a fixed set of single-wave workgroups strides the round's list; an item is a
+// piece [first, end) of a suspended packet's ranges.  The wave rebuilds the packet's 64 points, starts from the slot's current
+// minima (plain loads: a stale value is merely a looser bound), walks the piece and folds what it found into the slot.  Except
+// in the last round (`final`) a piece may be suspended again; what is left of it goes to the next round's list.
+template <int MODE>
+__global__ __launch_bounds__(64) void k_split_round(DeviceMesh mesh, GridParams g, SplitCtl split, uint32_t round, bool final, int* __restrict__ err) {
+  constexpr uint32_t AW = MODE == MODE_NORMAL_FOLD ? 128u : 64u;
+  const int lane = threadIdx.x & 63;
+  const uint32_t n_items = min(split.cnt[1u + round], split.cap_items);
+  const uint4* list = split.items + (size_t)(round - 1u) * split.cap_items;
+  for (uint32_t i = blockIdx.x; i < n_items; i += gridDim.x) {
+    const uint4 it = list[i];
+    const uint32_t packet = __builtin_amdgcn_readfirstlane(it.x), end = __builtin_amdgcn_readfirstlane(it.z), slot = __builtin_amdgcn_readfirstlane(it.w);
+    uint32_t off = __builtin_amdgcn_readfirstlane(it.y);
+    if (off >= end) continue;                                              // an empty item (a list that overflowed)
+    const GridBrick vox = grid_lane_voxel(g, packet, lane);
+    const f3 p = grid_point(g, vox);
+    const float scale = fmaxf(mesh_scale(mesh), fmaxf(fabsf(p.x), fmaxf(fabsf(p.y), fabsf(p.z))));
+    const float slack = 4.0e-6f * scale + (MODE == MODE_NORMAL_FOLD ? 2.5e-6f : 0.0f);
+    uint32_t* acc = split.acc + (size_t)slot * AW;
+    Best<MODE> best;
+    const uint32_t d2_in = acc[lane];
+    uint32_t d2pos_in = 0x7f800000u;
+    best.d2 = __uint_as_float(d2_in);
+    if (MODE == MODE_NORMAL_FOLD) { d2pos_in = acc[64 + lane]; best.d2pos = __uint_as_float(d2pos_in); }
+    float thr = prune_bound(best.d2, slack);
+    WalkStats st;
+    SplitState sp;
+    split_arm(sp, split, round, !final);
+    for (;;) {
+      walk_span<MODE, false, true>(mesh, p, slack, best, thr, off, end, st, sp);
+      if (!sp.suspended) break;
+      const uint32_t l = (uint32_t)lane;
+      if (split_append(split, round + 1u, packet, slot, l == 1u ? off : 0u, l == 1u ? end : 0u)) break;
+      sp.suspended = false;                                                // no room: finish the piece here
+      sp.next_check = 0xffffffffu;
     }
-    return;
+    // NaN never enters a minimum (fminf drops it), so the words stay ordered like non-negative floats
+    if (__float_as_uint(best.d2) < d2_in) atomicMin(&acc[lane], __float_as_uint(best.d2));
+    if (MODE == MODE_NORMAL_FOLD) {
+      if (__float_as_uint(best.d2pos) < d2pos_in) atomicMin(&acc[64 + lane], __float_as_uint(best.d2pos));
+      if (best.nan) atomicOr(err, ERRF_NAN);
+    }
   }
-  if (store) out[out_index] = result;
-  // M2S_PEER_STORE: the same value into every peer's whole-grid buffer (grid path; indices are whole-grid there)
-  if (GRID && peers.n != 0u && store) {
-    const size_t gi = out_index + (size_t)g.out_off;
-    for (uint32_t i = 0; i < peers.n; ++i) peers.p[i][gi] = result;
+  // out of items: from here on this wave's slot is idle (many waves write the same word: harmless)
+  if (!final && lane == 0) __hip_atomic_store(&split.cnt[8u + round], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// The voxels of the suspended packets, from their merged minima.
+template <int MODE, int SIGN>
+__global__ __launch_bounds__(256) void k_split_finish(GridParams g, const uint32_t* __restrict__ plane, float* __restrict__ out, SplitCtl split, PeerOut peers) {
+  constexpr uint32_t AW = MODE == MODE_NORMAL_FOLD ? 128u : 64u;
+  const int lane = threadIdx.x & 63;
+  const uint32_t n_slots = min(split.cnt[0], split.cap_slots);
+  for (uint32_t slot = blockIdx.x * 4u + (threadIdx.x >> 6); slot < n_slots; slot += gridDim.x * 4u) {
+    const uint32_t packet = split.slot_packet[slot];
+    if (packet == 0xffffffffu) continue;                                   // walked to the end by its own wave after all
+    const GridBrick vox = grid_lane_voxel(g, packet, lane);
+    const uint32_t* acc = split.acc + (size_t)slot * AW;
+    Best<MODE> best;
+    best.d2 = __uint_as_float(acc[lane]);
+    if (MODE == MODE_NORMAL_FOLD) best.d2pos = __uint_as_float(acc[64 + lane]);
+    bool negate = false;
+    if (MODE == MODE_UNSIGNED && SIGN == SIGN_GRID_PLANE) {
+      const size_t w = ((size_t)vox.x * g.n[1] + vox.y) * g.nzw + (vox.z >> 5);
+      negate = (plane[w] >> (vox.z & 31u)) & 1u;
+    }
+    const float result = finish<MODE>(best, negate);
+    const size_t out_index = ((size_t)vox.x * g.n[1] + vox.y) * g.n[2] + vox.z - (size_t)g.out_off;
+    store_grid_result(out, out_index, result, vox.in_range, g, vox, peers, lane);
   }
+}
+// Clears the counters and flags of a split walk; `forced`: the flags start raised (every walk is suspended at its first check).
+__global__ void k_split_init(uint32_t* __restrict__ cnt, uint32_t forced) {
+  if (threadIdx.x < 32u) cnt[threadIdx.x] = (threadIdx.x >= 8u && threadIdx.x < 8u + SPLIT_MAX_ROUNDS + 1u) ? forced : 0u;
 }
 
 // M2S_PEER_TRAIL: pushes the slab to the peers unit by unit while the walk is still running.  Unit u = the x-layers of
@@ -840,7 +1025,7 @@ template <int MODE, int SIGN>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(M2S_LANE_WAVES, 8))) void k_lane(DeviceMesh mesh, GridParams g, const uint32_t* __restrict__ plane,
                                               float* __restrict__ out, int* __restrict__ err, uint32_t n_packets,
                                               const uint32_t* __restrict__ seed_in, uint32_t seed_shift, uint32_t seed_ny, uint32_t seed_nz,
-                                              uint32_t bx_off, PeerOut peers, bool greedy, float mix_thr) {
+                                              uint32_t bx_off, PeerOut peers) {
   const int lane = threadIdx.x & 63;
   const uint32_t packet = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (packet >= n_packets) return;
@@ -858,8 +1043,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(M2S_LANE_WA
     if (seed_in != nullptr)
       slot = min(seed_in[(((vox.bx + bx_off) >> seed_shift) * seed_ny + (vox.by >> seed_shift)) * seed_nz + (vox.bz >> seed_shift)], mesh.n_tris - 1);
     eval_triangle<MODE>(best, p, mesh.tris[slot]);
-    if (mix_thr > 0.0f && !(__shfl(best.d2, 0) < mix_thr * mix_thr)) return;   // M2S_MIX_CELLS: this packet belongs to k_packet
-    if (greedy) greedy_leaf<MODE>(mesh, p, best);
+    greedy_leaf<MODE>(mesh, p, best);
     uint32_t st_nodes = 0, st_exact = 0;               // M2S_STATS
     __shared__ LaneShare lane_share[4];                // one per wave of the workgroup
     lane_tree_walk<MODE>(mesh, p, slack, best, LANE_VALID, st_nodes, st_exact, lane_share[threadIdx.x >> 6]);
@@ -1045,12 +1229,11 @@ __global__ __launch_bounds__(256) void k_jfa_pass32(GridParams g, const float4* 
   out[i] = bc;
   if (ids_out) ids_out[i] = best;
 }
-// One flooding pass over the lattice g (M2S_JFA32=0: always the general kernel).
+// One flooding pass over the lattice g.
 static void launch_jfa_pass(hipStream_t st, const GridParams& g, const float4* in, float4* out, int step, uint32_t* ids) {
-  static const bool fast = !(getenv("M2S_JFA32") && atoi(getenv("M2S_JFA32")) == 0);
   const size_t total = (size_t)g.n[0] * g.n[1] * g.n[2];
   const unsigned nb = (unsigned)((total + 255) / 256);
-  if (fast && total < (1ull << 30) && (unsigned long long)step * g.n[1] * g.n[2] < (1ull << 30))
+  if (total < (1ull << 30) && (unsigned long long)step * g.n[1] * g.n[2] < (1ull << 30))
     hipLaunchKernelGGL(k_jfa_pass32, dim3(nb), dim3(256), 0, st, g, in, out, step, ids);
   else
     hipLaunchKernelGGL(k_jfa_pass, dim3(nb), dim3(256), 0, st, g, (const GridParams*)nullptr, in, out, step, ids);
@@ -1089,7 +1272,7 @@ __device__ __forceinline__ uint32_t stab_count_lane(const DeviceMesh& mesh, f3 p
 template <int MODE, int SIGN>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(M2S_LANE_WAVES, 8))) void k_lane_q(DeviceMesh mesh, const float4* __restrict__ qsorted, const uint32_t* __restrict__ perm,
                                                 uint32_t n_q, float* __restrict__ out, int* __restrict__ err,
-                                                const uint32_t* __restrict__ seed_in, const GridParams* __restrict__ seed_lattice, bool greedy) {
+                                                const uint32_t* __restrict__ seed_in, const GridParams* __restrict__ seed_lattice) {
   const uint32_t i_raw = blockIdx.x * blockDim.x + threadIdx.x;
   const bool LANE_VALID = i_raw < n_q;                 // the last wave's spare lanes stay: the wave-cooperative tail of the walk needs all 64
   const uint32_t i = min(i_raw, n_q - 1u);
@@ -1102,7 +1285,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(M2S_LANE_WA
     uint32_t slot = 0;
     if (seed_in != nullptr) slot = min(seed_in[query_lattice_cell(*seed_lattice, p.x, p.y, p.z)], mesh.n_tris - 1);
     eval_triangle<MODE>(best, p, mesh.tris[slot]);
-    if (greedy) greedy_leaf<MODE>(mesh, p, best);
+    greedy_leaf<MODE>(mesh, p, best);
     uint32_t st_nodes = 0, st_exact = 0;               // M2S_STATS
     __shared__ LaneShare lane_share[4];                // one per wave of the workgroup
     lane_tree_walk<MODE>(mesh, p, slack, best, LANE_VALID, st_nodes, st_exact, lane_share[threadIdx.x >> 6]);
@@ -1601,38 +1784,17 @@ void launch_packet(hipStream_t st, const DeviceMesh& mesh, const GridParams& g, 
                    uint32_t n_q, const uint32_t* plane, float* out, int* err, uint32_t n_packets,
                    const uint32_t* seed_in = nullptr, uint32_t seed_shift = 0, uint32_t seed_ny = 0,
                    uint32_t seed_nz = 0, const GridParams* seed_lattice = nullptr, CutList cut = {nullptr, 0, 0, 0, 0, nullptr},
-                   const PeerOut* peers_in = nullptr, float mix_thr = 0.0f) {
+                   const PeerOut* peers_in = nullptr) {
   PeerOut peers{};
   if (peers_in) peers = *peers_in;
-  static const uint32_t wpb = getenv("M2S_WPB") ? std::min(4u, std::max(1u, (uint32_t)atoi(getenv("M2S_WPB")))) : 1u;   // waves (packets) per workgroup: single-wave groups free their slot as soon as the walk ends (4 -> 1: -3.8 %)
-  const uint32_t blocks = (n_packets + wpb - 1) / wpb;
-  // 2 (default): XCD x takes runs x, x+8, ... of 2^run_log packets; 1: one contiguous eighth per XCD; 0: plain order
-  static const int remap_mode = getenv("M2S_XCD_REMAP") ? atoi(getenv("M2S_XCD_REMAP")) : 2;
-  static const uint32_t run_log = getenv("M2S_XCD_RUN_LOG") ? std::min(20u, (uint32_t)atoi(getenv("M2S_XCD_RUN_LOG"))) : 8u;   // 7 is as fast, 8 re-fetches less (L2 misses 363 -> 263 MB)
-  const bool remap = remap_mode != 0;
-  uint32_t chunk = remap ? (blocks + 7) / 8 : 0;
-  if (remap_mode == 2) {
-    const uint32_t per = 8u << run_log;
-    chunk = ((blocks + per - 1) / per) * (per / 8);          // blocks per XCD, a whole number of runs
-    const uint32_t grid_blocks = chunk * 8;
-    const uint32_t code = 0x80000000u | run_log;
-    if (mesh.stats != nullptr)
-      hipLaunchKernelGGL((k_packet<GRID, MODE, SIGN, true>), dim3(grid_blocks), dim3(64 * wpb), 0, st, mesh, g,
-                         qs, perm, n_q, plane, out, err, n_packets, code, seed_in, seed_shift, seed_ny, seed_nz, seed_lattice, cut, peers, mix_thr);
-    else if (GRID && MODE == MODE_UNSIGNED && SIGN == SIGN_GRID_PLANE && getenv("M2S_LDS_STAGE") && atoi(getenv("M2S_LDS_STAGE")) != 0)
-      hipLaunchKernelGGL((k_packet<GRID, MODE_UNSIGNED, SIGN_GRID_PLANE, false, true>), dim3(grid_blocks), dim3(64 * wpb), wpb * STAGE_CAP, st, mesh, g,
-                         qs, perm, n_q, plane, out, err, n_packets, code, seed_in, seed_shift, seed_ny, seed_nz, seed_lattice, cut, peers, mix_thr);
-    else
-      hipLaunchKernelGGL((k_packet<GRID, MODE, SIGN, false>), dim3(grid_blocks), dim3(64 * wpb), 0, st, mesh, g,
-                         qs, perm, n_q, plane, out, err, n_packets, code, seed_in, seed_shift, seed_ny, seed_nz, seed_lattice, cut, peers, mix_thr);
-    return;
-  }
+  const uint32_t per = 8u << XCD_RUN_LOG;                              // one run on each of the eight XCDs
+  const uint32_t grid_blocks = ((n_packets + per - 1) / per) * per;    // a whole number of runs per XCD (xcd_remap)
   if (mesh.stats != nullptr)   // M2S_STATS: the counting variant (a few SALU ops more per node)
-    hipLaunchKernelGGL((k_packet<GRID, MODE, SIGN, true>), dim3(remap ? chunk * 8 : blocks), dim3(64 * wpb), 0, st, mesh, g,
-                       qs, perm, n_q, plane, out, err, n_packets, chunk, seed_in, seed_shift, seed_ny, seed_nz, seed_lattice, cut, peers, mix_thr);
+    hipLaunchKernelGGL((k_packet<GRID, MODE, SIGN, true>), dim3(grid_blocks), dim3(64), 0, st, mesh, g,
+                       qs, perm, n_q, plane, out, err, n_packets, seed_in, seed_shift, seed_ny, seed_nz, seed_lattice, cut, peers);
   else
-    hipLaunchKernelGGL((k_packet<GRID, MODE, SIGN, false>), dim3(remap ? chunk * 8 : blocks), dim3(64 * wpb), 0, st, mesh, g,
-                       qs, perm, n_q, plane, out, err, n_packets, chunk, seed_in, seed_shift, seed_ny, seed_nz, seed_lattice, cut, peers, mix_thr);
+    hipLaunchKernelGGL((k_packet<GRID, MODE, SIGN, false>), dim3(grid_blocks), dim3(64), 0, st, mesh, g,
+                       qs, perm, n_q, plane, out, err, n_packets, seed_in, seed_shift, seed_ny, seed_nz, seed_lattice, cut, peers);
 }
 template <bool GRID, int MODE, int SIGN>
 void launch_brute(hipStream_t st, const DeviceMesh& mesh, const GridParams& g, const float* q, uint32_t n_q,
@@ -1677,13 +1839,13 @@ static size_t cut_blocks(const GridParams& g, uint32_t log) {
 }
 
 // Tiny problems take k_brute_split: at most 2^22 cells and cells x triangles <= 1e8 + 3000 x triangles (M2S_BRUTE_MAX overrides the
-// product's limit; read per call: the tests switch it).  Measured (tools/exp_tiny.py, whole calls, brute / build + walk): blob-11k 16^3
+// product's limit).  Measured (tools/exp_tiny.py, whole calls, brute / build + walk): blob-11k 16^3
 // 0.34 / 0.92 ms, 20^3 0.58 / 0.96, 24^3 0.92 / 0.83; blob-100k 8^3 0.41 / 2.21, 12^3 1.08 / 2.55, 16^3 2.21 / 2.22; blob-6k 16^3 0.20 / 0.74,
 // 32^3 1.10 / 0.61 — brute force runs at 178 G point-triangle pairs per second (half the chip's fp32 issue rate), the walks of such
 // grids as long as their slowest lane's chain of dependent loads, which grows with the mesh.
 bool grid_is_tiny(const GridParams& g, size_t n_tris, int algorithm) {
   if (algorithm != 0 || n_tris == 0 || g.xe <= g.xb || g.n[1] == 0 || g.n[2] == 0 || g.chunk_log < 31u) return false;
-  const double limit = getenv("M2S_BRUTE_MAX") ? atof(getenv("M2S_BRUTE_MAX")) : 1.0e8 + 3.0e3 * (double)n_tris;
+  const double limit = tuning().brute_max >= 0.0 ? tuning().brute_max : 1.0e8 + 3.0e3 * (double)n_tris;
   const double cells = (double)(g.xe - g.xb) * g.n[1] * g.n[2];
   return cells <= 4194304.0 && cells * (double)n_tris <= limit;
 }
@@ -1705,9 +1867,8 @@ __global__ __launch_bounds__(256) void k_seed_remap(uint32_t* __restrict__ ids, 
 uint32_t host_packet_bricks(const GridParams& g) { return (g.xe <= g.xb || g.n[1] == 0 || g.n[2] == 0) ? 0u : host_brick_count(g); }
 
 bool grid_walk_wants_seeds(const GridParams& g, size_t n_tris, int algorithm) {
-  static const bool use_seeds = !(getenv("M2S_SEEDS") && atoi(getenv("M2S_SEEDS")) == 0);
   if (g.xe <= g.xb || g.n[1] == 0 || g.n[2] == 0) return false;
-  return algorithm != 1 && n_tris && host_brick_count(g) >= 8 && use_seeds;
+  return algorithm != 1 && n_tris && host_brick_count(g) >= 8;
 }
 
 // Seeding: every 4^3 brick starts its walk from a triangle near its own centre (jump flooding over the lattice of brick
@@ -1717,8 +1878,8 @@ int launch_grid_seeds(Arena& ws, hipStream_t st, const float4* cen, uint32_t n_t
   DeviceMesh mesh{};
   mesh.cen = cen;
   mesh.n_tris = n_tris;
-  // one lattice point per 2^shift packet bricks per axis, at the centre of that block of bricks (M2S_SEED_SHIFT, default 0)
-  static const uint32_t seed_shift = getenv("M2S_SEED_SHIFT") ? (uint32_t)std::min(3, std::max(0, atoi(getenv("M2S_SEED_SHIFT")))) : 0u;
+  // one lattice point per packet brick, at its centre (one per 2 x 2 x 2 bricks — shift 1 — costs the headline walk 8.11 -> 9.23 ms)
+  constexpr uint32_t seed_shift = 0u;
   const uint32_t stride_log[3] = {g.bl[0] + seed_shift, g.bl[1] + seed_shift, g.bl[2] + seed_shift};
   const GridParams g1 = coarse_level(g, stride_log, g.xb);
   const size_t points1 = (size_t)g1.n[0] * g1.n[1] * g1.n[2];
@@ -1781,34 +1942,33 @@ int prepare_grid_walk(Arena& ws, hipStream_t st, const DeviceMesh& mesh, const G
   }
   // Walk flavour: bricks that each meet MANY triangles (triangles much smaller than voxels) are better served by
   // independent per-lane walks.  Estimate: triangles per surface brick ~ T / (6 * bricks^(2/3)).
-  const int lane_env = getenv("M2S_LANE_WALK") ? atoi(getenv("M2S_LANE_WALK")) : -1;   // -1 auto, 0 never, 1 always (read per call: the tests switch it)
+  const int lane_env = tuning().lane_walk;   // -1 auto, 0 never, 1 always
   // measured crossover with the work-sharing lane walk (lane / packet walk, whole call, Raycast): blob-11k 32^3 0.77 / 0.86 ms, 48^3
   // 0.80 / 0.71; blob-100k 64^3 1.71 / 2.85, 96^3 2.19 / 2.12; blob-1M 128^3 8.8 / 12.1, 256^3 32.7 / 14.3: the lane walk wins while
   // there are more than ~8 triangles per brick
   const double real_bricks = (double)bricks_along(g.xe - g.xb, g.bl[0]) * bricks_along(g.n[1], g.bl[1]) * bricks_along(g.n[2], g.bl[2]);
-  const double lane_ratio = getenv("M2S_LANE_RATIO") ? atof(getenv("M2S_LANE_RATIO")) : 8.0;
+  const double lane_ratio = tuning().lane_ratio;
   const bool lane_walk = !brute && mesh.n_tris && (lane_env >= 0 ? lane_env == 1 : (double)mesh.n_tris > lane_ratio * real_bricks);
   // cut lists: the top of the tree is walked once per block of 2^log bricks per axis (k_cut)
   CutList cut = {nullptr, 0, 0, 0, 0, nullptr};
   // k_cut costs about 0.25 us per brick plus a latency floor of ~0.1 ms; measured crossover (blob-100k / blob-6k,
   // tools/exp_cutmin.py): 192^3 = 110 592 packets loses 0.1-0.2 ms with the lists, 256^3 = 262 144 packets breaks even or
-  // gains, 512^3 gains 1.3 ms.  Read per call: the tests lower it to cover small grids.
+  // gains, 512^3 gains 1.3 ms.  The tests lower it to cover small grids.
   // (asynchronous calls are the pieces of a caller who pipelines them on two streams: k_cut then runs under the previous
   // piece's walk and pays from about half that size)
-  const uint32_t cut_min_packets = getenv("M2S_CUT_MIN_PACKETS") ? (uint32_t)atoi(getenv("M2S_CUT_MIN_PACKETS")) : 100000u;   // (round 2: 200 000 for synchronous calls; re-measured with the 64-byte lists: 224^3 2.88 -> 2.75 ms, 192^3 2.41 -> 2.38, 160^3 2.04 -> 2.07)
-  static const int cut_env = getenv("M2S_CUT") ? atoi(getenv("M2S_CUT")) : 1;   // 0 = off
-  if (!brute && !lane_walk && seed1 != nullptr && cut_env > 0 && packets >= cut_min_packets) {
+  const uint32_t cut_min_packets = tuning().cut_min_packets;   // 100 000 (round 2: 200 000 for synchronous calls; re-measured with the 64-byte lists: 224^3 2.88 -> 2.75 ms, 192^3 2.41 -> 2.38, 160^3 2.04 -> 2.07)
+  if (!brute && !lane_walk && seed1 != nullptr && packets >= cut_min_packets) {
     // emission radius of a list entry: emit_near brick radii next to the surface, emit_far of the distance far from it
-    const float emit_near = getenv("M2S_CUT_NEAR") ? (float)atof(getenv("M2S_CUT_NEAR")) : 2.0f;
-    const float emit_far = getenv("M2S_CUT_FAR") ? (float)atof(getenv("M2S_CUT_FAR")) : 1.0f / 32.0f;   // re-tuned at the end of round 3 (1/16 before): headline 9.19 -> 9.11 ms, 1024^3 x sheet-100k 92.95 -> 89.33 ms
+    const float emit_near = tuning().cut_near;
+    const float emit_far = tuning().cut_far;   // 1/32: re-tuned at the end of round 3 (1/16 before): headline 9.19 -> 9.11 ms, 1024^3 x sheet-100k 92.95 -> 89.33 ms
     // A wave that has visited this many nodes lets its bricks emit whatever they meet next: the long union walks of the
     // regions with many near-ties (deep inside a round body) are the tail of the launch — on the 64-layer slab of an 8-GPU
     // rank, 4 waves per SIMD, they WERE its duration (0.39 -> 0.19 ms; 512^3: flat between 300 and 450, 200 costs the
     // packets 0.5 ms) — and what they still decide so deep in the tree the packets decide almost as cheaply.
     uint32_t depth = 1;
     while ((1ull << depth) < (unsigned long long)mesh.n_tris + 1ull) ++depth;
-    const uint32_t wave_cap = getenv("M2S_CUT_WAVE_CAP") ? (uint32_t)atoi(getenv("M2S_CUT_WAVE_CAP")) : std::max(120u, 20u * depth);
-    const uint32_t budget = getenv("M2S_CUT_BUDGET") ? (uint32_t)atoi(getenv("M2S_CUT_BUDGET")) : 100000u;
+    const uint32_t wave_cap = tuning().cut_wave_cap ? tuning().cut_wave_cap : std::max(120u, 20u * depth);
+    const uint32_t budget = 100000u;
     const uint32_t nbx = bricks_along(g.xe - g.xb, g.bl[0]), nby = bricks_along(g.n[1], g.bl[1]), nbz = bricks_along(g.n[2], g.bl[2]);
     const size_t bricks = (size_t)nbx * nby * nbz;
     uint32_t* lists = ws.take<uint32_t>(bricks * CUT_WORDS);
@@ -1828,7 +1988,7 @@ int launch_push_cells(hipStream_t st, const float* src, const PeerOut& peers, ui
   if (peers.n == 0 || count == 0) return 0;
   // a bandwidth-bound copy next to the walk of the following piece: enough workgroups to keep every xGMI link busy,
   // few enough to leave the CUs to the walk (M2S_PUSH_BLOCKS)
-  static const unsigned max_blocks = getenv("M2S_PUSH_BLOCKS") ? (unsigned)std::max(1, atoi(getenv("M2S_PUSH_BLOCKS"))) : 256u;
+  const unsigned max_blocks = tuning().push_blocks ? tuning().push_blocks : 256u;
   const uint64_t want = (count / 4 + 255) / 256 + 1;
   const unsigned blocks = (unsigned)std::min<uint64_t>(max_blocks, want);
   hipLaunchKernelGGL(k_push_cells, dim3(blocks), dim3(256), 0, st, src, peers, first, count);
@@ -1837,9 +1997,8 @@ int launch_push_cells(hipStream_t st, const float* src, const PeerOut& peers, ui
 }
 
 uint32_t trail_unit_log(const GridParams& g) {
-  static const uint32_t ul = getenv("M2S_TRAIL_UNIT_LOG") ? (uint32_t)std::min(3, std::max(0, atoi(getenv("M2S_TRAIL_UNIT_LOG")))) : 2u;
   (void)g;
-  return ul;   // 4 bricks = 16 layers of a 4^3-brick grid (16 MB per peer and unit at 512^2 rows): 2-brick units stream finer but
+  return 2u;   // 4 bricks = 16 layers of a 4^3-brick grid (16 MB per peer and unit at 512^2 rows): 2-brick units stream finer but
                // their packet order (super-bricks 2 bricks wide) costs the walk 20 % of its locality
 }
 uint32_t trail_units(const GridParams& g) {
@@ -1849,7 +2008,7 @@ uint32_t trail_units(const GridParams& g) {
 uint32_t trail_rows(const GridParams& g) { return bricks_along(g.n[1], g.bl[1]); }
 int launch_push_trailing(hipStream_t st, const float* src, const PeerOut& peers, const GridParams& g, int* d_err) {
   if (peers.n == 0 || g.xe <= g.xb) return 0;
-  static const unsigned blocks = getenv("M2S_PUSH_BLOCKS") ? (unsigned)std::max(1, atoi(getenv("M2S_PUSH_BLOCKS"))) : 64u;
+  const unsigned blocks = tuning().push_blocks ? tuning().push_blocks : 64u;
   const uint64_t row = (uint64_t)g.n[1] * g.n[2];
   hipLaunchKernelGGL(k_push_trailing, dim3(blocks), dim3(256), 0, st, src, peers, (uint64_t)g.xb * row - g.out_off, row, g.xe - g.xb,
                      (1u << g.bl[0]) << peers.unit_log, trail_units(g), d_err);
@@ -1888,24 +2047,18 @@ int launch_grid_walk(hipStream_t st, const DeviceMesh& mesh, const GridParams& g
   }
   if (plan.lane_walk) {
     const unsigned blocks = (packets + 3) / 4;
-    const bool lane_greedy = getenv("M2S_LANE_GREEDY") ? atoi(getenv("M2S_LANE_GREEDY")) != 0 : true;
     if (mode == MODE_UNSIGNED && d_inside_plane)
-      hipLaunchKernelGGL((k_lane<MODE_UNSIGNED, SIGN_GRID_PLANE>), dim3(blocks), dim3(256), 0, st, mesh, g, d_inside_plane, d_out, d_err, packets, seed1, sh1, s1ny, s1nz, bx_off, pz, lane_greedy, 0.0f);
+      hipLaunchKernelGGL((k_lane<MODE_UNSIGNED, SIGN_GRID_PLANE>), dim3(blocks), dim3(256), 0, st, mesh, g, d_inside_plane, d_out, d_err, packets, seed1, sh1, s1ny, s1nz, bx_off, pz);
     else if (mode == MODE_UNSIGNED)
-      hipLaunchKernelGGL((k_lane<MODE_UNSIGNED, SIGN_NONE>), dim3(blocks), dim3(256), 0, st, mesh, g, nullptr, d_out, d_err, packets, seed1, sh1, s1ny, s1nz, bx_off, pz, lane_greedy, 0.0f);
+      hipLaunchKernelGGL((k_lane<MODE_UNSIGNED, SIGN_NONE>), dim3(blocks), dim3(256), 0, st, mesh, g, nullptr, d_out, d_err, packets, seed1, sh1, s1ny, s1nz, bx_off, pz);
     else
-      hipLaunchKernelGGL((k_lane<MODE_NORMAL_FOLD, SIGN_NONE>), dim3(blocks), dim3(256), 0, st, mesh, g, nullptr, d_out, d_err, packets, seed1, sh1, s1ny, s1nz, bx_off, pz, lane_greedy, 0.0f);
+      hipLaunchKernelGGL((k_lane<MODE_NORMAL_FOLD, SIGN_NONE>), dim3(blocks), dim3(256), 0, st, mesh, g, nullptr, d_out, d_err, packets, seed1, sh1, s1ny, s1nz, bx_off, pz);
     M2S_HIP_CHECK(hipGetLastError());
     return 0;
   }
-  // M2S_MIX_CELLS=c (experiment): the packets within c cells of their seed triangle walk lane by lane (k_lane), the others together
-  const float mix_cells = getenv("M2S_MIX_CELLS") ? (float)atof(getenv("M2S_MIX_CELLS")) : 0.0f;
-  const float mix_thr = mix_cells > 0.0f && seed1 != nullptr && !brute && pz.n == 0 && pz.progress == nullptr ? mix_cells * fabsf(g.size[0]) : 0.0f;
-  if (mix_thr > 0.0f && mode == MODE_UNSIGNED && d_inside_plane)
-    hipLaunchKernelGGL((k_lane<MODE_UNSIGNED, SIGN_GRID_PLANE>), dim3((packets + 3) / 4), dim3(256), 0, st, mesh, g, d_inside_plane, d_out, d_err, packets, seed1, sh1, s1ny, s1nz, bx_off, pz, true, mix_thr);
   if (mode == MODE_UNSIGNED && d_inside_plane) {
     if (brute) launch_brute<true, MODE_UNSIGNED, SIGN_GRID_PLANE>(st, mesh, g, nullptr, 0, d_inside_plane, d_out, d_err, packets, peers);
-    else launch_packet<true, MODE_UNSIGNED, SIGN_GRID_PLANE>(st, mesh, g, nullptr, nullptr, 0, d_inside_plane, d_out, d_err, packets, seed1, sh1, s1ny, s1nz, nullptr, cut, peers, mix_thr);
+    else launch_packet<true, MODE_UNSIGNED, SIGN_GRID_PLANE>(st, mesh, g, nullptr, nullptr, 0, d_inside_plane, d_out, d_err, packets, seed1, sh1, s1ny, s1nz, nullptr, cut, peers);
   } else if (mode == MODE_UNSIGNED) {
     if (brute) launch_brute<true, MODE_UNSIGNED, SIGN_NONE>(st, mesh, g, nullptr, 0, nullptr, d_out, d_err, packets, peers);
     else launch_packet<true, MODE_UNSIGNED, SIGN_NONE>(st, mesh, g, nullptr, nullptr, 0, nullptr, d_out, d_err, packets, seed1, sh1, s1ny, s1nz, nullptr, cut, peers);
@@ -1977,17 +2130,15 @@ int prepare_query_walk(Arena& ws, hipStream_t st, const float* d_queries, size_t
     set_error("internal: query workspace too small");
     return M2S_ERR_HIP_INTERNAL;
   }
-  // key bits that matter: cells of ~8 queries at the finest level, whole Morton triples, 12 ... 30 (M2S_QUERY_KEY_BITS overrides)
+  // key bits that matter: cells of ~8 queries at the finest level, whole Morton triples, 12 ... 30
   uint32_t bits = 12;
   while (bits < (uint32_t)QKEY_BITS && (1ull << bits) * 8ull < (unsigned long long)n_q) bits += 3;
-  if (getenv("M2S_QUERY_KEY_BITS")) bits = (uint32_t)std::min(QKEY_BITS, std::max(3, atoi(getenv("M2S_QUERY_KEY_BITS")) / 3 * 3));
   const uint32_t drop = (uint32_t)QKEY_BITS - bits;
   const unsigned B = 256, nb = (nq + B - 1) / B;
   const unsigned qblocks = nb < QB_BLOCKS ? nb : QB_BLOCKS;
   hipLaunchKernelGGL(k_qbounds, dim3(qblocks), dim3(B), 0, st, d_queries, nq, qb + 8);
   hipLaunchKernelGGL(k_qbounds_final, dim3(1), dim3(B), 0, st, qb + 8, qblocks, qb);
-  static const bool use_seeds = !(getenv("M2S_SEEDS") && atoi(getenv("M2S_SEEDS")) == 0);
-  const bool seeds = use_seeds && n_tris && packets >= 8;
+  const bool seeds = n_tris && packets >= 8;
   if (seeds) {                                   // the seed lattice's description: QL^3 cells over the queries' bounding box
     GridParams* lat = ws.take<GridParams>(1);
     if (!lat) { set_error("internal: query workspace too small"); return M2S_ERR_HIP_INTERNAL; }
@@ -2001,18 +2152,17 @@ int prepare_query_walk(Arena& ws, hipStream_t st, const float* d_queries, size_t
   // RtreeBvh): blob-100k 100 k queries 1.36 / 3.65 ms, 1 M 2.70 / 3.45, 3 M 5.00 / 4.38, 10 M 12.3 / 6.7 (crossover ~2 M);
   // blob-1M 1 M 6.3 / 12.8 ms, 10 M 26.4 / 22.4 (~7 M).  Below it the packet walk lasts as long as its worst packet's chain of
   // dependent loads (2.7 ms), above it the lane walk's divergence costs more than the packets' union.  n* ~ 3500 T^0.55 fits both.
-  const int lane_env = getenv("M2S_LANE_WALK") ? atoi(getenv("M2S_LANE_WALK")) : -1;   // -1 auto, 0 never, 1 always (read per call: the tests switch it)
-  const double lane_coeff = getenv("M2S_QUERY_LANE_COEFF") ? atof(getenv("M2S_QUERY_LANE_COEFF")) : 3500.0;
+  const int lane_env = tuning().lane_walk;   // -1 auto, 0 never, 1 always
+  const double lane_coeff = tuning().query_lane_coeff;
   const bool lane_walk = n_tris && sign_src != SIGN_XRAY_ALL &&
                          (lane_env >= 0 ? lane_env == 1 : (double)n_q < lane_coeff * pow((double)n_tris, 0.55));
   // packets = leaves of the bucket k-d tree over the sorted keys (k_qcells); the launch has room for twice the consecutive
   // count, and k_qtable_mode falls back to consecutive packets should there be more
   const uint32_t* table = nullptr;
   uint32_t launched = packets;
-  const bool bucket_packets = !(getenv("M2S_QUERY_CELLS") && atoi(getenv("M2S_QUERY_CELLS")) == 0);
-  if (bucket_packets && !lane_walk) {
+  if (!lane_walk) {
     launched = nq / 32u + 64u;
-    if (getenv("M2S_QUERY_LAUNCH_TIGHT") && atoi(getenv("M2S_QUERY_LAUNCH_TIGHT")) != 0) launched = packets + 1u;   // test hook: forces the consecutive-packet fallback
+    if (tuning().query_launch_tight != 0) launched = packets + 1u;   // test hook: forces the consecutive-packet fallback
     uint8_t* head = ws.take<uint8_t>(n_q);
     uint32_t* tb = ws.take<uint32_t>(n_q + 2);               // [0] count, [1] mode, then one start per head (at most n_q)
     size_t sel_bytes = 0;
@@ -2025,10 +2175,9 @@ int prepare_query_walk(Arena& ws, hipStream_t st, const float* d_queries, size_t
     table = tb;
   }
   // cut lists, one per packet (k_cut<false>): they need the packets' centres, and the kernel that finds those gathers the queries too
-  const uint32_t qcut_min = getenv("M2S_QUERY_CUT_MIN") ? (uint32_t)atoi(getenv("M2S_QUERY_CUT_MIN")) : 20000u;
-  static const int cut_env = getenv("M2S_CUT") ? atoi(getenv("M2S_CUT")) : 1;
+  const uint32_t qcut_min = tuning().query_cut_min;
   float4* centres = nullptr;
-  if (table != nullptr && seeds && cut_env > 0 && packets >= qcut_min) {
+  if (table != nullptr && seeds && packets >= qcut_min) {
     centres = ws.take<float4>(launched);
     if (!centres) { set_error("internal: query workspace too small"); return M2S_ERR_HIP_INTERNAL; }
     hipLaunchKernelGGL(k_qpacket_bounds, dim3((launched + 3) / 4), dim3(256), 0, st, sorted, table, nq, launched, centres, d_queries, (const uint32_t*)perm);
@@ -2114,22 +2263,21 @@ int launch_query_walk(Arena& ws, hipStream_t st, const DeviceMesh& mesh, const f
   if (plan.centres != nullptr && seeds != nullptr) {
     uint32_t* lists = ws.take<uint32_t>((size_t)launched * CUT_WORDS);
     if (!lists) { set_error("internal: query workspace too small"); return M2S_ERR_HIP_INTERNAL; }
-    const float emit_near = getenv("M2S_CUT_NEAR") ? (float)atof(getenv("M2S_CUT_NEAR")) : 2.0f;
-    const float emit_far = getenv("M2S_CUT_FAR") ? (float)atof(getenv("M2S_CUT_FAR")) : 1.0f / 32.0f;   // re-tuned at the end of round 3 (1/16 before): headline 9.19 -> 9.11 ms, 1024^3 x sheet-100k 92.95 -> 89.33 ms
+    const float emit_near = tuning().cut_near;
+    const float emit_far = tuning().cut_far;   // 1/32: re-tuned at the end of round 3 (1/16 before): headline 9.19 -> 9.11 ms, 1024^3 x sheet-100k 92.95 -> 89.33 ms
     uint32_t depth = 1;
     while ((1ull << depth) < (unsigned long long)mesh.n_tris + 1ull) ++depth;
-    const uint32_t wave_cap = getenv("M2S_CUT_WAVE_CAP") ? (uint32_t)atoi(getenv("M2S_CUT_WAVE_CAP")) : std::max(120u, 20u * depth);
+    const uint32_t wave_cap = tuning().cut_wave_cap ? tuning().cut_wave_cap : std::max(120u, 20u * depth);
     hipLaunchKernelGGL(k_cut<false>, dim3((launched + 63) / 64), dim3(64), 0, st, mesh, g, seeds, 0u, 0u, 0u, launched, 1u, 1u, lists,
                        emit_near, emit_far, 100000u, wave_cap, (const float4*)plan.centres, table, d_lat);
     cut = {lists, 0, 0, 0, 0, plan.centres};
   }
   if (lane_walk) {
     const unsigned lb = (nq + 255u) / 256u;
-    const bool lane_greedy = getenv("M2S_LANE_GREEDY") ? atoi(getenv("M2S_LANE_GREEDY")) != 0 : true;
-    if (mode == MODE_UNSIGNED && sign_src == SIGN_RAYS3) hipLaunchKernelGGL((k_lane_q<MODE_UNSIGNED, SIGN_RAYS3>), dim3(lb), dim3(256), 0, st, mesh, (const float4*)sorted, (const uint32_t*)perm, nq, d_out, d_err, seeds, d_lat, lane_greedy);
-    else if (mode == MODE_UNSIGNED) hipLaunchKernelGGL((k_lane_q<MODE_UNSIGNED, SIGN_NONE>), dim3(lb), dim3(256), 0, st, mesh, (const float4*)sorted, (const uint32_t*)perm, nq, d_out, d_err, seeds, d_lat, lane_greedy);
-    else if (mode == MODE_NORMAL_FOLD) hipLaunchKernelGGL((k_lane_q<MODE_NORMAL_FOLD, SIGN_NONE>), dim3(lb), dim3(256), 0, st, mesh, (const float4*)sorted, (const uint32_t*)perm, nq, d_out, d_err, seeds, d_lat, lane_greedy);
-    else hipLaunchKernelGGL((k_lane_q<MODE_NEAREST_NORMAL, SIGN_NONE>), dim3(lb), dim3(256), 0, st, mesh, (const float4*)sorted, (const uint32_t*)perm, nq, d_out, d_err, seeds, d_lat, lane_greedy);
+    if (mode == MODE_UNSIGNED && sign_src == SIGN_RAYS3) hipLaunchKernelGGL((k_lane_q<MODE_UNSIGNED, SIGN_RAYS3>), dim3(lb), dim3(256), 0, st, mesh, (const float4*)sorted, (const uint32_t*)perm, nq, d_out, d_err, seeds, d_lat);
+    else if (mode == MODE_UNSIGNED) hipLaunchKernelGGL((k_lane_q<MODE_UNSIGNED, SIGN_NONE>), dim3(lb), dim3(256), 0, st, mesh, (const float4*)sorted, (const uint32_t*)perm, nq, d_out, d_err, seeds, d_lat);
+    else if (mode == MODE_NORMAL_FOLD) hipLaunchKernelGGL((k_lane_q<MODE_NORMAL_FOLD, SIGN_NONE>), dim3(lb), dim3(256), 0, st, mesh, (const float4*)sorted, (const uint32_t*)perm, nq, d_out, d_err, seeds, d_lat);
+    else hipLaunchKernelGGL((k_lane_q<MODE_NEAREST_NORMAL, SIGN_NONE>), dim3(lb), dim3(256), 0, st, mesh, (const float4*)sorted, (const uint32_t*)perm, nq, d_out, d_err, seeds, d_lat);
     M2S_HIP_CHECK(hipGetLastError());
     return 0;
   }

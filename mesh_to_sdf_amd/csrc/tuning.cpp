@@ -1,0 +1,129 @@
+// tuning.cpp — the knob table of tuning.h: defaults, names, the one place the environment is read.
+#include "tuning.h"
+
+#include <cstddef>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+
+namespace m2s {
+
+namespace {
+
+enum Kind { K_INT, K_U32, K_F32, K_F64 };
+struct Entry {
+  const char* name;
+  Kind kind;
+  size_t offset;
+};
+#define M2S_KNOB(NAME, KIND, FIELD) {NAME, KIND, offsetof(Tuning, FIELD)}
+const Entry TABLE[] = {
+    M2S_KNOB("M2S_STATS", K_INT, stats),
+    M2S_KNOB("M2S_HOST_TIMES", K_INT, host_times),
+    M2S_KNOB("M2S_LANE_WALK", K_INT, lane_walk),
+    M2S_KNOB("M2S_LANE_RATIO", K_F64, lane_ratio),
+    M2S_KNOB("M2S_QUERY_LANE_COEFF", K_F64, query_lane_coeff),
+    M2S_KNOB("M2S_BRUTE_MAX", K_F64, brute_max),
+    M2S_KNOB("M2S_CUT_MIN_PACKETS", K_U32, cut_min_packets),
+    M2S_KNOB("M2S_QUERY_CUT_MIN", K_U32, query_cut_min),
+    M2S_KNOB("M2S_QUERY_LAUNCH_TIGHT", K_INT, query_launch_tight),
+    M2S_KNOB("M2S_CUT_NEAR", K_F32, cut_near),
+    M2S_KNOB("M2S_CUT_FAR", K_F32, cut_far),
+    M2S_KNOB("M2S_CUT_WAVE_CAP", K_U32, cut_wave_cap),
+    M2S_KNOB("M2S_SPLIT", K_INT, split),
+    M2S_KNOB("M2S_SPLIT_BUDGET", K_U32, split_budget),
+    M2S_KNOB("M2S_SPLIT_WAYS", K_U32, split_ways),
+    M2S_KNOB("M2S_SPLIT_ROUNDS", K_U32, split_rounds),
+    M2S_KNOB("M2S_LEAF_MAX", K_U32, leaf_max),
+    M2S_KNOB("M2S_HOST_PIECE_MB", K_U32, host_piece_mb),
+    M2S_KNOB("M2S_PUSH_PIECES", K_U32, push_pieces),
+    M2S_KNOB("M2S_PUSH_BLOCKS", K_U32, push_blocks),
+};
+#undef M2S_KNOB
+
+Tuning g_tuning;
+std::once_flag g_once;
+std::mutex g_set_mu;
+
+bool assign(Tuning& t, const Entry& e, const char* text) {
+  char* end = nullptr;
+  char* field = reinterpret_cast<char*>(&t) + e.offset;
+  switch (e.kind) {
+    case K_INT: { const long v = strtol(text, &end, 10); if (end == text) return false; *reinterpret_cast<int*>(field) = (int)v; break; }
+    case K_U32: { const long long v = strtoll(text, &end, 10); if (end == text || v < 0) return false; *reinterpret_cast<uint32_t*>(field) = (uint32_t)v; break; }
+    case K_F32: { const double v = strtod(text, &end); if (end == text) return false; *reinterpret_cast<float*>(field) = (float)v; break; }
+    case K_F64: { const double v = strtod(text, &end); if (end == text) return false; *reinterpret_cast<double*>(field) = v; break; }
+  }
+  return true;
+}
+
+void copy_field(Tuning& dst, const Tuning& src, const Entry& e) {
+  const size_t bytes = e.kind == K_F64 ? 8 : 4;
+  memcpy(reinterpret_cast<char*>(&dst) + e.offset, reinterpret_cast<const char*>(&src) + e.offset, bytes);
+}
+
+void sanitise(Tuning& t) {
+  if (t.leaf_max < 1) t.leaf_max = 1;
+  if (t.split_ways < 2) t.split_ways = 2;
+  if (t.split_ways > 32) t.split_ways = 32;
+  if (t.split_rounds < 1) t.split_rounds = 1;
+  if (t.split_rounds > 8) t.split_rounds = 8;
+  if (t.push_pieces < 1) t.push_pieces = 1;
+  if (t.host_piece_mb < 1) t.host_piece_mb = 1;
+}
+
+void load_from_environment() {
+  for (const Entry& e : TABLE) {
+    const char* v = getenv(e.name);   // the library's only look at the environment for its knobs
+    if (v && *v && !assign(g_tuning, e, v)) fprintf(stderr, "[m2s] %s=%s ignored: not a number\n", e.name, v);
+  }
+  sanitise(g_tuning);
+}
+
+}  // namespace
+
+const Tuning& tuning() {
+  std::call_once(g_once, load_from_environment);
+  return g_tuning;
+}
+
+int tuning_set(const char* name, const char* value) {
+  (void)tuning();
+  if (!name) return -1;
+  std::lock_guard<std::mutex> lk(g_set_mu);
+  for (const Entry& e : TABLE) {
+    if (strcmp(e.name, name) != 0) continue;
+    if (value == nullptr || *value == 0) {
+      const Tuning defaults;
+      copy_field(g_tuning, defaults, e);
+    } else if (!assign(g_tuning, e, value)) {
+      return -1;
+    }
+    sanitise(g_tuning);
+    return 0;
+  }
+  return -1;
+}
+
+int tuning_describe(char* buf, int cap) {
+  const Tuning& t = tuning();
+  int need = 0;
+  for (const Entry& e : TABLE) {
+    char line[96];
+    const char* field = reinterpret_cast<const char*>(&t) + e.offset;
+    int n = 0;
+    switch (e.kind) {
+      case K_INT: n = snprintf(line, sizeof(line), "%s=%d\n", e.name, *reinterpret_cast<const int*>(field)); break;
+      case K_U32: n = snprintf(line, sizeof(line), "%s=%u\n", e.name, *reinterpret_cast<const uint32_t*>(field)); break;
+      case K_F32: n = snprintf(line, sizeof(line), "%s=%.9g\n", e.name, (double)*reinterpret_cast<const float*>(field)); break;
+      case K_F64: n = snprintf(line, sizeof(line), "%s=%.17g\n", e.name, *reinterpret_cast<const double*>(field)); break;
+    }
+    if (buf && need + n < cap) memcpy(buf + need, line, (size_t)n);
+    need += n;
+  }
+  if (buf && cap > 0) buf[need < cap ? need : cap - 1] = 0;
+  return need;
+}
+
+}  // namespace m2s

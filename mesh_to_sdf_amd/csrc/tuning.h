@@ -1,0 +1,46 @@
+// tuning.h — every run-time knob of the library, in one table.
+//
+// The values are read from the environment ONCE, when the library is first used (tuning()), by the single getenv loop in
+// tuning.cpp; a process that wants to change one afterwards — the tests that force a walk flavour, tools/soak_modes.py — calls
+// m2s_tuning_set(name, value) (include/m2s.h).  None of them changes a result: they select between code paths that produce the
+// same bits (that is what the tests use them for) or move a crossover.  DESIGN.md §9 carries the same table with the
+// measurements behind the defaults.
+#pragma once
+#include <stdint.h>
+
+namespace m2s {
+
+struct Tuning {
+  // ---- diagnostics
+  int stats = 0;                    // M2S_STATS        1: traversal counters of the packet walk on stderr, 2: + a counting pass from the final bound
+  int host_times = 0;               // M2S_HOST_TIMES   1: where the host time of a call goes, on stderr
+  // ---- which walk (tests force each flavour; the defaults are measured crossovers, distance.hip)
+  int lane_walk = -1;               // M2S_LANE_WALK    -1 automatic, 0 never, 1 always: one voxel / query per lane instead of one packet per wave
+  double lane_ratio = 8.0;          // M2S_LANE_RATIO   grid: lane walk above this many triangles per packet brick
+  double query_lane_coeff = 3500.0; // M2S_QUERY_LANE_COEFF   queries: lane walk below coeff * T^0.55 queries
+  double brute_max = -1.0;          // M2S_BRUTE_MAX    tree-less path for cells x triangles (queries x triangles) up to this; < 0: automatic, 0: never
+  uint32_t cut_min_packets = 100000;// M2S_CUT_MIN_PACKETS   grid: cut lists from this many packets on
+  uint32_t query_cut_min = 20000;   // M2S_QUERY_CUT_MIN     queries: cut lists from this many packets on
+  int query_launch_tight = 0;       // M2S_QUERY_LAUNCH_TIGHT  test hook: forces the consecutive-packet fallback of the query packets
+  // ---- cut lists
+  float cut_near = 2.0f;            // M2S_CUT_NEAR     emission radius of a list entry, in brick radii (next to the surface)
+  float cut_far = 1.0f / 32.0f;     // M2S_CUT_FAR      ... and as a fraction of the distance (far from it)
+  uint32_t cut_wave_cap = 0;        // M2S_CUT_WAVE_CAP node visits after which a k_cut wave emits what it meets; 0: max(120, 20 x tree depth)
+  // ---- heavy packets (distance.hip "split walk")
+  int split = -1;                   // M2S_SPLIT        -1 automatic, 0 never, 1 always: packets that exhaust their budget hand the rest of their ranges to several waves
+  uint32_t split_budget = 0;        // M2S_SPLIT_BUDGET work units (node tests + 4 x exact evaluations) a wave spends on one item; 0: automatic
+  uint32_t split_ways = 8;          // M2S_SPLIT_WAYS   pieces the unfinished ranges of an item are cut into
+  uint32_t split_rounds = 3;        // M2S_SPLIT_ROUNDS follow-up launches (the last one walks to the end)
+  // ---- tree
+  uint32_t leaf_max = 2;            // M2S_LEAF_MAX     triangles per collapsed leaf
+  // ---- host-pointer calls and peer delivery
+  uint32_t host_piece_mb = 32;      // M2S_HOST_PIECE_MB   x-pieces of the result streamed to the host while the next is walked
+  uint32_t push_pieces = 4;         // M2S_PUSH_PIECES     x-pieces of a slab pushed to the peers while the next is walked
+  uint32_t push_blocks = 0;         // M2S_PUSH_BLOCKS     workgroups of a push kernel; 0: 256 (pieces) / 64 (trailing)
+};
+
+const Tuning& tuning();                                   // loaded from the environment on first use
+int tuning_set(const char* name, const char* value);      // value NULL: back to the default; 0 ok, -1 unknown name / unparsable value
+int tuning_describe(char* buf, int cap);                  // "NAME=value\n" lines of the current values; returns the length needed
+
+}  // namespace m2s

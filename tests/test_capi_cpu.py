@@ -28,7 +28,7 @@ def test_exports_match_header(lib):
     assert declared == set(_lib.EXPORTS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.m2s_version() == 4
+    assert lib.m2s_version() == 5
 
 
 def test_struct_layout_matches_header(tmp_path):

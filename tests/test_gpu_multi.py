@@ -11,6 +11,7 @@ import sys
 import numpy as np
 import pytest
 
+from mesh_to_sdf_amd import _lib
 from mesh_to_sdf_amd import (AccelerationMethod, Exchange, Grid, Partition, PeerMode, SignMethod, Topology, generate_grid_sdf,
                              generate_grid_sdf_multi, generate_sdf, generate_sdf_multi, interleaved_slab, meshes, slab_bounds)
 
@@ -120,8 +121,7 @@ def test_interleaved_calls_fuzz(case):
     if case % 4 == 2:
         hi[0] = lo[0] + (hi[0] - lo[0]) * 8   # anisotropic: long cells along x, so packet bricks thin along x
     g = Grid.from_bounding_box(lo, hi, counts)
-    os.environ["M2S_CUT_MIN_PACKETS"] = "8"
-    try:
+    with _lib.knobs(M2S_CUT_MIN_PACKETS=8):
         dv, di = torch.as_tensor(v, device="cuda:0"), torch.as_tensor(idx.astype(np.int64), device="cuda:0")
         for sign in (SignMethod.Raycast, SignMethod.Normal):
             want = generate_grid_sdf(dv, Topology.TriangleList(di), g, sign)
@@ -132,8 +132,6 @@ def test_interleaved_calls_fuzz(case):
                 used += period != 0
                 generate_grid_sdf(dv, Topology.TriangleList(di), g, sign, x_slab=(a, b), x_period=period, out=out)
             assert torch.equal(out.view(torch.int32), want.view(torch.int32)), (case, sign, counts, world, used)
-    finally:
-        os.environ.pop("M2S_CUT_MIN_PACKETS", None)
 
 
 def test_multi_interleaved_where_the_grid_does_not_allow_it():

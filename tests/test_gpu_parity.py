@@ -10,6 +10,7 @@ import numpy as np
 import pytest
 
 import oracle as orc
+from mesh_to_sdf_amd import _lib
 from mesh_to_sdf_amd import (AccelerationMethod, Grid, M2SPanic, M2STimings, SignMethod, Topology, generate_grid_sdf,
                              generate_sdf, meshes)
 
@@ -18,7 +19,7 @@ F = np.float32
 TOL = 1e-5  # north_star tolerance (absolute, f32 distances); signs must match exactly
 
 
-@pytest.fixture(autouse=True, params=["default", "cut lists on every grid", "lane walks"])
+@pytest.fixture(autouse=True, params=["default", "cut lists on every grid", "lane walks", "split walks"])
 def cut_lists_mode(request):
     """The cut lists (k_cut) are used from 100 000 packets per launch upwards and the packet walk of generic queries from a
     few million queries; the second run of every test lowers the thresholds and forces the packet walks, so that the nasty
@@ -37,17 +38,20 @@ def cut_lists_mode(request):
         pytest.skip("a report against minutes of CPU propagation: once is enough (the kernels' modes are covered by the other tests)")
     if mode == "lane walks" and big:
         pytest.skip("the lane walk is not meant for this size")
+    if mode == "split walks" and big:
+        pytest.skip("a budget of 24 work units is for small inputs (test_split_walk_* covers the large ones with realistic budgets)")
+    # the library reads its knobs from the environment once; afterwards they are switched through m2s_tuning_set (_lib.set_knob)
+    forced = {}
     if mode == "cut lists on every grid":
-        os.environ["M2S_CUT_MIN_PACKETS"] = "8"
-        os.environ["M2S_QUERY_CUT_MIN"] = "1"
-        os.environ["M2S_LANE_WALK"] = "0"
-        os.environ["M2S_BRUTE_MAX"] = "0"         # no brute-force shortcut for tiny problems (the default mode takes it): the walks must see them
+        # M2S_BRUTE_MAX=0: no brute-force shortcut for tiny problems (the default mode takes it): the walks must see them
+        forced = {"M2S_CUT_MIN_PACKETS": 8, "M2S_QUERY_CUT_MIN": 1, "M2S_LANE_WALK": 0, "M2S_BRUTE_MAX": 0, "M2S_SPLIT": 0}
     elif mode == "lane walks":
-        os.environ["M2S_LANE_WALK"] = "1"
-        os.environ["M2S_BRUTE_MAX"] = "0"
-    yield
-    for k in ("M2S_CUT_MIN_PACKETS", "M2S_QUERY_CUT_MIN", "M2S_LANE_WALK", "M2S_BRUTE_MAX"):
-        os.environ.pop(k, None)
+        forced = {"M2S_LANE_WALK": 1, "M2S_BRUTE_MAX": 0}
+    elif mode == "split walks":
+        # every packet that lasts longer than a few node tests hands the rest of its ranges to other waves (distance.hip, split walk)
+        forced = {"M2S_SPLIT": 1, "M2S_SPLIT_BUDGET": 24, "M2S_SPLIT_WAYS": 3, "M2S_LANE_WALK": 0, "M2S_BRUTE_MAX": 0}
+    with _lib.knobs(**forced):
+        yield
 
 
 def bits(a):
@@ -204,11 +208,8 @@ def test_generic_consecutive_packet_fallback():
     v, idx = meshes.blob(60, 31)
     q = meshes.uniform_queries(*meshes.extended_bbox(v, 0.1), 50_000)
     want = orc.generate_sdf(v, idx, q, accel=3, fast=True)
-    os.environ["M2S_QUERY_LAUNCH_TIGHT"] = "1"
-    try:
+    with _lib.knobs(M2S_QUERY_LAUNCH_TIGHT=1):
         got = generate_sdf(v, Topology.TriangleList(idx), q, AccelerationMethod.RtreeBvh)
-    finally:
-        os.environ.pop("M2S_QUERY_LAUNCH_TIGHT", None)
     assert_bit_equal(got, want, "consecutive-packet fallback")
 
 
@@ -453,17 +454,14 @@ def test_tiny_grids_brute_force_matches_walks_and_oracle(suzanne):
 
     from mesh_to_sdf_amd import Mesh
 
-    if os.environ.get("M2S_BRUTE_MAX") == "0":
+    if float(_lib.describe_knobs()["M2S_BRUTE_MAX"]) == 0.0:
         pytest.skip("this run forces the walks")
     v, idx = suzanne
     for counts, lo_hi in (([16, 16, 16], None), ([13, 7, 21], None), ([24, 5, 9], ((-2.0, -0.5, -1.0), (2.0, 0.5, 1.5)))):
         g = grid_of(v, counts) if lo_hi is None else Grid.from_bounding_box(lo_hi[0], lo_hi[1], counts)
         for sign in (SignMethod.Raycast, SignMethod.Normal):
-            os.environ["M2S_BRUTE_MAX"] = "0"
-            try:
+            with _lib.knobs(M2S_BRUTE_MAX=0):
                 walk = generate_grid_sdf(v, Topology.TriangleList(idx), g, sign)
-            finally:
-                os.environ.pop("M2S_BRUTE_MAX", None)
             t = M2STimings()
             brute = generate_grid_sdf(v, Topology.TriangleList(idx), g, sign, timings=t)
             assert_bit_equal(brute, walk, f"brute force vs walk {counts} {sign.name}")
@@ -498,23 +496,15 @@ def test_four_million_triangles_every_walk_equals_brute_force():
     g = Grid.from_bounding_box(lo, hi, [40, 36, 44])
     dv = torch.as_tensor(v, device="cuda")
     topo = Topology.TriangleList(torch.as_tensor(idx.astype(np.int64), device="cuda").to(torch.int32))
-    saved = {k: os.environ.get(k) for k in ("M2S_LANE_WALK", "M2S_CUT_MIN_PACKETS", "M2S_BRUTE_MAX")}
-    try:
-        for sign in (SignMethod.Raycast, SignMethod.Normal):
-            want = generate_grid_sdf(dv, topo, g, sign, algorithm=1).cpu().numpy()
-            assert np.isfinite(want).all() and (want < 0).any() and (want > 0).any()
-            for name, env in (("default", {}), ("packet walk", {"M2S_LANE_WALK": "0"}),
-                              ("packet walk + cut lists", {"M2S_LANE_WALK": "0", "M2S_CUT_MIN_PACKETS": "1"}), ("lane walk", {"M2S_LANE_WALK": "1"})):
-                for k in saved:
-                    os.environ.pop(k, None)
-                os.environ.update(env)
+    for sign in (SignMethod.Raycast, SignMethod.Normal):
+        want = generate_grid_sdf(dv, topo, g, sign, algorithm=1).cpu().numpy()
+        assert np.isfinite(want).all() and (want < 0).any() and (want > 0).any()
+        for name, env in (("default", {}), ("packet walk", {"M2S_LANE_WALK": 0}),
+                          ("packet walk + cut lists", {"M2S_LANE_WALK": 0, "M2S_CUT_MIN_PACKETS": 1}),
+                          ("packet walk, split", {"M2S_LANE_WALK": 0, "M2S_SPLIT": 1, "M2S_SPLIT_BUDGET": 200}), ("lane walk", {"M2S_LANE_WALK": 1})):
+            with _lib.knobs(**env):
                 got = generate_grid_sdf(dv, topo, g, sign).cpu().numpy()
-                assert_bit_equal(got, want, f"4 M triangles, {sign.name}, {name}")
-    finally:
-        for k, val in saved.items():
-            os.environ.pop(k, None)
-            if val is not None:
-                os.environ[k] = val
+            assert_bit_equal(got, want, f"4 M triangles, {sign.name}, {name}")
 
 
 def test_x_slabs_concatenate(suzanne):
@@ -925,8 +915,7 @@ def test_cut_lists_where_many_triangles_are_equidistant(shape, sign):
     forced onto these small grids (fixture) and the result must equal the on-device brute force bit for bit."""
     import os
 
-    os.environ["M2S_CUT_MIN_PACKETS"] = "8"
-    try:
+    with _lib.knobs(M2S_CUT_MIN_PACKETS=8):
         if shape.startswith("sphere"):
             v, idx = _uv_sphere(96, 48)
             lo, hi = (np.array([-0.6] * 3, F), np.array([0.6] * 3, F)) if "inside" in shape else (np.array([-4.0, -3.0, -2.5], F), np.array([3.0, 4.0, 5.0], F))
@@ -947,8 +936,6 @@ def test_cut_lists_where_many_triangles_are_equidistant(shape, sign):
         a = generate_grid_sdf(v, Topology.TriangleList(idx), g, sign, algorithm=0)
         b = generate_grid_sdf(v, Topology.TriangleList(idx), g, sign, algorithm=1)
         assert_bit_equal(a, b, f"{shape} {sign.name}")
-    finally:
-        os.environ.pop("M2S_CUT_MIN_PACKETS", None)
 
 
 @pytest.mark.parametrize("counts", [[260, 9, 33], [7, 300, 5], [3, 6, 500], [64, 1, 64]])

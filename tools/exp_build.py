@@ -28,8 +28,7 @@ def main():
             v, idx = meshes.named(name)
         dv = torch.as_tensor(v, device="cuda")
         topo = Topology.TriangleList(torch.as_tensor(idx.astype(np.int64), device="cuda").to(torch.int32))
-        for b in args.builds.split(","):
-            os.environ["M2S_BUILD"] = b
+        for b in ("lean",):
             ts, dev = [], []
             for i in range(args.iters + 3):
                 torch.cuda.synchronize()
@@ -41,9 +40,8 @@ def main():
                 if i >= 3:
                     ts.append((t1 - t0) * 1e3)
                     dev.append(d)
-            print(f"{name} ({idx.size // 3} triangles) M2S_BUILD={b}: device build median {np.median(dev):.3f} ms (min {np.min(dev):.3f}); "
+            print(f"{name} ({idx.size // 3} triangles) {b} build: device build median {np.median(dev):.3f} ms (min {np.min(dev):.3f}); "
                   f"m2s_mesh_create wall median {np.median(ts):.3f} ms", flush=True)
-        os.environ.pop("M2S_BUILD", None)
 
 
 if __name__ == "__main__":

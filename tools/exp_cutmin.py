@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Step time of small / medium grids with and without cut lists (M2S_CUT_MIN_PACKETS is read per call)."""
+"""Step time of small / medium grids with and without cut lists (M2S_CUT_MIN_PACKETS switched through m2s_tuning_set)."""
 import os
 import sys
 import time
@@ -9,7 +9,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 
-from mesh_to_sdf_amd import Grid, M2STimings, SignMethod, Topology, generate_grid_sdf, meshes  # noqa: E402
+from mesh_to_sdf_amd import _lib, Grid, M2STimings, SignMethod, Topology, generate_grid_sdf, meshes  # noqa: E402
 
 for mesh in ("blob-100k", "blob-6k"):
     v, idx = meshes.named(mesh)
@@ -21,7 +21,7 @@ for mesh in ("blob-100k", "blob-6k"):
         out = torch.empty(n ** 3, dtype=torch.float32, device="cuda")
         res = []
         for cutmin in ("8", "100000000"):
-            os.environ["M2S_CUT_MIN_PACKETS"] = cutmin
+            _lib.set_knob("M2S_CUT_MIN_PACKETS", cutmin)
             ts = []
             for i in range(12):
                 t0 = time.perf_counter()

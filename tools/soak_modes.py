@@ -6,22 +6,17 @@ queries likewise.   python tools/soak_modes.py [--seeds 60] [--first 0] [--secon
 import argparse, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from mesh_to_sdf_amd import AccelerationMethod, Grid, SignMethod, Topology, generate_grid_sdf, generate_sdf, interleaved_slab, meshes
+from mesh_to_sdf_amd import AccelerationMethod, Grid, SignMethod, Topology, _lib, generate_grid_sdf, generate_sdf, interleaved_slab, meshes
 
-MODES = {"default": {}, "packet + cut lists": {"M2S_CUT_MIN_PACKETS": "8", "M2S_QUERY_CUT_MIN": "1", "M2S_LANE_WALK": "0", "M2S_BRUTE_MAX": "0"},
-         "lane walk": {"M2S_LANE_WALK": "1", "M2S_BRUTE_MAX": "0"}}
-KEYS = ("M2S_CUT_MIN_PACKETS", "M2S_QUERY_CUT_MIN", "M2S_LANE_WALK", "M2S_BRUTE_MAX")
+MODES = {"default": {}, "packet + cut lists": {"M2S_CUT_MIN_PACKETS": 8, "M2S_QUERY_CUT_MIN": 1, "M2S_LANE_WALK": 0, "M2S_BRUTE_MAX": 0, "M2S_SPLIT": 0},
+         "packet + split": {"M2S_LANE_WALK": 0, "M2S_BRUTE_MAX": 0, "M2S_SPLIT": 1, "M2S_SPLIT_BUDGET": 40, "M2S_SPLIT_WAYS": 5},
+         "packet + cut lists + split": {"M2S_CUT_MIN_PACKETS": 8, "M2S_QUERY_CUT_MIN": 1, "M2S_LANE_WALK": 0, "M2S_BRUTE_MAX": 0, "M2S_SPLIT": 1, "M2S_SPLIT_BUDGET": 60},
+         "lane walk": {"M2S_LANE_WALK": 1, "M2S_BRUTE_MAX": 0}}
 
 
 def with_mode(env, fn):
-    for k in KEYS:
-        os.environ.pop(k, None)
-    os.environ.update(env)
-    try:
+    with _lib.knobs(**env):
         return fn()
-    finally:
-        for k in KEYS:
-            os.environ.pop(k, None)
 
 
 def main():
