@@ -296,6 +296,7 @@ int finish_call(const CallCtx& c, DeviceState& st, int* d_err, m2s_timings* t, s
   if (e & ERRF_NAN) return fail(M2S_ERR_NAN, "NaN distance (lib.rs:257)");
   if (e & ERRF_TRAIL_TIMEOUT) return fail(M2S_ERR_HIP, "the trailing peer push gave up waiting for the walk (M2S_PEER_TRAIL)");
   if (e & ERRF_BUILD_TIMEOUT) return fail(M2S_ERR_HIP, "the LBVH build gave up waiting for a neighbouring tile of its sort");
+  if (e & ERRF_SPLIT_OVERFLOW) return fail(M2S_ERR_HIP, "internal: a suspended packet found no accumulator slot (split walk)");
   return M2S_OK;
 }
 
@@ -316,9 +317,9 @@ static std::vector<std::pair<uint32_t, uint32_t>> slab_chunks(const GridParams& 
 static int stats_begin(Arena& ws, hipStream_t stream, DeviceMesh* mesh, unsigned long long** d_stats) {
   *d_stats = nullptr;
   if (!tuning().stats) return 0;
-  *d_stats = ws.take<unsigned long long>(80);
+  *d_stats = ws.take<unsigned long long>(128);
   if (!*d_stats) return fail(M2S_ERR_HIP, "internal: workspace");
-  unsigned long long init[80] = {0};
+  unsigned long long init[128] = {0};
   init[7] = (unsigned long long)tuning().stats;
   M2S_HIP_CHECK(hipMemcpyAsync(*d_stats, init, sizeof(init), hipMemcpyHostToDevice, stream));
   M2S_HIP_CHECK(hipStreamSynchronize(stream));
@@ -327,13 +328,20 @@ static int stats_begin(Arena& ws, hipStream_t stream, DeviceMesh* mesh, unsigned
 }
 static int stats_end(hipStream_t stream, const unsigned long long* d_stats) {
   if (!d_stats) return 0;
-  unsigned long long h[80];
+  unsigned long long h[128];
   M2S_HIP_CHECK(hipMemcpyAsync(h, d_stats, sizeof(h), hipMemcpyDeviceToHost, stream));
   M2S_HIP_CHECK(hipStreamSynchronize(stream));
   const double w = h[3] ? (double)h[3] : 1.0;
   fprintf(stderr, "[m2s stats] packets %llu: per packet node tests %.1f, leaf pre-tests %.1f, exact triangle tests %.1f; node tests that pruned %.1f (by the slab term alone %.1f, by a sphere test %.1f)\n",
           h[3], h[0] / w, h[1] / w, h[2] / w, h[4] / w, h[5] / w, h[6] / w);
-  fprintf(stderr, "[m2s stats]   longest packet: %llu node tests, %llu exact triangle tests (the launch cannot end before its chain does)\n", h[72], h[73]);
+  fprintf(stderr, "[m2s stats]   longest packet: %llu node tests, %llu exact triangle tests (the launch cannot end before its chain does); most work units in one packet %llu, mean %.1f\n", h[72], h[73], h[74],
+          (h[0] + h[1] + 4.0 * h[2]) / w);
+  {  // work units (node tests + pre-tests + 4 x exact evaluations) per packet, in octaves
+    char line[512] = "";
+    for (int o = 0; o < 24; ++o)
+      if (h[80 + o]) snprintf(line + strlen(line), sizeof(line) - strlen(line), " [%u,%u): %llu", o ? 1u << o : 0u, 2u << o, h[80 + o]);
+    fprintf(stderr, "[m2s stats]   packets by work units:%s\n", line);
+  }
   // grid path: by distance of the packet's first voxel to its seed triangle, in cells: [0,1) [1,2) [2,4) ... [64,inf)
   for (int bk = 0; bk < 8; ++bk) {
     const unsigned long long* q = h + 8 + 8 * bk;

@@ -168,7 +168,7 @@ struct PeerOut {
 };
 
 // Device-side error flags (OR-ed into one int by kernels).
-enum : int { ERRF_INDEX_OOB = 1, ERRF_NAN = 2, ERRF_TRAIL_TIMEOUT = 4, ERRF_BUILD_TIMEOUT = 8 };
+enum : int { ERRF_INDEX_OOB = 1, ERRF_NAN = 2, ERRF_TRAIL_TIMEOUT = 4, ERRF_BUILD_TIMEOUT = 8, ERRF_SPLIT_OVERFLOW = 16 };
 
 // Result modes of the nearest search.
 enum : int {
@@ -235,17 +235,20 @@ int build_grid_sign_plane(Arena& ws, hipStream_t st, const DeviceMesh& mesh, con
 // distance.hip
 size_t grid_distance_workspace_bytes(const GridParams& g);
 // Split walk (distance.hip): a packet still walking when the launch runs dry hands the rest of its pre-order ranges to other waves.
-// `cnt`: [0] suspended packets (= accumulator slots taken), [1 + r] items in the list of follow-up round r (r = 1 ..), [8 + r] the
-// "somebody has run out of work" flag of round r (r = 0: the packet launch itself); all cleared per launch by k_split_init.
-constexpr uint32_t SPLIT_MAX_ROUNDS = 6;
+// `cnt`: [0] suspended packets (= accumulator slots taken), [1 + r] items in the list of follow-up round r (r = 1 ..),
+// [16 + x] the time (10 ns ticks, made odd) at which XCD x was handed its last packet, [24 + x] the time it was handed its first,
+// [16 + 16 r + x] the "a wave of XCD x has run out of items" flag of follow-up round r; all cleared per launch by k_split_init.
+constexpr uint32_t SPLIT_MAX_ROUNDS = 6, SPLIT_CNT_WORDS = 16 + 16 * (SPLIT_MAX_ROUNDS + 1);
 struct SplitCtl {
   uint32_t* cnt = nullptr;          // nullptr: no splitting
   uint32_t* slot_packet = nullptr;  // accumulator slot -> packet (0xffffffff: the packet finished by itself after all)
   uint32_t* acc = nullptr;          // per slot: 64 x d2 bits, then (Normal fold) 64 x d2pos bits — merged with atomic minima
   uint4* items = nullptr;           // lists of the follow-up rounds, cap_items each: (packet, first byte, end byte, slot)
   uint32_t cap_slots = 0, cap_items = 0;
-  uint32_t grace = 0;               // work units a walk gets before it may be suspended
-  uint32_t ways = 8;                // pieces an unfinished walk is cut into
+  uint32_t grace = 0;               // work units a walk does before it first looks at the flag (rounds: and between flag and suspension)
+  uint32_t patience_q8 = 0;         // k_packet: (ordinary packet times a walk may outlast the flag) / (rounds before the flag), in 1/256
+  uint32_t idle_below = 0;          // 1: forced — the stamps are all time 0 (flags up, no patience)
+  uint32_t emit_min = 0, emit_max = 0;   // bytes of records: a suspended walk hands over the surviving subtrees of this size range
   uint32_t rounds = 3;              // follow-up launches; the last one walks to the end
 };
 // What a grid walk needs besides the mesh: the seed lattice and the cut lists of a slab (device pointers into the call's arena).

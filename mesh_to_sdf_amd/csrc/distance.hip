@@ -17,6 +17,7 @@
 // arithmetic (see prune_bound), so the minimum is the brute-force minimum bit for bit.
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 
@@ -36,9 +37,33 @@ constexpr int TILE = 128;  // triangles per LDS tile in k_brute (12 KiB)
 // Record `index` of a read-only array through a 32-bit BYTE offset: a wave-uniform offset then goes straight into
 // the scalar load's offset operand (no 64-bit address arithmetic in the walk loops).  Arrays stay below 4 GiB:
 // 96 B x n_tris with n_tris < 2^25 (checked by the build).
+// The records are read through the CONSTANT address space: the mesh arrays are never written while a walk runs, and only for a
+// constant-address-space load does the compiler keep a wave-uniform address on the scalar unit (s_load) whatever else the kernel
+// does — a global-address-space load falls back to the vector unit as soon as the kernel stores or performs an atomic anywhere
+// before it ("may be clobbered"), which is what the suspension path of the split walk does (first version: every node record
+// through global_load, walk 7.9 -> 17.2 ms).
+template <class T>
+__device__ __forceinline__ T record_at_bytes(const void* base, uint32_t byte_offset) {
+  static_assert(sizeof(T) % 16 == 0 && alignof(T) >= 16, "records are whole 16-byte words");
+  // builtin vectors (they load from any address space), declared 16-byte aligned: one s_load_dwordx16 / x8 / x4 each
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  typedef uint32_t u32x8 __attribute__((ext_vector_type(8), aligned(16)));
+  typedef uint32_t u32x16 __attribute__((ext_vector_type(16), aligned(16)));
+  typedef const __attribute__((address_space(4))) char* const_bytes;
+  const const_bytes q = (const_bytes)(uintptr_t)base + byte_offset;
+  constexpr unsigned N16 = sizeof(T) / 64, R16 = sizeof(T) % 64, N8 = R16 / 32, N4 = (R16 % 32) / 16;
+  union { T rec; unsigned char raw[sizeof(T)]; } u;
+#pragma unroll
+  for (unsigned k = 0; k < N16; ++k) { const u32x16 v = *(const __attribute__((address_space(4))) u32x16*)(q + 64 * k); __builtin_memcpy(u.raw + 64 * k, &v, 64); }
+#pragma unroll
+  for (unsigned k = 0; k < N8; ++k) { const u32x8 v = *(const __attribute__((address_space(4))) u32x8*)(q + 64 * N16 + 32 * k); __builtin_memcpy(u.raw + 64 * N16 + 32 * k, &v, 32); }
+#pragma unroll
+  for (unsigned k = 0; k < N4; ++k) { const u32x4 v = *(const __attribute__((address_space(4))) u32x4*)(q + 64 * N16 + 32 * N8 + 16 * k); __builtin_memcpy(u.raw + 64 * N16 + 32 * N8 + 16 * k, &v, 16); }
+  return u.rec;
+}
 template <class T>
 __device__ __forceinline__ T record_at(const T* base, uint32_t index) {
-  return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + index * (uint32_t)sizeof(T));
+  return record_at_bytes<T>(base, index * (uint32_t)sizeof(T));
 }
 
 // The 96-byte triangle records of the exact evaluation are read through the VECTOR path although their address
@@ -371,58 +396,170 @@ struct WalkStats {
 };
 
 // ---- split walk -------------------------------------------------------------------------------
-// A launch whose packets are all resident at once lasts as long as its heaviest packet: blob-100k in 128^3 has one wave doing 2 103
-// node tests + 1 289 exact evaluations against 293 + 85 on average, blob-1M's heaviest packet (4 004 + 2 220) is 3.4 ms alone on a
-// SIMD and bounds every thin slab of an 8-GPU run — while most of the chip has already run out of packets.  So a walk may be
-// SUSPENDED: the pre-order ranges it has not walked yet are cut into pieces, every piece becomes an item of a follow-up launch in
-// which any wave may take it, starting from the bests the packet had reached (the seed is within 10 % of a perfect bound, so a
-// piece loses little by not seeing what the others find), and the pieces' minima are merged with atomic minima on per-voxel words
-// (non-negative floats order like their bit patterns; min is associative and commutative: the same bits as one walk).  Any record
-// may start a piece (walk_range says why).  k_split_finish turns the merged minima into signed distances.
+// When the dispatcher has handed out the last packet of a launch, the wave slots fall idle one by one while the packets still
+// running — the heavy ones: blob-1M's heaviest packet does 4 004 node tests + 2 220 exact evaluations and is 3.4 ms alone on a
+// SIMD — decide when the launch ends.  So a walk may be SUSPENDED: from then on it keeps walking the TOP of what is left (the node
+// tests there prune most of it), but a subtree of at most `emit_max` bytes of records that survives its test is not entered: it
+// becomes an ITEM of a follow-up launch in which any wave may take it, starting from the bests the packet ends with (the seed is
+// within 10 % of a perfect bound, so an item loses little by not seeing what the others find).  The items' minima are merged
+// with atomic minima on per-voxel words (non-negative floats order like their bit patterns; min is associative and commutative:
+// the same bits as one walk), and k_split_finish turns the merged minima into signed distances.  (A first form cut the unwalked
+// record RANGES into eight equal pieces: a piece that starts in the middle of a subtree has lost its ancestors' pruning, seven of
+// eight pieces lie where one test of an ancestor would have dropped them, and the follow-up rounds of 128^3 x blob-100k took longer
+// than the walk — 46 000 items, 1.7 ms.)
 //
-// WHEN to suspend needs no model of the work: the last workgroup of a launch to be dispatched raises a flag ("the dispatcher has
-// run dry": from here on, wave slots fall idle), a walk looks at the flag every CHECK_EVERY work units (one device-scope load,
-// requested one check ahead), and once it is up every walk that has spent its `grace` is suspended at its next check.  The
-// follow-up rounds work through their items with a fixed set of waves striding the list; the first wave to run out raises that
-// round's flag.  The last round walks to the end.  Work unit: one node test or leaf pre-test = 1, one exact evaluation = 4
-// (25 : 20 : 140 vector instructions).
+// WHEN to suspend needs no model of the work: the launch measures itself.  The first workgroup an XCD is handed stamps the time
+// (s_memrealtime, 100 MHz) into that XCD's start word, the last one into its flag ("the dispatcher has run dry here": from now on
+// wave slots of this XCD fall idle).  The time between the two, divided by the rounds of the chip's wave slots that the launch is deep
+// (host: packets / slots - 1, at least 1), is how long an ordinary packet of THIS launch takes at full occupancy; a walk that has done
+// `grace` work units looks every CHECK_EVERY units, and once the flag has been up for `patience` such packet times it is suspended:
+// every ordinary packet that was running when the flag went up has finished by then, what is left are the stragglers.  The
+// follow-up rounds work through their items with a fixed set of waves striding the list; the first wave of an XCD to run out raises
+// the round's flag, and an item still being walked `grace` units later is suspended in its turn (items are bounded — at most emit_max
+// records — so a work count serves there).  The last round walks to the end.  (Forms that did not work: suspending everything still
+// running when the flag goes up — at 128^3, four rounds deep, that is a quarter of all packets, ordinary ones, and the rounds did more
+// work than the walk had left; a fixed number of work units after the flag — right for one grid, 40 % slower on the next: 96^3 wants
+// 1024, 128^3 512, a 1 M-triangle slab 256; counting running packets with two atomics per packet on a per-XCD word — 45 ns each,
+// serialised: 1.2 -> 7 ms.)
+// Work is counted where it is done, at the leaves — 3 units per leaf visited (the node tests that led to it), 1 per
+// pre-test, 4 per exact evaluation (25 : 20 : 140 vector instructions) — so the inner nodes' path carries no bookkeeping at all.
+// The words are per XCD because a word everybody reads at device scope is a serial resource (one flag, one agent-scope load per
+// packet: + 10 ms on the 512^3 walk — 2 M loads, ~5 ns each at the memory side).  Workgroup b of a one-dimensional launch runs on
+// XCD b % 8; writer and readers share that XCD's L2, so the stores are the plain kind (the line stays in that L2) and the loads
+// only have to pass the CU's own L1, which other CUs' stores never refresh: non-temporal loads (L2-served; a workgroup-scope `sc0`
+// load hits the L1 like a plain one and kept seeing the flag down).  A stale word (or another dispatch order) would cost time,
+// never a result.  All of it is inline asm: to the compiler these are not memory operations, so nothing around them is reordered
+// or demoted for their sake (a store at the top of k_packet moved every wave-uniform load of its prologue — seed index, mesh scale —
+// from the scalar to the vector unit, "may be clobbered", behind the cut list's cold miss: + 20 %).  Every string starts with
+// s_nop 4: the compiler does not see into it, and an address that has just come out of a spill lane (a VALU write of an SGPR) needs
+// five wait states before a memory instruction may read it — without them a follow-up round loaded its flag from garbage addresses.
 constexpr uint32_t SPLIT_CHECK_EVERY = 64;
-constexpr uint32_t SPLIT_MIN_PIECE = 16u * (uint32_t)sizeof(NodeExt);   // bytes: pieces shorter than 16 records are not worth an item
+constexpr uint32_t SPLIT_CONTINUATION = 0x80000000u;   // item tag (with the slot): a suspended packet, not a subtree
+#ifndef M2S_SPLIT_DEBUG
+#define M2S_SPLIT_DEBUG 4   // experiment: 1 nothing in the walk, 2 + work accounting, 3 + flag checks, 4 everything
+#endif
 struct SplitState {
   uint32_t units = 0, next_check = 0xffffffffu;   // work done so far; next look at the flag (never, unless armed)
-  uint32_t flag = 0;                              // the flag as loaded one check ago (VGPR; wave-uniform value)
-  const uint32_t* flag_addr = nullptr;
-  bool suspended = false;
+  const uint32_t* flag_addr = nullptr;            // this XCD's flag of the launch (k_packet: the time it went up, odd; rounds: 1)
+  uint32_t patience_q8 = 0;                       // k_packet: patience / rounds-before-the-flag, in 1/256
+  uint32_t grace = 0;
+  bool suspended = false, flag_seen = false;
+  uint32_t resume_end = 0;                        // suspended: the end of the range that was being walked
+  uint32_t* n_ranges = nullptr;                   // k_packet: the caller's count of ranges (zeroed on suspension: its loop ends too)
 };
-__device__ __forceinline__ uint32_t split_flag_load(const uint32_t* addr) {   // written by waves on other XCDs: past this XCD's L2
-  return __hip_atomic_load(addr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+__device__ __forceinline__ uint32_t* split_flag_addr(const SplitCtl& ctl, uint32_t round) {   // this XCD's flag of the round
+  return ctl.cnt + 16u + round * 16u + (blockIdx.x & 7u);
 }
+__device__ __forceinline__ uint32_t split_peek(const uint32_t* addr) {          // wave-uniform address, wave-uniform result
+  uint32_t v;
+  const uint32_t zero = 0;
+  asm volatile("s_nop 4\n\tglobal_load_dword %0, %1, %2 nt\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(zero), "s"(addr));
+  return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+}
+__device__ __forceinline__ void split_poke(uint32_t* addr, uint32_t value) {   // call with one lane active
+  const uint32_t zero = 0;
+  asm volatile("s_nop 4\n\tglobal_store_dword %0, %1, %2" : : "v"(zero), "v"(value), "s"(addr));
+}
+__device__ __forceinline__ uint32_t split_now() { return (uint32_t)__builtin_amdgcn_s_memrealtime(); }   // 10 ns ticks; differences survive the wrap
 __device__ __forceinline__ void split_arm(SplitState& sp, const SplitCtl& ctl, uint32_t round, bool may_suspend) {
   if (ctl.cnt == nullptr || !may_suspend) return;
-  sp.flag_addr = ctl.cnt + 8 + round;
-  sp.flag = split_flag_load(sp.flag_addr);        // arrives while the seed is evaluated
+  sp.flag_addr = split_flag_addr(ctl, round);
   sp.next_check = ctl.grace;
+  sp.grace = ctl.grace;
+  sp.patience_q8 = ctl.patience_q8;
+}
+// k_packet: has this XCD's flag been up for `patience` ordinary packet times?  (the start word lies 8 words behind the flag)
+__device__ __forceinline__ bool split_stragglers_only(const SplitState& sp) {
+  const uint32_t up = split_peek(sp.flag_addr);
+  if (up == 0u) return false;
+  const uint32_t start = split_peek(sp.flag_addr + 8), now = split_now();
+  const uint32_t fill = up - start;                                       // time it took to hand out this XCD's packets
+  const uint32_t allowed = (uint32_t)(((unsigned long long)fill * sp.patience_q8) >> 8);
+  return now - up >= allowed;
+}
+
+// A suspended PACKET (k_packet) leaves its bests and ONE item — "go on at record `off` of range `range`" — and gives up its wave slot;
+// a wave of round 1 walks the top of what is left and turns the subtrees that survive into the items of round 2 (k_split_round).
+// false: no accumulator slot or list entry left (the packet then walks on by itself).
+template <int MODE>
+__device__ __forceinline__ bool split_handover(const SplitCtl& split, uint32_t packet, uint32_t range, uint32_t off, const Best<MODE>& best, int* err) {
+  const uint32_t lane = threadIdx.x & 63u;
+  uint32_t slot = 0, idx = 0;
+  if (lane == 0u) slot = atomicAdd(&split.cnt[0], 1u);
+  slot = __builtin_amdgcn_readfirstlane(slot);
+  if (slot >= split.cap_slots) return false;
+  if (lane == 0u) idx = atomicAdd(&split.cnt[2], 1u);
+  idx = __builtin_amdgcn_readfirstlane(idx);
+  if (idx >= split.cap_items) {
+    if (lane == 0u) split.slot_packet[slot] = 0xffffffffu;                  // the slot stays empty
+    return false;
+  }
+  constexpr uint32_t AW = MODE == MODE_NORMAL_FOLD ? 128u : 64u;
+  uint32_t* acc = split.acc + (size_t)slot * AW;
+  acc[lane] = __float_as_uint(best.d2);
+  if (MODE == MODE_NORMAL_FOLD) {
+    acc[64 + lane] = __float_as_uint(best.d2pos);
+    if (best.nan) atomicOr(err, ERRF_NAN);
+  }
+  if (lane == 0u) {
+    split.items[idx] = make_uint4(packet, off, range, slot | SPLIT_CONTINUATION);
+    split.slot_packet[slot] = packet;
+  }
+  return true;
+}
+
+// Where a suspended walk leaves the subtrees it does not enter: slots of the next round's list, reserved 64 at a time.
+struct EmitState {
+  uint4* list = nullptr;
+  uint32_t* count = nullptr;          // the list's fill counter
+  uint32_t cap = 0;
+  uint32_t base = 0, used = 0, room = 0;
+  uint32_t min_bytes = 0xffffffffu, max_bytes = 0;   // subtrees of min_bytes .. max_bytes of records are handed over; min = ~0: nothing is
+  uint32_t packet = 0, slot = 0;
+};
+__device__ __forceinline__ void emit_begin(EmitState& em, const SplitCtl& ctl, uint32_t next_round, uint32_t packet, uint32_t slot) {
+  em.list = ctl.items + (size_t)(next_round - 1u) * ctl.cap_items;
+  em.count = ctl.cnt + 1u + next_round;
+  em.cap = ctl.cap_items;
+  em.min_bytes = ctl.emit_min;
+  em.max_bytes = ctl.emit_max;
+  em.packet = packet;
+  em.slot = slot;
+}
+// The unused part of the reserved block becomes empty items (first == end): the list has no holes of stale data.
+__device__ __forceinline__ void emit_close(EmitState& em) {
+  const uint32_t i = em.base + em.used + (threadIdx.x & 63u);
+  if (i < em.base + em.room && i < em.cap) em.list[i] = make_uint4(em.packet, 0u, 0u, em.slot);
+  em.used = em.room;
+}
+// One more block of 64 slots; when the list is full, emission is switched off (the walk then enters everything itself).
+__device__ __forceinline__ void emit_reserve(EmitState& em) {
+  uint32_t base = 0;
+  if ((threadIdx.x & 63u) == 0u) base = atomicAdd(em.count, 64u);
+  em.base = __builtin_amdgcn_readfirstlane(base);
+  em.used = 0;
+  em.room = 64u;
+  if (em.base + 64u > em.cap) {       // (what lies below the cap is this wave's to blank)
+    emit_close(em);
+    em.room = 0;
+    em.min_bytes = 0xffffffffu;
+  }
 }
 
 // The pre-order records [off, end) of the oriented-bound tree for the 64 points of a wave: position wave-uniform (SGPR), node
 // records and pre-test planes through scalar loads, a subtree left when no lane's bound reaches it.  BUDGET: the walk may stop
-// early (sp.suspended, off = the first record not yet looked at).
-template <int MODE, bool STATS, bool BUDGET>
+// early (sp.suspended, off = the first record not yet looked at).  EMIT: a suspended walk — surviving subtrees of em.min_bytes ..
+// em.max_bytes are written to the next round's list instead of being entered.
+template <int MODE, bool STATS, bool BUDGET, bool EMIT = false, bool HANDOVER = false>
 __device__ __forceinline__ void walk_span(const DeviceMesh& mesh, f3 p, float slack, Best<MODE>& best, float& thr, uint32_t& off,
-                                          uint32_t end, WalkStats& st, SplitState& sp) {
+                                          uint32_t end, WalkStats& st, SplitState& sp, EmitState* emp = nullptr) {
   // The walk addresses NodeExt by BYTE offset (its skip links are stored that way): the scalar loads then take
   // the offset operand directly and the loop carries no address arithmetic.
   constexpr uint32_t NB = (uint32_t)sizeof(NodeExt);
   while (off < end) {
     off = __builtin_amdgcn_readfirstlane(off);
-    if (BUDGET && sp.units >= sp.next_check) {
-      if (__builtin_amdgcn_readfirstlane((int)sp.flag) != 0) { sp.suspended = true; return; }
-      sp.flag = split_flag_load(sp.flag_addr);    // for the next check
-      sp.next_check = sp.units + SPLIT_CHECK_EVERY;
-    }
-    const NodeExt nr = *reinterpret_cast<const NodeExt*>(reinterpret_cast<const char*>(mesh.ext) + off);
+    const NodeExt nr = record_at_bytes<NodeExt>(mesh.ext, off);
     if (STATS) ++st.box;
-    if (BUDGET) ++sp.units;
     const float ed2 = ext_dist2(p, nr);
     if (STATS && __ballot(!(ed2 > thr)) == 0ull) {
       ++st.pruned;
@@ -438,57 +575,57 @@ __device__ __forceinline__ void walk_span(const DeviceMesh& mesh, f3 p, float sl
       const uint32_t cnt = (nr.skip - off + NB) / (2u * NB);    // triangles of this (possibly collapsed) leaf
       for (uint32_t k = 0; k < cnt; ++k) {
         if (STATS) ++st.ext;
-        if (BUDGET) ++sp.units;
         const TriPlanes tp = record_at(mesh.planes, (uint32_t)nr.tri + k);   // scalar: small, needed for every leaf triangle
         const bool reach = !(planes_dist2(p, tp) > thr);
         if (__ballot(reach) != 0ull) {   // some lane's bound reaches the triangle itself
           if (STATS) { ++st.leaf; st.pairs += (uint32_t)__popcll(__ballot(reach)); }
-          if (BUDGET) sp.units += 4u;
+          if (BUDGET && M2S_SPLIT_DEBUG >= 2) sp.units += 4u;
           const TriRec tr = record_at_vec(mesh.tris, (uint32_t)nr.tri + k);
           eval_triangle_leaf<MODE>(best, p, tr, reach);
           thr = prune_bound(best.d2, slack);
         }
       }
       off = nr.skip;
+      if (BUDGET && M2S_SPLIT_DEBUG >= 2) {
+        sp.units += 3u + cnt;
+        if (M2S_SPLIT_DEBUG >= 3 && sp.units >= sp.next_check) {
+          // (no exit of its own: a second way out of this loop cost the walk 11 % although it was never taken; the loop ends by its
+          // own condition)
+          bool go;
+          if (HANDOVER) go = split_stragglers_only(sp);                   // k_packet: measured patience
+          else {                                                           // a follow-up round: `grace` units after the flag was first seen up
+            go = sp.flag_seen;
+            if (!go && split_peek(sp.flag_addr) != 0u) { sp.flag_seen = true; sp.next_check = sp.units + sp.grace; }
+          }
+          if (go) {
+            // Suspended.  No exit of its own and nothing but three scalar moves here: the loop ends by its condition (and so does the
+            // caller's loop over the ranges, whose count is taken away).  Every other form tried in k_packet — an early return, a
+            // hand-over in this branch that ends the wave, a retry loop around the call, a rewound range counter — cost the 512^3
+            // walk 10 ... 40 % although none of it was ever executed there.
+            if (off < end || HANDOVER) { sp.suspended = true; sp.resume_end = end; end = off; if (HANDOVER) *sp.n_ranges = 0u; }
+            sp.next_check = 0xffffffffu;
+          } else if (HANDOVER || !sp.flag_seen) {
+            sp.next_check = sp.units + SPLIT_CHECK_EVERY;
+          }
+        }
+      }
     } else {
+      if (EMIT) {
+        EmitState& em = *emp;
+        const uint32_t bytes = nr.skip - off;
+        if (bytes >= em.min_bytes && bytes <= em.max_bytes) {
+          if (em.used == em.room) emit_reserve(em);
+          if (em.used < em.room) {
+            if ((threadIdx.x & 63u) == 0u) em.list[em.base + em.used] = make_uint4(em.packet, off, nr.skip, em.slot);
+            ++em.used;
+            off = nr.skip;                                      // somebody else's from here
+            continue;
+          }
+        }
+      }
       off = off + NB;
     }
   }
-}
-
-// Appends the pieces of the unfinished byte ranges to list `round` (lane L <= 15 holds range L - 1 in (s, e); lanes without one
-// hold s == e).  Returns false when the list is full (the caller then walks on by itself); entries below the cap that this wave had
-// already reserved are written as empty items.  Wave-uniform control flow.
-__device__ __forceinline__ bool split_append(const SplitCtl& ctl, uint32_t round, uint32_t packet, uint32_t slot, uint32_t s, uint32_t e) {
-  constexpr uint32_t NB = (uint32_t)sizeof(NodeExt);
-  const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t len = (lane < 16u && e > s) ? e - s : 0u;
-  uint32_t total = len;
-  for (int o = 8; o >= 1; o >>= 1) total += __shfl_xor(total, o);          // over the 16 lanes that may hold a range
-  total = __builtin_amdgcn_readfirstlane(total);
-  uint32_t piece = (total / ctl.ways + NB - 1u) / NB * NB;                 // bytes per piece, whole records
-  piece = max(piece, SPLIT_MIN_PIECE);
-  const uint32_t mine = (len + piece - 1u) / piece;
-  uint32_t before = mine;                                                  // exclusive prefix over the lanes
-  for (uint32_t o = 1; o < 16u; o <<= 1) {
-    const uint32_t t = __shfl_up(before, o);
-    if ((lane & 15u) >= o) before += t;
-  }
-  const uint32_t n_items = __builtin_amdgcn_readfirstlane(__shfl(before, 15));
-  before -= mine;
-  uint32_t base = 0;
-  if (lane == 0u) base = atomicAdd(&ctl.cnt[1u + round], n_items);
-  base = __builtin_amdgcn_readfirstlane(base);
-  const bool fits = base + n_items <= ctl.cap_items;
-  uint4* list = ctl.items + (size_t)(round - 1u) * ctl.cap_items;
-  if (lane < 16u)
-    for (uint32_t j = 0; j < mine; ++j) {
-      const uint32_t i = base + before + j;
-      if (i >= ctl.cap_items) break;
-      const uint32_t first = s + j * piece;
-      list[i] = fits ? make_uint4(packet, first, min(e, first + piece), slot) : make_uint4(packet, 0u, 0u, slot);
-    }
-  return fits;
 }
 
 // The value of one voxel / query, stored the way the call's delivery asks for (plain, peer stores, trailing push).
@@ -522,8 +659,10 @@ __device__ __forceinline__ void store_grid_result(float* __restrict__ out, size_
 // ---- k_packet -------------------------------------------------------------------------------
 // `seed_in` (one TriRec slot per 2^seed_shift bricks per axis, may be null) replaces the greedy descent:
 // the packet starts from a triangle near its own centre (jump-flooding seed pass below).
+// (eight waves per SIMD: the split variant's bookkeeping would otherwise take the kernel to 106 SGPRs — seven waves, - 12 %; the
+// compiler parks what does not fit in spare VGPR lanes)
 template <bool GRID, int MODE, int SIGN, bool STATS, bool SPLIT>
-__global__ __launch_bounds__(64) void k_packet(DeviceMesh mesh, GridParams g, const float4* __restrict__ qsorted,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_packet(DeviceMesh mesh, GridParams g, const float4* __restrict__ qsorted,
                                                const uint32_t* __restrict__ perm, uint32_t n_q,
                                                const uint32_t* __restrict__ plane, float* __restrict__ out,
                                                int* __restrict__ err, uint32_t n_packets,
@@ -531,8 +670,12 @@ __global__ __launch_bounds__(64) void k_packet(DeviceMesh mesh, GridParams g, co
                                                uint32_t seed_ny, uint32_t seed_nz,
                                                const GridParams* __restrict__ seed_lattice, CutList cut, PeerOut peers, SplitCtl split) {
   const int lane = threadIdx.x & 63;
-  // the last workgroup to be dispatched says so: from here on wave slots fall idle (split walk)
-  if (SPLIT && blockIdx.x == gridDim.x - 1u && lane == 0) __hip_atomic_store(&split.cnt[8], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // the first and the last workgroup an XCD is handed stamp the time: start of the launch there; from here on its wave slots fall idle
+  if (SPLIT && (blockIdx.x < 8u || blockIdx.x + 8u >= gridDim.x) && lane == 0) {
+    const uint32_t t = split.idle_below /* forced */ ? 0u : split_now();
+    if (blockIdx.x < 8u) split_poke(split_flag_addr(split, 0u) + 8, t);
+    if (blockIdx.x + 8u >= gridDim.x) split_poke(split_flag_addr(split, 0u), t | 1u);
+  }
   const uint32_t block = xcd_remap(blockIdx.x);
   // wave-uniform, and said so: the brick decode below (two divisions by multiplication, shifts, bounds) then runs on the scalar unit
   const uint32_t packet = (uint32_t)__builtin_amdgcn_readfirstlane((int)block);   // one packet per single-wave workgroup: the slot is free as soon as the walk ends (4 waves per group: +3.8 %)
@@ -575,6 +718,7 @@ __global__ __launch_bounds__(64) void k_packet(DeviceMesh mesh, GridParams g, co
     constexpr uint32_t NB = (uint32_t)sizeof(NodeExt);
     const uint32_t* cl = nullptr;
     uint32_t n_ranges = 1, cut_off_v = 0, cut_end_v = (lane == 1) ? mesh.n_nodes * NB : 0u;   // no list: lane 1 holds the whole tree
+    if (SPLIT) sp.n_ranges = &n_ranges;
     if (cut.lists != nullptr) {
       const uint32_t cb = GRID ? __builtin_amdgcn_readfirstlane((((vox.bx + cut.bx_off) >> cut.log) * cut.ny + (vox.by >> cut.log)) * cut.nz + (vox.bz >> cut.log))
                                : packet;
@@ -639,39 +783,18 @@ __global__ __launch_bounds__(64) void k_packet(DeviceMesh mesh, GridParams g, co
     for (int pass = 0; pass < passes; ++pass) {
       if (pass == 1) { st.box = 0; st.ext = 0; st.leaf = 0; }
       if (STATS) st_ranges = n_ranges;
-      for (uint32_t range = 0; range < n_ranges; ++range) {
+      uint32_t range = 0, off = 0;
+      for (; range < n_ranges; ++range) {
         // (a rounded-up range may reach into the next one: those records are then walked twice, which changes no minimum)
-        uint32_t off = (uint32_t)__builtin_amdgcn_readlane((int)cut_off_v, (int)(1u + range));
+        off = (uint32_t)__builtin_amdgcn_readlane((int)cut_off_v, (int)(1u + range));
         const uint32_t end = (uint32_t)__builtin_amdgcn_readlane((int)cut_end_v, (int)(1u + range));
         if (STATS) st_rbytes += end - off;
-        for (;;) {
-          walk_span<MODE, STATS, SPLIT>(mesh, p, slack, best, thr, off, end, st, sp);
-          if (!SPLIT || !sp.suspended) break;
-          // hand over what is left — [off, end) of this range and the ranges behind it — with the bests reached so far
-          uint32_t slot = 0;
-          if (lane == 0) slot = atomicAdd(&split.cnt[0], 1u);
-          slot = __builtin_amdgcn_readfirstlane(slot);
-          bool handed = slot < split.cap_slots;
-          if (handed) {
-            const uint32_t l = (uint32_t)lane;
-            const bool live = l >= 1u + range && l <= n_ranges;               // lane L holds range L - 1
-            const uint32_t s = live ? (l == 1u + range ? off : cut_off_v) : 0u, e = live ? cut_end_v : 0u;
-            handed = split_append(split, 1u, packet, slot, s, e);
-            if (lane == 0) split.slot_packet[slot] = handed ? packet : 0xffffffffu;
-          }
-          if (handed) {
-            constexpr uint32_t AW = MODE == MODE_NORMAL_FOLD ? 128u : 64u;
-            uint32_t* acc = split.acc + (size_t)slot * AW;
-            acc[lane] = __float_as_uint(best.d2);
-            if (MODE == MODE_NORMAL_FOLD) {
-              acc[64 + lane] = __float_as_uint(best.d2pos);
-              if (best.nan) atomicOr(err, ERRF_NAN);
-            }
-            return;                                                            // k_split_finish writes this packet's voxels
-          }
-          sp.suspended = false;                                                // no room in the lists: walk on, never to be suspended again
-          sp.next_check = 0xffffffffu;
-        }
+        walk_span<MODE, STATS, SPLIT, false, SPLIT>(mesh, p, slack, best, thr, off, end, st, sp);
+      }
+      if (SPLIT && sp.suspended && M2S_SPLIT_DEBUG >= 4) {
+        // (range has been stepped once more by the loop's increment)
+        if (!split_handover<MODE>(split, packet, range - 1u, off, best, err)) atomicOr(err, ERRF_SPLIT_OVERFLOW);   // cannot happen: a slot per packet
+        return;                                                                // k_split_finish writes this packet's voxels
       }
     }
   }
@@ -722,21 +845,26 @@ __global__ __launch_bounds__(64) void k_packet(DeviceMesh mesh, GridParams g, co
   else if (store) out[out_index] = result;
 }
 
-// One follow-up round of the split walk (grid path): a fixed set of single-wave workgroups strides the round's list; an item is a
-// piece [first, end) of a suspended packet's ranges.  The wave rebuilds the packet's 64 points, starts from the slot's current
-// minima (plain loads: a stale value is merely a looser bound), walks the piece and folds what it found into the slot.  Except
-// in the last round (`final`) a piece may be suspended again; what is left of it goes to the next round's list.
+// One follow-up round of the split walk (grid path): a fixed set of single-wave workgroups strides the round's list.  An item is either
+// a CONTINUATION — a suspended packet: the rest of its range `range` from record `first` on, and the ranges behind it (round 1) — or a
+// subtree [first, end) that a suspended walk did not enter.  The wave rebuilds the packet's 64 points, starts from the slot's current
+// minima (plain loads: a stale value is merely a looser bound), walks, and folds what it found into the slot.  A continuation is walked
+// in emit mode from the start; a subtree may be suspended in its turn (except in the last round, `final`) and is then finished in emit
+// mode: what is not entered goes to the next round's list.
 template <int MODE>
-__global__ __launch_bounds__(64) void k_split_round(DeviceMesh mesh, GridParams g, SplitCtl split, uint32_t round, bool final, int* __restrict__ err) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_split_round(DeviceMesh mesh, GridParams g, SplitCtl split, CutList cut, uint32_t round, bool final, int* __restrict__ err) {
   constexpr uint32_t AW = MODE == MODE_NORMAL_FOLD ? 128u : 64u;
+  constexpr uint32_t NB = (uint32_t)sizeof(NodeExt);
   const int lane = threadIdx.x & 63;
   const uint32_t n_items = min(split.cnt[1u + round], split.cap_items);
   const uint4* list = split.items + (size_t)(round - 1u) * split.cap_items;
   for (uint32_t i = blockIdx.x; i < n_items; i += gridDim.x) {
     const uint4 it = list[i];
-    const uint32_t packet = __builtin_amdgcn_readfirstlane(it.x), end = __builtin_amdgcn_readfirstlane(it.z), slot = __builtin_amdgcn_readfirstlane(it.w);
+    const uint32_t packet = __builtin_amdgcn_readfirstlane(it.x), third = __builtin_amdgcn_readfirstlane(it.z), tag = __builtin_amdgcn_readfirstlane(it.w);
+    const uint32_t slot = tag & ~SPLIT_CONTINUATION;
+    const bool continuation = (tag & SPLIT_CONTINUATION) != 0u;
     uint32_t off = __builtin_amdgcn_readfirstlane(it.y);
-    if (off >= end) continue;                                              // an empty item (a list that overflowed)
+    if (!continuation && off >= third) continue;                           // an empty item (the unused part of a reserved block)
     const GridBrick vox = grid_lane_voxel(g, packet, lane);
     const f3 p = grid_point(g, vox);
     const float scale = fmaxf(mesh_scale(mesh), fmaxf(fabsf(p.x), fmaxf(fabsf(p.y), fabsf(p.z))));
@@ -749,15 +877,36 @@ __global__ __launch_bounds__(64) void k_split_round(DeviceMesh mesh, GridParams 
     if (MODE == MODE_NORMAL_FOLD) { d2pos_in = acc[64 + lane]; best.d2pos = __uint_as_float(d2pos_in); }
     float thr = prune_bound(best.d2, slack);
     WalkStats st;
-    SplitState sp;
-    split_arm(sp, split, round, !final);
-    for (;;) {
-      walk_span<MODE, false, true>(mesh, p, slack, best, thr, off, end, st, sp);
-      if (!sp.suspended) break;
-      const uint32_t l = (uint32_t)lane;
-      if (split_append(split, round + 1u, packet, slot, l == 1u ? off : 0u, l == 1u ? end : 0u)) break;
-      sp.suspended = false;                                                // no room: finish the piece here
-      sp.next_check = 0xffffffffu;
+    SplitState idle;
+    EmitState em;
+    if (continuation) {
+      // the packet's ranges again (k_packet's decode), from range `third` on
+      uint32_t n_ranges = 1, cut_off_v = 0, cut_end_v = (lane == 1) ? mesh.n_nodes * NB : 0u;
+      if (cut.lists != nullptr) {
+        const uint32_t cb = __builtin_amdgcn_readfirstlane((((vox.bx + cut.bx_off) >> cut.log) * cut.ny + (vox.by >> cut.log)) * cut.nz + (vox.bz >> cut.log));
+        const uint32_t cw = cut.lists[(size_t)cb * CUT_WORDS + ((uint32_t)lane & 15u)];
+        const uint32_t cS = cut_start_bits(mesh.n_nodes), cfirst = cw & ((1u << cS) - 1u);
+        const uint32_t clen = ((cw >> cS) & ((1u << (27u - cS)) - 1u)) << (cw >> 27);
+        cut_off_v = cfirst * NB;
+        cut_end_v = min(cfirst + clen, mesh.n_nodes) * NB;
+        n_ranges = __builtin_amdgcn_readfirstlane(cw);
+      }
+      if (!final) emit_begin(em, split, round + 1u, packet, slot);           // (a one-round configuration walks everything here)
+      for (uint32_t range = third; range < n_ranges; ++range) {
+        if (range != third) off = (uint32_t)__builtin_amdgcn_readlane((int)cut_off_v, (int)(1u + range));
+        const uint32_t end = (uint32_t)__builtin_amdgcn_readlane((int)cut_end_v, (int)(1u + range));
+        walk_span<MODE, false, false, true>(mesh, p, slack, best, thr, off, end, st, idle, &em);
+      }
+      emit_close(em);
+    } else {
+      SplitState sp;
+      split_arm(sp, split, round, !final);
+      walk_span<MODE, false, true>(mesh, p, slack, best, thr, off, third, st, sp);
+      if (sp.suspended) {
+        emit_begin(em, split, round + 1u, packet, slot);
+        walk_span<MODE, false, false, true>(mesh, p, slack, best, thr, off, sp.resume_end, st, idle, &em);
+        emit_close(em);
+      }
     }
     // NaN never enters a minimum (fminf drops it), so the words stay ordered like non-negative floats
     if (__float_as_uint(best.d2) < d2_in) atomicMin(&acc[lane], __float_as_uint(best.d2));
@@ -767,7 +916,7 @@ __global__ __launch_bounds__(64) void k_split_round(DeviceMesh mesh, GridParams 
     }
   }
   // out of items: from here on this wave's slot is idle (many waves write the same word: harmless)
-  if (!final && lane == 0) __hip_atomic_store(&split.cnt[8u + round], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (!final && lane == 0) split_poke(split_flag_addr(split, round), 1u);
 }
 
 // The voxels of the suspended packets, from their merged minima.
@@ -796,7 +945,7 @@ __global__ __launch_bounds__(256) void k_split_finish(GridParams g, const uint32
 }
 // Clears the counters and flags of a split walk; `forced`: the flags start raised (every walk is suspended at its first check).
 __global__ void k_split_init(uint32_t* __restrict__ cnt, uint32_t forced) {
-  if (threadIdx.x < 32u) cnt[threadIdx.x] = (threadIdx.x >= 8u && threadIdx.x < 8u + SPLIT_MAX_ROUNDS + 1u) ? forced : 0u;
+  for (uint32_t i = threadIdx.x; i < SPLIT_CNT_WORDS; i += blockDim.x) cnt[i] = i >= 16u ? forced : 0u;   // forced: every flag starts raised
 }
 
 // M2S_PEER_TRAIL: pushes the slab to the peers unit by unit while the walk is still running.  Unit u = the x-layers of
@@ -1784,17 +1933,40 @@ void launch_packet(hipStream_t st, const DeviceMesh& mesh, const GridParams& g, 
                    uint32_t n_q, const uint32_t* plane, float* out, int* err, uint32_t n_packets,
                    const uint32_t* seed_in = nullptr, uint32_t seed_shift = 0, uint32_t seed_ny = 0,
                    uint32_t seed_nz = 0, const GridParams* seed_lattice = nullptr, CutList cut = {nullptr, 0, 0, 0, 0, nullptr},
-                   const PeerOut* peers_in = nullptr) {
+                   const PeerOut* peers_in = nullptr, const SplitCtl* split_in = nullptr) {
   PeerOut peers{};
   if (peers_in) peers = *peers_in;
+  SplitCtl split{};
+  if (split_in) split = *split_in;
   const uint32_t per = 8u << XCD_RUN_LOG;                              // one run on each of the eight XCDs
   const uint32_t grid_blocks = ((n_packets + per - 1) / per) * per;    // a whole number of runs per XCD (xcd_remap)
-  if (mesh.stats != nullptr)   // M2S_STATS: the counting variant (a few SALU ops more per node)
-    hipLaunchKernelGGL((k_packet<GRID, MODE, SIGN, true>), dim3(grid_blocks), dim3(64), 0, st, mesh, g,
-                       qs, perm, n_q, plane, out, err, n_packets, seed_in, seed_shift, seed_ny, seed_nz, seed_lattice, cut, peers);
+  if (mesh.stats != nullptr)   // M2S_STATS: the counting variant (a few SALU ops more per node); never suspended, so that a packet's counters are whole
+    hipLaunchKernelGGL((k_packet<GRID, MODE, SIGN, true, false>), dim3(grid_blocks), dim3(64), 0, st, mesh, g,
+                       qs, perm, n_q, plane, out, err, n_packets, seed_in, seed_shift, seed_ny, seed_nz, seed_lattice, cut, peers, split);
+  else if (GRID && MODE != MODE_NEAREST_NORMAL && split.cnt != nullptr)
+    hipLaunchKernelGGL((k_packet<GRID, MODE == MODE_NEAREST_NORMAL ? MODE_UNSIGNED : MODE, SIGN, false, GRID>), dim3(grid_blocks), dim3(64), 0, st, mesh, g,
+                       qs, perm, n_q, plane, out, err, n_packets, seed_in, seed_shift, seed_ny, seed_nz, seed_lattice, cut, peers, split);
   else
-    hipLaunchKernelGGL((k_packet<GRID, MODE, SIGN, false>), dim3(grid_blocks), dim3(64), 0, st, mesh, g,
-                       qs, perm, n_q, plane, out, err, n_packets, seed_in, seed_shift, seed_ny, seed_nz, seed_lattice, cut, peers);
+    hipLaunchKernelGGL((k_packet<GRID, MODE, SIGN, false, false>), dim3(grid_blocks), dim3(64), 0, st, mesh, g,
+                       qs, perm, n_q, plane, out, err, n_packets, seed_in, seed_shift, seed_ny, seed_nz, seed_lattice, cut, peers, split);
+}
+// The follow-up rounds and the finish of a split grid walk (after launch_packet on the same stream).
+template <int MODE, int SIGN>
+void launch_split_rounds(hipStream_t st, const DeviceMesh& mesh, const GridParams& g, const uint32_t* plane, float* out, int* err,
+                         const SplitCtl& split, const CutList& cut, const PeerOut* peers_in) {
+  PeerOut peers{};
+  if (peers_in) peers = *peers_in;
+  // as many single-wave workgroups as two rounds of the chip's wave slots: enough to fill it whatever the items' lengths, few enough
+  // that a wave gets several items of a long list
+  constexpr unsigned waves = 16384;
+  const bool trace = tuning().split_report >= 2;   // debugging aid: which launch faults
+  if (trace) { const hipError_t e = hipStreamSynchronize(st); fprintf(stderr, "[m2s split] packet launch: %s\n", hipGetErrorString(e)); }
+  for (uint32_t r = 1; r <= split.rounds; ++r) {
+    hipLaunchKernelGGL((k_split_round<MODE>), dim3(waves), dim3(64), 0, st, mesh, g, split, cut, r, r == split.rounds, err);
+    if (trace) { const hipError_t e = hipStreamSynchronize(st); fprintf(stderr, "[m2s split] round %u: %s\n", r, hipGetErrorString(e)); }
+  }
+  hipLaunchKernelGGL((k_split_finish<MODE, SIGN>), dim3(2048), dim3(256), 0, st, g, plane, out, split, peers);
+  if (trace) { const hipError_t e = hipStreamSynchronize(st); fprintf(stderr, "[m2s split] finish: %s\n", hipGetErrorString(e)); }
 }
 template <bool GRID, int MODE, int SIGN>
 void launch_brute(hipStream_t st, const DeviceMesh& mesh, const GridParams& g, const float* q, uint32_t n_q,
@@ -1843,6 +2015,16 @@ static size_t cut_blocks(const GridParams& g, uint32_t log) {
 // 0.34 / 0.92 ms, 20^3 0.58 / 0.96, 24^3 0.92 / 0.83; blob-100k 8^3 0.41 / 2.21, 12^3 1.08 / 2.55, 16^3 2.21 / 2.22; blob-6k 16^3 0.20 / 0.74,
 // 32^3 1.10 / 0.61 — brute force runs at 178 G point-triangle pairs per second (half the chip's fp32 issue rate), the walks of such
 // grids as long as their slowest lane's chain of dependent loads, which grows with the mesh.
+// Split walk: accumulator slots for up to SPLIT_CAP_SLOTS suspended packets, lists of SPLIT_ITEMS_PER_SLOT items per slot and round.
+// A launch of more packets than SPLIT_MAX_PACKETS is not split at all: it is hundreds of rounds of the chip's wave slots deep, its tail a
+// percent or two of it.  Below that every packet has a slot (a suspended packet can always hand over: no path back into the walk).
+constexpr uint32_t SPLIT_MAX_PACKETS = 1u << 19, SPLIT_ITEMS_PER_SLOT = 8;
+static uint32_t split_cap_slots(size_t packets) { return (uint32_t)std::min<size_t>(std::max<size_t>(packets, 64), SPLIT_MAX_PACKETS); }
+static size_t split_workspace_bytes(size_t packets) {
+  const size_t cap = split_cap_slots(packets);
+  const size_t items = std::max<size_t>(cap, std::min<size_t>(cap * SPLIT_ITEMS_PER_SLOT, 1u << 20));
+  return 256 + SPLIT_CNT_WORDS * 4 + cap * 4 + 256 + cap * 128 * 4 + 256 + (size_t)SPLIT_MAX_ROUNDS * items * 16 + 256;
+}
 bool grid_is_tiny(const GridParams& g, size_t n_tris, int algorithm) {
   if (algorithm != 0 || n_tris == 0 || g.xe <= g.xb || g.n[1] == 0 || g.n[2] == 0 || g.chunk_log < 31u) return false;
   const double limit = tuning().brute_max >= 0.0 ? tuning().brute_max : 1.0e8 + 3.0e3 * (double)n_tris;
@@ -1852,9 +2034,9 @@ bool grid_is_tiny(const GridParams& g, size_t n_tris, int algorithm) {
 size_t grid_distance_workspace_bytes(const GridParams& g) {
   const size_t bricks = (size_t)host_brick_count(g);
   if ((double)(g.xe - g.xb) * g.n[1] * g.n[2] <= 4194304.0)   // room for k_brute_split's per-voxel words
-    return bricks * 44 + bricks + 16384 + cut_blocks(g, 0) * CUT_WORDS * 4 + bricks * 64 * 8 + 4096;
+    return bricks * 44 + bricks + 16384 + cut_blocks(g, 0) * CUT_WORDS * 4 + bricks * 64 * 8 + 4096 + split_workspace_bytes(bricks);
   const size_t trail_counters = (size_t)bricks_along(g.xe - g.xb, g.bl[0]) * (bricks_along(g.n[1], g.bl[1]) + 1) * 4;   // M2S_PEER_TRAIL progress
-  return bricks * 44 + bricks + 16384 + cut_blocks(g, 0) * CUT_WORDS * 4 + trail_counters + 1024;   // seeds + cut lists (one per brick)
+  return bricks * 44 + bricks + 16384 + cut_blocks(g, 0) * CUT_WORDS * 4 + trail_counters + 1024 + split_workspace_bytes(bricks);   // seeds + cut lists (one per brick) + split walk
 }
 
 __global__ __launch_bounds__(256) void k_seed_remap(uint32_t* __restrict__ ids, size_t n, const uint32_t* __restrict__ slot_of, uint32_t n_tris) {
@@ -1981,6 +2163,29 @@ int prepare_grid_walk(Arena& ws, hipStream_t st, const DeviceMesh& mesh, const G
   plan->seeds = seed1; plan->seed_shift = sh1; plan->seed_ny = s1ny; plan->seed_nz = s1nz;
   plan->cut_lists = cut.lists; plan->cut_log = cut.log; plan->cut_ny = cut.ny; plan->cut_nz = cut.nz;
   plan->lane_walk = lane_walk;
+  // split walk (packet walk only; M2S_SPLIT: -1 / 1 on, 0 off, 2 on with the flags raised from the start)
+  const Tuning& tn = tuning();
+  if (!brute && !lane_walk && mesh.n_nodes != 0 && tn.split != 0 && mesh.stats == nullptr && packets <= SPLIT_MAX_PACKETS) {
+    SplitCtl sc;
+    sc.cap_slots = split_cap_slots(packets);
+    sc.cap_items = std::max(sc.cap_slots, std::min(sc.cap_slots * SPLIT_ITEMS_PER_SLOT, 1u << 20));
+    sc.rounds = std::min(tn.split_rounds, SPLIT_MAX_ROUNDS);
+    sc.emit_min = std::max(2u, tn.split_min_records) * (uint32_t)sizeof(NodeExt);
+    sc.emit_max = std::max(std::max(2u, tn.split_min_records), tn.split_max_records) * (uint32_t)sizeof(NodeExt);
+    sc.grace = tn.split_budget ? tn.split_budget : 128u;
+    sc.idle_below = tn.split == 2 ? 1u : 0u;                               // forced (tests): every stamp is time 0 — all flags up, no patience
+    // patience, in ordinary packet times: the launch is packets / slots rounds of the chip's 8 192 wave slots deep, the flag goes up
+    // when all but the last round have been handed out
+    const double rounds_before = std::max(1.0, (double)packets / 8192.0 - 1.0);
+    sc.patience_q8 = (uint32_t)std::min(65535.0 * 256.0, 256.0 * tn.split_patience / rounds_before);
+    sc.cnt = ws.take<uint32_t>(SPLIT_CNT_WORDS);
+    sc.slot_packet = ws.take<uint32_t>(sc.cap_slots);
+    sc.acc = ws.take<uint32_t>((size_t)sc.cap_slots * 128);
+    sc.items = ws.take<uint4>((size_t)sc.rounds * sc.cap_items);
+    if (!sc.cnt || !sc.slot_packet || !sc.acc || !sc.items) { set_error("internal: split-walk workspace too small"); return M2S_ERR_HIP_INTERNAL; }
+    plan->split = sc;
+    plan->split_forced = tn.split == 2;
+  }
   return 0;
 }
 
@@ -2056,17 +2261,32 @@ int launch_grid_walk(hipStream_t st, const DeviceMesh& mesh, const GridParams& g
     M2S_HIP_CHECK(hipGetLastError());
     return 0;
   }
+  const SplitCtl* split = (!brute && plan.split.cnt != nullptr && mesh.stats == nullptr) ? &plan.split : nullptr;
+  if (split) hipLaunchKernelGGL(k_split_init, dim3(1), dim3(64), 0, st, split->cnt, plan.split_forced ? 1u : 0u);
   if (mode == MODE_UNSIGNED && d_inside_plane) {
     if (brute) launch_brute<true, MODE_UNSIGNED, SIGN_GRID_PLANE>(st, mesh, g, nullptr, 0, d_inside_plane, d_out, d_err, packets, peers);
-    else launch_packet<true, MODE_UNSIGNED, SIGN_GRID_PLANE>(st, mesh, g, nullptr, nullptr, 0, d_inside_plane, d_out, d_err, packets, seed1, sh1, s1ny, s1nz, nullptr, cut, peers);
+    else launch_packet<true, MODE_UNSIGNED, SIGN_GRID_PLANE>(st, mesh, g, nullptr, nullptr, 0, d_inside_plane, d_out, d_err, packets, seed1, sh1, s1ny, s1nz, nullptr, cut, peers, split);
+    if (split) launch_split_rounds<MODE_UNSIGNED, SIGN_GRID_PLANE>(st, mesh, g, d_inside_plane, d_out, d_err, *split, cut, peers);
   } else if (mode == MODE_UNSIGNED) {
     if (brute) launch_brute<true, MODE_UNSIGNED, SIGN_NONE>(st, mesh, g, nullptr, 0, nullptr, d_out, d_err, packets, peers);
-    else launch_packet<true, MODE_UNSIGNED, SIGN_NONE>(st, mesh, g, nullptr, nullptr, 0, nullptr, d_out, d_err, packets, seed1, sh1, s1ny, s1nz, nullptr, cut, peers);
+    else launch_packet<true, MODE_UNSIGNED, SIGN_NONE>(st, mesh, g, nullptr, nullptr, 0, nullptr, d_out, d_err, packets, seed1, sh1, s1ny, s1nz, nullptr, cut, peers, split);
+    if (split) launch_split_rounds<MODE_UNSIGNED, SIGN_NONE>(st, mesh, g, nullptr, d_out, d_err, *split, cut, peers);
   } else {
     if (brute) launch_brute<true, MODE_NORMAL_FOLD, SIGN_NONE>(st, mesh, g, nullptr, 0, nullptr, d_out, d_err, packets, peers);
-    else launch_packet<true, MODE_NORMAL_FOLD, SIGN_NONE>(st, mesh, g, nullptr, nullptr, 0, nullptr, d_out, d_err, packets, seed1, sh1, s1ny, s1nz, nullptr, cut, peers);
+    else launch_packet<true, MODE_NORMAL_FOLD, SIGN_NONE>(st, mesh, g, nullptr, nullptr, 0, nullptr, d_out, d_err, packets, seed1, sh1, s1ny, s1nz, nullptr, cut, peers, split);
+    if (split) launch_split_rounds<MODE_NORMAL_FOLD, SIGN_NONE>(st, mesh, g, nullptr, d_out, d_err, *split, cut, peers);
   }
   M2S_HIP_CHECK(hipGetLastError());
+  if (split && tuning().split_report) {
+    uint32_t h[SPLIT_CNT_WORDS];
+    M2S_HIP_CHECK(hipStreamSynchronize(st));
+    M2S_HIP_CHECK(hipMemcpy(h, split->cnt, sizeof(h), hipMemcpyDeviceToHost));
+    fprintf(stderr, "[m2s split] %u packets: %u suspended (room for %u); items per round:", packets, h[0], split->cap_slots);
+    for (uint32_t r = 1; r <= split->rounds; ++r) fprintf(stderr, " %u", h[1 + r]);
+    fprintf(stderr, " (room for %u each, reserved in blocks of 64); first look after %u units, patience %.2f of the time to the flag, subtrees of %u .. %u records; XCD 0: handed out in %.1f us\n",
+            split->cap_items, split->grace, split->patience_q8 / 256.0, split->emit_min / (uint32_t)sizeof(NodeExt), split->emit_max / (uint32_t)sizeof(NodeExt),
+            h[16] ? ((h[16] & ~1u) - h[24]) * 0.01 : 0.0);
+  }
   return 0;
 }
 
@@ -2303,10 +2523,15 @@ void warm_distance(hipStream_t st) {
   hipLaunchKernelGGL(k_warm_distance, dim3(1), dim3(64), 0, st);
   // ... and resolves a kernel FUNCTION at its own first launch (~0.3 ms each): ask for the attributes of the ones a first call uses
   const void* fns[] = {
-      (const void*)k_packet<true, MODE_UNSIGNED, SIGN_GRID_PLANE, false>,
-      (const void*)k_packet<true, MODE_NORMAL_FOLD, SIGN_NONE, false>,
-      (const void*)k_packet<false, MODE_UNSIGNED, SIGN_RAYS3, false>,
-      (const void*)k_packet<false, MODE_NEAREST_NORMAL, SIGN_NONE, false>,
+      (const void*)k_packet<true, MODE_UNSIGNED, SIGN_GRID_PLANE, false, true>,
+      (const void*)k_packet<true, MODE_NORMAL_FOLD, SIGN_NONE, false, true>,
+      (const void*)k_packet<false, MODE_UNSIGNED, SIGN_RAYS3, false, false>,
+      (const void*)k_packet<false, MODE_NEAREST_NORMAL, SIGN_NONE, false, false>,
+      (const void*)k_split_init,
+      (const void*)k_split_round<MODE_UNSIGNED>,
+      (const void*)k_split_round<MODE_NORMAL_FOLD>,
+      (const void*)k_split_finish<MODE_UNSIGNED, SIGN_GRID_PLANE>,
+      (const void*)k_split_finish<MODE_NORMAL_FOLD, SIGN_NONE>,
       (const void*)k_cut<true>,
       (const void*)k_cut<false>,
       (const void*)k_lane<MODE_UNSIGNED, SIGN_GRID_PLANE>,

@@ -33,8 +33,11 @@ const Entry TABLE[] = {
     M2S_KNOB("M2S_CUT_WAVE_CAP", K_U32, cut_wave_cap),
     M2S_KNOB("M2S_SPLIT", K_INT, split),
     M2S_KNOB("M2S_SPLIT_BUDGET", K_U32, split_budget),
-    M2S_KNOB("M2S_SPLIT_WAYS", K_U32, split_ways),
+    M2S_KNOB("M2S_SPLIT_PATIENCE", K_F64, split_patience),
+    M2S_KNOB("M2S_SPLIT_MIN_RECORDS", K_U32, split_min_records),
+    M2S_KNOB("M2S_SPLIT_MAX_RECORDS", K_U32, split_max_records),
     M2S_KNOB("M2S_SPLIT_ROUNDS", K_U32, split_rounds),
+    M2S_KNOB("M2S_SPLIT_REPORT", K_INT, split_report),
     M2S_KNOB("M2S_LEAF_MAX", K_U32, leaf_max),
     M2S_KNOB("M2S_HOST_PIECE_MB", K_U32, host_piece_mb),
     M2S_KNOB("M2S_PUSH_PIECES", K_U32, push_pieces),
@@ -65,10 +68,8 @@ void copy_field(Tuning& dst, const Tuning& src, const Entry& e) {
 
 void sanitise(Tuning& t) {
   if (t.leaf_max < 1) t.leaf_max = 1;
-  if (t.split_ways < 2) t.split_ways = 2;
-  if (t.split_ways > 32) t.split_ways = 32;
   if (t.split_rounds < 1) t.split_rounds = 1;
-  if (t.split_rounds > 8) t.split_rounds = 8;
+  if (t.split_rounds > 6) t.split_rounds = 6;
   if (t.push_pieces < 1) t.push_pieces = 1;
   if (t.host_piece_mb < 1) t.host_piece_mb = 1;
 }

@@ -27,10 +27,13 @@ struct Tuning {
   float cut_far = 1.0f / 32.0f;     // M2S_CUT_FAR      ... and as a fraction of the distance (far from it)
   uint32_t cut_wave_cap = 0;        // M2S_CUT_WAVE_CAP node visits after which a k_cut wave emits what it meets; 0: max(120, 20 x tree depth)
   // ---- heavy packets (distance.hip "split walk")
-  int split = -1;                   // M2S_SPLIT        -1 automatic, 0 never, 1 always: packets that exhaust their budget hand the rest of their ranges to several waves
-  uint32_t split_budget = 0;        // M2S_SPLIT_BUDGET work units (node tests + 4 x exact evaluations) a wave spends on one item; 0: automatic
-  uint32_t split_ways = 8;          // M2S_SPLIT_WAYS   pieces the unfinished ranges of an item are cut into
-  uint32_t split_rounds = 3;        // M2S_SPLIT_ROUNDS follow-up launches (the last one walks to the end)
+  int split = -1;                   // M2S_SPLIT        -1 automatic, 0 never, 1 on, 2 on with the "out of work" flags raised from the start (tests): walks still running when the launch runs dry hand subtrees to other waves
+  uint32_t split_budget = 0;        // M2S_SPLIT_BUDGET work units (3 per leaf + 1 per pre-test + 4 per exact evaluation) a walk does before it first looks whether its XCD is running dry; 0: 128
+  double split_patience = 1.5;      // M2S_SPLIT_PATIENCE   a packet still walking this many ordinary packet times (measured by the launch) after its XCD ran out of packets is suspended
+  uint32_t split_min_records = 16;  // M2S_SPLIT_MIN_RECORDS  a suspended walk hands over surviving subtrees of at least this many node records ...
+  uint32_t split_max_records = 128; // M2S_SPLIT_MAX_RECORDS  ... and at most this many (larger ones it opens itself)
+  uint32_t split_rounds = 2;        // M2S_SPLIT_ROUNDS follow-up launches: the continuations of the suspended packets, then their subtrees (with more rounds, subtrees may be suspended in their turn; the last round walks to the end)
+  int split_report = 0;             // M2S_SPLIT_REPORT 1: suspended packets and items per round of every grid walk, on stderr (synchronises)
   // ---- tree
   uint32_t leaf_max = 2;            // M2S_LEAF_MAX     triangles per collapsed leaf
   // ---- host-pointer calls and peer delivery

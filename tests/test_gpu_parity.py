@@ -49,7 +49,7 @@ def cut_lists_mode(request):
         forced = {"M2S_LANE_WALK": 1, "M2S_BRUTE_MAX": 0}
     elif mode == "split walks":
         # every packet that lasts longer than a few node tests hands the rest of its ranges to other waves (distance.hip, split walk)
-        forced = {"M2S_SPLIT": 1, "M2S_SPLIT_BUDGET": 24, "M2S_SPLIT_WAYS": 3, "M2S_LANE_WALK": 0, "M2S_BRUTE_MAX": 0}
+        forced = {"M2S_SPLIT": 2, "M2S_SPLIT_BUDGET": 24, "M2S_SPLIT_MIN_RECORDS": 4, "M2S_SPLIT_MAX_RECORDS": 64, "M2S_SPLIT_ROUNDS": 3, "M2S_LANE_WALK": 0, "M2S_BRUTE_MAX": 0}
     with _lib.knobs(**forced):
         yield
 
@@ -501,7 +501,7 @@ def test_four_million_triangles_every_walk_equals_brute_force():
         assert np.isfinite(want).all() and (want < 0).any() and (want > 0).any()
         for name, env in (("default", {}), ("packet walk", {"M2S_LANE_WALK": 0}),
                           ("packet walk + cut lists", {"M2S_LANE_WALK": 0, "M2S_CUT_MIN_PACKETS": 1}),
-                          ("packet walk, split", {"M2S_LANE_WALK": 0, "M2S_SPLIT": 1, "M2S_SPLIT_BUDGET": 200}), ("lane walk", {"M2S_LANE_WALK": 1})):
+                          ("packet walk, split", {"M2S_LANE_WALK": 0, "M2S_SPLIT": 2, "M2S_SPLIT_BUDGET": 200}), ("lane walk", {"M2S_LANE_WALK": 1})):
             with _lib.knobs(**env):
                 got = generate_grid_sdf(dv, topo, g, sign).cpu().numpy()
             assert_bit_equal(got, want, f"4 M triangles, {sign.name}, {name}")

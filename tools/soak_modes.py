@@ -9,8 +9,8 @@ import numpy as np, torch
 from mesh_to_sdf_amd import AccelerationMethod, Grid, SignMethod, Topology, _lib, generate_grid_sdf, generate_sdf, interleaved_slab, meshes
 
 MODES = {"default": {}, "packet + cut lists": {"M2S_CUT_MIN_PACKETS": 8, "M2S_QUERY_CUT_MIN": 1, "M2S_LANE_WALK": 0, "M2S_BRUTE_MAX": 0, "M2S_SPLIT": 0},
-         "packet + split": {"M2S_LANE_WALK": 0, "M2S_BRUTE_MAX": 0, "M2S_SPLIT": 1, "M2S_SPLIT_BUDGET": 40, "M2S_SPLIT_WAYS": 5},
-         "packet + cut lists + split": {"M2S_CUT_MIN_PACKETS": 8, "M2S_QUERY_CUT_MIN": 1, "M2S_LANE_WALK": 0, "M2S_BRUTE_MAX": 0, "M2S_SPLIT": 1, "M2S_SPLIT_BUDGET": 60},
+         "packet + split": {"M2S_LANE_WALK": 0, "M2S_BRUTE_MAX": 0, "M2S_SPLIT": 2, "M2S_SPLIT_BUDGET": 40, },
+         "packet + cut lists + split": {"M2S_CUT_MIN_PACKETS": 8, "M2S_QUERY_CUT_MIN": 1, "M2S_LANE_WALK": 0, "M2S_BRUTE_MAX": 0, "M2S_SPLIT": 2, "M2S_SPLIT_BUDGET": 60},
          "lane walk": {"M2S_LANE_WALK": 1, "M2S_BRUTE_MAX": 0}}
 
 
