@@ -404,19 +404,25 @@ def main():
             else:
                 per_rank = [mine]
             exchange_ran = exchange
-        try:
-            from mesh_to_sdf_amd import peer_bandwidth
-            probe_cells = min(n ** 3, 16 << 20)                     # 64 MB to each peer
-            if in_process and len(set(devices)) > 1:
+        # A probe must never cost the run its number — and in the one-process-per-GPU form every rank must issue the same collectives
+        # whatever happened to ITS probe: the error is caught into the rank's own entry, the gather stands outside the try.
+        probe_cells = min(n ** 3, 16 << 20)                     # 64 MB to each peer
+        if in_process and len(set(devices)) > 1:
+            try:
+                from mesh_to_sdf_amd import peer_bandwidth
                 each, together = peer_bandwidth(outs[0], [o for o, d in zip(outs[1:], devices[1:]) if d != devices[0]], probe_cells)
                 link_probe = {"from_device": devices[0], "payload_mb": probe_cells * 4 >> 20, "gbps_per_peer": [round(x, 1) for x in each], "gbps_all_peers_at_once": round(together, 1)}
-            elif pg is not None and world > 1:
+            except Exception as e:   # noqa: BLE001
+                link_probe = {"error": f"{type(e).__name__}: {e}"}
+        elif pg is not None and world > 1:
+            try:
+                from mesh_to_sdf_amd import peer_bandwidth
                 each, together = peer_bandwidth(pg.tensor, pg.peers, probe_cells)
                 mine = {"rank": rank, "payload_mb": probe_cells * 4 >> 20, "gbps_per_peer": [round(x, 1) for x in each], "gbps_all_peers_at_once": round(together, 1)}
-                link_probe = [None] * world
-                dist.all_gather_object(link_probe, mine)
-        except Exception as e:   # noqa: BLE001  (a probe must never cost the run its number)
-            link_probe = {"error": f"{type(e).__name__}: {e}"}
+            except Exception as e:   # noqa: BLE001
+                mine = {"rank": rank, "error": f"{type(e).__name__}: {e}"}
+            link_probe = [None] * world
+            dist.all_gather_object(link_probe, mine)
 
     # phase breakdown of one extra, untimed, synchronous one-shot call on this rank's whole slab
     ph = M2STimings()

@@ -250,7 +250,8 @@ int m2s_interleaved_slab(const m2s_grid* grid, int n, int k, uint64_t* x_begin, 
  * first one peer at a time (gbps_each[k], optional), then all peers in one launch (*gbps_all, optional: the sum over the links).
  * GB/s of payload, best of three timed launches per figure.  xGMI is point-to-point, so gbps_each is a per-link number and
  * gbps_all / n_peers shows what a link keeps when all are busy: together they decide whether a slab's delivery hides under the
- * walk.  Blocks until done. */
+ * walk.  Blocks until done.  The first n_cells floats of every peer buffer ARE OVERWRITTEN with src's (the probe is
+ * the push itself); the caller's current device is left as it was. */
 int m2s_peer_bandwidth(const float* src, float* const* peers, uint32_t n_peers, size_t n_cells, int device, float* gbps_each, float* gbps_all);
 
 /* One process per GPU (torch.distributed / MPI launchers): the same no-collective exchange across processes.
@@ -406,7 +407,9 @@ void m2s_gltf_close(m2s_gltf* gltf);
 /* The one-off costs of a process's first call, paid now instead: the HIP runtime and this library's code objects on `device`
  * (-1 = the current one), the streams and events of the device's context, `workspace_bytes` of device workspace (0 = none: it
  * grows on demand; a 512^3 grid call needs ~0.6 GB, 10 M queries ~1.5 GB) and, for callers of the host-pointer entry points, the
- * pinned staging ring (`host_ring_bytes` > 0: three slots of min(host_ring_bytes, 64 MB)).  Optional, idempotent, blocking.
+ * pinned staging ring (`host_ring_bytes` > 0: three slots of min(host_ring_bytes, 64 MB)).  Optional, idempotent (a repeated call
+ * touches only what has grown since), blocking.  The workspace it grows is the one of the library's OWN stream: a caller that passes
+ * m2s_opts.stream (or stream_mode 1) works out of a block per stream, which still grows, and is first touched, in that caller's first call.
  * The reference's usage is one call per process (examples/demo.rs:29-54): without this the first call pays 20-40 ms (grid,
  * host result) to ~0.9 s (10 M queries through host pointers) on top of its steady-state time — INTEGRATION.md has the breakdown;
  * M2S_HOST_TIMES=1 prints it per call on stderr. */

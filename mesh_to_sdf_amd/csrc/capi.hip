@@ -1130,6 +1130,26 @@ int m2s_generate_sdf(const float* vertices, size_t n_vertices, const void* indic
     hc.lap("queries to the device (pinned ring on a first call)");
   }
   M2S_HIP_CHECK(hipEventRecord(st->ev[0], c.stream));
+  if (query_is_tiny(n_queries, n_tris, algorithm, sign_src) && !tuning().stats) {
+    // a small query set (the crate's documented use): the triangle records and nothing else — no keys, no sort, no tree (k_brute_split_q)
+    DeviceMesh mesh;
+    rc = build_device_mesh(ws, c.stream, sm.d_verts, n_vertices, sm.d_indices, n_indices, index_bytes, topology, n_tris, d_err, &mesh, nullptr, true);
+    if (rc) return rc;
+    M2S_HIP_CHECK(hipEventRecord(st->ev[1], c.stream));
+    M2S_HIP_CHECK(hipEventRecord(st->ev[2], c.stream));
+    rc = launch_query_brute_split(ws, c.stream, mesh, d_q, n_queries, mode, sign_src, d_out, d_err);
+    if (rc) return rc;
+    M2S_HIP_CHECK(hipEventRecord(st->ev[3], c.stream));
+    if (c.mem_kind == M2S_MEM_HOST) {
+      rc = staged_d2h(*st, c.stream, reinterpret_cast<char*>(out), reinterpret_cast<const char*>(d_out), n_queries * 4);
+      if (rc) return rc;
+    }
+    if (n_out) *n_out = n_queries;
+    rc = finish_call(c, *st, d_err, c.timings, n_tris, n_queries, false);
+    hc.lap("records + all pairs + result");
+    hc.done("m2s_generate_sdf (small query set)");
+    return rc;
+  }
   // What the queries need before the walk — bounding box, Morton keys, sort, packet table, gather (distance.hip prepare_query_walk) — does
   // not need the tree: a synchronous call runs it on the side stream beside the build
   QueryPlan qplan;
@@ -1220,7 +1240,7 @@ int m2s_warmup(int device, size_t workspace_bytes, size_t host_ring_bytes) {
   if (rc) return rc;
   if (!st->side_stream2) { rc = create_side_stream(&st->side_stream2); if (rc) return rc; }
   if (!st->copy_stream) M2S_HIP_CHECK(hipStreamCreateWithFlags(&st->copy_stream, hipStreamNonBlocking));
-  {
+  if (st->warmed_cap == 0 || st->cap > st->warmed_cap) {        // (a repeated call with nothing new to touch does none of this again)
     // the first copy between PAGEABLE host memory and the device makes the runtime set up its staging path (measured: 15 ms of a first
     // call's mesh upload): a few bytes each way through the workspace
     constexpr size_t probe = (size_t)4 << 20;                     // large enough to take the runtime's chunked staging path
@@ -1232,6 +1252,7 @@ int m2s_warmup(int device, size_t workspace_bytes, size_t host_ring_bytes) {
     // ... and the first touch of freshly allocated device memory maps its pages (17 ms for the 0.7 GB of a 512^3 call): touch it all now
     M2S_HIP_CHECK(hipMemsetAsync(st->base, 0, workspace_bytes ? st->cap : 256, c.stream));
     M2S_HIP_CHECK(hipStreamSynchronize(c.stream));
+    st->warmed_cap = st->cap;
   }
   warm_bvh(c.stream);                                            // one empty kernel per translation unit: the runtime loads a code object
   warm_sign(c.stream);                                           // (all the unit's kernels) at the first launch out of it
@@ -1544,12 +1565,27 @@ int m2s_peer_bandwidth(const float* src, float* const* peers, uint32_t n_peers, 
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(M2S_ERR_HIP, "no HIP device available");
   if (device < 0) M2S_HIP_CHECK(hipGetDevice(&device));
   if (device >= ndev) return fail(M2S_ERR_BAD_ARG, "device %d out of range (%d devices)", device, ndev);
+  int prev_device = device;
+  (void)hipGetDevice(&prev_device);
+  // everything created below is released, and the caller's current device restored, on every way out
+  struct Guard {
+    hipStream_t st = nullptr;
+    hipEvent_t a = nullptr, b = nullptr;
+    int restore;
+    ~Guard() {
+      if (a) (void)hipEventDestroy(a);
+      if (b) (void)hipEventDestroy(b);
+      if (st) (void)hipStreamDestroy(st);
+      (void)hipSetDevice(restore);
+    }
+  } guard;
+  guard.restore = prev_device;
   M2S_HIP_CHECK(hipSetDevice(device));
-  hipStream_t st;
-  hipEvent_t a, b;
-  M2S_HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-  M2S_HIP_CHECK(hipEventCreate(&a));
-  M2S_HIP_CHECK(hipEventCreate(&b));
+  M2S_HIP_CHECK(hipStreamCreateWithFlags(&guard.st, hipStreamNonBlocking));
+  M2S_HIP_CHECK(hipEventCreate(&guard.a));
+  M2S_HIP_CHECK(hipEventCreate(&guard.b));
+  const hipStream_t st = guard.st;
+  const hipEvent_t a = guard.a, b = guard.b;
   int rc = M2S_OK;
   auto timed = [&](const PeerOut& po, float* gbps) -> int {
     float best = 0.0f;
@@ -1581,9 +1617,6 @@ int m2s_peer_bandwidth(const float* src, float* const* peers, uint32_t n_peers, 
     for (uint32_t k = 0; k < n_peers; ++k) all.p[k] = peers[k];
     rc = timed(all, gbps_all);
   }
-  (void)hipEventDestroy(a);
-  (void)hipEventDestroy(b);
-  (void)hipStreamDestroy(st);
   return rc;
 }
 

@@ -17,6 +17,7 @@ struct DeviceState {
   // blocks, so asynchronous calls on two streams (the x-pieces of a sharded grid) may overlap on the device.
   char* base = nullptr;
   size_t cap = 0;
+  size_t warmed_cap = 0;   // m2s_warmup: capacity of the workspace block it has already touched
   struct Scratch {
     hipStream_t stream = nullptr;
     char* base = nullptr;

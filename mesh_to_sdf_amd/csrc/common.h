@@ -296,6 +296,9 @@ int launch_grid_distance(Arena& ws, hipStream_t st, const DeviceMesh& mesh, cons
                          const PeerOut* peers = nullptr);
 void cut_word_roundtrip(uint32_t n_nodes, uint32_t start, uint32_t len, uint32_t* word, uint32_t* first, uint32_t* end);   // test hook
 size_t query_workspace_bytes(size_t n_q);
+bool query_is_tiny(size_t n_q, size_t n_tris, int algorithm, int sign_src);   // small query sets: all queries x all triangles, no tree
+int launch_query_brute_split(Arena& ws, hipStream_t st, const DeviceMesh& mesh, const float* d_queries, size_t n_q, int mode, int sign_src,
+                             float* d_out, int* d_err);
 // What the walk of a generic query set needs besides the mesh (prepare_query_walk; device pointers into the call's arena).
 struct QueryPlan {
   size_t n_q = 0;

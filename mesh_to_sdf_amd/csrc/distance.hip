@@ -1754,6 +1754,87 @@ __global__ __launch_bounds__(256) void k_brute_finish(GridParams g, const uint32
   for (uint32_t i = 0; i < peers.n; ++i) peers.p[i][out_index + (size_t)g.out_off] = result;
 }
 
+// ---- k_brute_split_q: small query sets without a tree ---------------------------------------------------------------
+// The crate's documented use is a handful of query points (lib.rs:13-31, examples/demo.rs:29-54): for those the LBVH build (0.16 -
+// 0.24 ms), the query sort and a lane walk that lasts as long as its slowest lane's chain of dependent loads (~1 ms) are all
+// overhead — queries x triangles is a few 10^7 evaluations, 0.1 - 0.3 ms if the whole chip takes part.  As k_brute_split: block
+// (x, y) evaluates query block x against triangle chunk y and folds into per-query words with atomics — minima for the distances
+// (non-negative floats order like their bits), a 64-bit (d2, index, !positive) key for the Rtree rule (lowest index on ties, as
+// the walks and k_brute take it), XOR for the three ray parities (the parity of a sum is the XOR of the parities) — and
+// k_brute_finish_q turns the words into signed distances.  Per query: [0] d2, [1] d2 of the positive side (Normal fold) or the
+// hit parities (bits 0..2: +X, +Y, +Z), [2..3] the key.  Same arithmetic per pair as everywhere else: bit-identical.
+__global__ __launch_bounds__(256) void k_brute_q_init(uint32_t* __restrict__ acc, uint32_t n_q, uint32_t second) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_q) return;
+  reinterpret_cast<uint4*>(acc)[i] = make_uint4(0x7f800000u, second, 0xffffffffu, 0xffffffffu);   // +inf, +inf or no hits, "no triangle"
+}
+template <int MODE, int SIGN>
+__global__ __launch_bounds__(256) void k_brute_split_q(DeviceMesh mesh, const float* __restrict__ queries, uint32_t n_q, uint32_t* __restrict__ acc,
+                                                       int* __restrict__ err, uint32_t tiles_per_chunk) {
+  __shared__ TriRec tile[TILE];
+  const uint32_t i_raw = blockIdx.x * 256u + threadIdx.x, i = min(i_raw, n_q - 1u);
+  const f3 p = mk3(queries[3 * (size_t)i], queries[3 * (size_t)i + 1], queries[3 * (size_t)i + 2]);
+  Best<MODE> best;
+  uint32_t hits[3] = {0, 0, 0};
+  const uint32_t t_begin = blockIdx.y * tiles_per_chunk * TILE, t_end = min(mesh.n_tris, t_begin + tiles_per_chunk * TILE);
+  for (uint32_t t0 = t_begin; t0 < t_end; t0 += TILE) {
+    const uint32_t nt = min((uint32_t)TILE, t_end - t0);
+    __syncthreads();
+    {
+      const float4* src = reinterpret_cast<const float4*>(mesh.tris + t0);
+      float4* dst = reinterpret_cast<float4*>(tile);
+      for (uint32_t k = threadIdx.x; k < nt * 6; k += 256) dst[k] = src[k];
+    }
+    __syncthreads();
+    for (uint32_t k = 0; k < nt; ++k) {
+      const TriRec& tr = tile[k];
+      eval_triangle<MODE>(best, p, tr);
+      if (MODE == MODE_UNSIGNED && SIGN == SIGN_RAYS3) {               // the candidate rule of bvh.rs:119 / rtree_bvh.rs:149: the triangle's own padded box
+        const f3 a = mk3(tr.ax, tr.ay, tr.az), b = mk3(tr.bx, tr.by, tr.bz), c = mk3(tr.cx, tr.cy, tr.cz);
+        f3 mn, mx;
+        triangle_bounding_box(a, b, c, &mn, &mx);
+        float t;
+        hits[0] += (ray_meets_box<0>(p, mn, mx) & ray_triangle_aligned<0>(p, a, b, c, &t)) ? 1u : 0u;
+        hits[1] += (ray_meets_box<1>(p, mn, mx) & ray_triangle_aligned<1>(p, a, b, c, &t)) ? 1u : 0u;
+        hits[2] += (ray_meets_box<2>(p, mn, mx) & ray_triangle_aligned<2>(p, a, b, c, &t)) ? 1u : 0u;
+      }
+    }
+  }
+  if (i_raw >= n_q) return;
+  uint32_t* w = acc + 4 * (size_t)i;
+  if (MODE == MODE_NEAREST_NORMAL) {
+    if (best.idx != 0xffffffffu)
+      atomicMin(reinterpret_cast<unsigned long long*>(w + 2), ((unsigned long long)__float_as_uint(best.d2) << 32) | ((unsigned long long)best.idx << 1) | (best.pos ? 0ull : 1ull));
+    return;
+  }
+  atomicMin(&w[0], __float_as_uint(best.d2));
+  if (MODE == MODE_NORMAL_FOLD) {
+    atomicMin(&w[1], __float_as_uint(best.d2pos));
+    if (best.nan) atomicOr(err, ERRF_NAN);
+  } else if (SIGN == SIGN_RAYS3) {
+    const uint32_t par = (hits[0] & 1u) | ((hits[1] & 1u) << 1) | ((hits[2] & 1u) << 2);
+    if (par) atomicXor(&w[1], par);
+  }
+}
+template <int MODE, int SIGN>
+__global__ __launch_bounds__(256) void k_brute_finish_q(const uint32_t* __restrict__ acc, uint32_t n_q, float* __restrict__ out) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= n_q) return;
+  const uint4 w = reinterpret_cast<const uint4*>(acc)[i];
+  Best<MODE> best;
+  bool negate = false;
+  if (MODE == MODE_NEAREST_NORMAL) {
+    best.d2 = __uint_as_float(w.w);                                    // high word of the key; "no triangle" reads as NaN, as a walk over nothing would not
+    best.pos = (w.z & 1u) == 0u;
+    if (w.w == 0xffffffffu && w.z == 0xffffffffu) { best.d2 = __builtin_inff(); best.pos = false; }
+  } else {
+    best.d2 = __uint_as_float(w.x);
+    if (MODE == MODE_NORMAL_FOLD) best.d2pos = __uint_as_float(w.y);
+    else if (SIGN == SIGN_RAYS3) negate = ((w.y & 1u) + ((w.y >> 1) & 1u) + ((w.y >> 2) & 1u)) > 1u;   // bvh.rs:131-141, rtree_bvh.rs:161-171
+  }
+  out[i] = finish<MODE>(best, negate);
+}
+
 // ---- query ordering (generic path): Morton sort so that a packet is spatially compact ---------
 __device__ __forceinline__ int ordf(float f) {
   int i = __float_as_int(f);
@@ -2316,13 +2397,50 @@ void cut_word_roundtrip(uint32_t n_nodes, uint32_t start, uint32_t len, uint32_t
   *end = std::min(f + l, n_nodes);
 }
 
+// Small query sets take k_brute_split_q: queries x triangles <= 1.2e8, 6e7 with the three ray tests per pair (M2S_BRUTE_MAX overrides; 0:
+// never).  Measured (tools/exp_small_queries.py, whole one-shot calls, all pairs / build + walk): 11 k triangles x 1 ... 1 000 queries
+// 0.085 - 0.15 / 0.25 - 0.70 ms, x 10 000 0.47 (0.83 with rays) / 0.55 (0.66); 100 k triangles x 64 0.13 - 0.22 / 1.0 - 1.3 ms, x 1 000
+// 0.46 (0.81) / 0.74 (0.94), x 10 000 3.2 (5.8) / 0.9 (1.0): 240 G pairs/s for the distance alone, 135 G with the rays.
+bool query_is_tiny(size_t n_q, size_t n_tris, int algorithm, int sign_src) {
+  if (algorithm != 0 || n_tris == 0 || n_q == 0 || sign_src == SIGN_XRAY_ALL) return false;
+  const double limit = tuning().brute_max >= 0.0 ? tuning().brute_max : (sign_src == SIGN_RAYS3 ? 6.0e7 : 1.2e8);
+  return (double)n_q * (double)n_tris <= limit;
+}
+int launch_query_brute_split(Arena& ws, hipStream_t st, const DeviceMesh& mesh, const float* d_queries, size_t n_q, int mode, int sign_src,
+                             float* d_out, int* d_err) {
+  const uint32_t nq = (uint32_t)n_q;
+  uint32_t* acc = ws.take<uint32_t>(4 * n_q);
+  if (!acc) { set_error("internal: query workspace too small"); return M2S_ERR_HIP_INTERNAL; }
+  const uint32_t qblocks = (nq + 255u) / 256u, tiles = (mesh.n_tris + TILE - 1) / TILE;
+  // ~4 blocks per CU over (query blocks x triangle chunks); a chunk is a whole number of 128-triangle tiles
+  const uint32_t chunks = std::max(1u, std::min(tiles, (1024u + qblocks - 1) / qblocks));
+  const uint32_t tiles_per_chunk = (tiles + chunks - 1) / chunks, ychunks = (tiles + tiles_per_chunk - 1) / tiles_per_chunk;
+  const dim3 grid(qblocks, ychunks);
+  hipLaunchKernelGGL(k_brute_q_init, dim3(qblocks), dim3(256), 0, st, acc, nq, mode == MODE_NORMAL_FOLD ? 0x7f800000u : 0u);
+  if (mode == MODE_UNSIGNED && sign_src == SIGN_RAYS3) {
+    hipLaunchKernelGGL((k_brute_split_q<MODE_UNSIGNED, SIGN_RAYS3>), grid, dim3(256), 0, st, mesh, d_queries, nq, acc, d_err, tiles_per_chunk);
+    hipLaunchKernelGGL((k_brute_finish_q<MODE_UNSIGNED, SIGN_RAYS3>), dim3(qblocks), dim3(256), 0, st, (const uint32_t*)acc, nq, d_out);
+  } else if (mode == MODE_UNSIGNED) {
+    hipLaunchKernelGGL((k_brute_split_q<MODE_UNSIGNED, SIGN_NONE>), grid, dim3(256), 0, st, mesh, d_queries, nq, acc, d_err, tiles_per_chunk);
+    hipLaunchKernelGGL((k_brute_finish_q<MODE_UNSIGNED, SIGN_NONE>), dim3(qblocks), dim3(256), 0, st, (const uint32_t*)acc, nq, d_out);
+  } else if (mode == MODE_NORMAL_FOLD) {
+    hipLaunchKernelGGL((k_brute_split_q<MODE_NORMAL_FOLD, SIGN_NONE>), grid, dim3(256), 0, st, mesh, d_queries, nq, acc, d_err, tiles_per_chunk);
+    hipLaunchKernelGGL((k_brute_finish_q<MODE_NORMAL_FOLD, SIGN_NONE>), dim3(qblocks), dim3(256), 0, st, (const uint32_t*)acc, nq, d_out);
+  } else {
+    hipLaunchKernelGGL((k_brute_split_q<MODE_NEAREST_NORMAL, SIGN_NONE>), grid, dim3(256), 0, st, mesh, d_queries, nq, acc, d_err, tiles_per_chunk);
+    hipLaunchKernelGGL((k_brute_finish_q<MODE_NEAREST_NORMAL, SIGN_NONE>), dim3(qblocks), dim3(256), 0, st, (const uint32_t*)acc, nq, d_out);
+  }
+  M2S_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
 size_t query_workspace_bytes(size_t n_q) {
   size_t n = n_q ? n_q : 1, tmp = 0;
   (void)rocprim::radix_sort_pairs(nullptr, tmp, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr,
                             n, 0, 30, (hipStream_t)0);
   size_t sel = 0;
   (void)rocprim::select(nullptr, sel, rocprim::counting_iterator<uint32_t>(0), (uint8_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, n, (hipStream_t)0);
-  return n * (8 + 8 + 4 + 4 + 16 + 1 + 4) + (n / 32 + 64) * (16 + 4 * CUT_WORDS) + tmp + sel + 21 * 256 + (size_t)64 * 64 * 64 * 44 + 8192 + 24 * 1024 + 256;
+  return n * (8 + 8 + 4 + 4 + 16 + 1 + 4) + n * 16 + 256 + (n / 32 + 64) * (16 + 4 * CUT_WORDS) + tmp + sel + 21 * 256 + (size_t)64 * 64 * 64 * 44 + 8192 + 24 * 1024 + 256;
 }
 
 // Generic queries in two parts.  prepare_query_walk needs the queries only — bounding box, Morton keys, sort, packet table, the
@@ -2511,6 +2629,8 @@ int launch_query_walk(Arena& ws, hipStream_t st, const DeviceMesh& mesh, const f
 
 int launch_query_distance(Arena& ws, hipStream_t st, const DeviceMesh& mesh, const float* d_queries, size_t n_q,
                           int mode, int sign_src, int algorithm, float* d_out, int* d_err) {
+  if (query_is_tiny(n_q, mesh.n_tris, algorithm, sign_src) && mesh.stats == nullptr)
+    return launch_query_brute_split(ws, st, mesh, d_queries, n_q, mode, sign_src, d_out, d_err);
   QueryPlan plan;
   const int rc = prepare_query_walk(ws, st, d_queries, n_q, mesh.n_tris, sign_src, algorithm, &plan, nullptr);
   if (rc) return rc;

@@ -10,6 +10,7 @@
 // One host thread per shard: each calls the ordinary single-device entry point with its (device, lane) context,
 // x-slab and peer list, so the multi-device path adds no second implementation of anything.
 #include <dlfcn.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <atomic>
@@ -185,6 +186,13 @@ class ShardPool {
     if (n <= 1) { if (n == 1) job(0); return true; }
     std::unique_lock<std::mutex> own(owner_, std::try_to_lock);
     if (!own.owns_lock()) return run_adhoc(n, job);
+    if (pid_ != getpid()) {
+      // a child of fork(): the workers' threads stayed with the parent — posting to them would wait for ever.  Their records are
+      // abandoned (a std::thread that believes it is joinable must not be destroyed) and the child grows workers of its own.
+      for (auto& w : workers_) (void)w.release();
+      workers_.clear();
+      pid_ = getpid();
+    }
     try {
       while ((int)workers_.size() < n - 1) {
         workers_.emplace_back(new Worker());
@@ -265,6 +273,7 @@ class ShardPool {
   }
   std::mutex owner_;
   std::vector<std::unique_ptr<Worker>> workers_;
+  pid_t pid_ = getpid();
 };
 ShardPool& shard_pool() {
   static ShardPool p;
@@ -279,6 +288,10 @@ struct AdaptiveKey {
   m2s_grid grid;
   size_t n_vertices, n_indices;
   int sign_method, n;
+  // ... and where and how the shards run: the same grid on other devices, with another delivery, is another problem
+  int mem_kind, exchange, peer_mode;
+  int devices[M2S_MAX_PEERS + 1];
+  unsigned long long mesh_tag;   // a fingerprint of the first and last vertices / indices passed (host pointers: their bytes; device pointers: the addresses)
   bool operator<(const AdaptiveKey& o) const { return memcmp(this, &o, sizeof(*this)) < 0; }
 };
 std::mutex g_adaptive_mu;
@@ -422,9 +435,22 @@ int m2s_generate_grid_sdf_multi(const float* vertices, size_t n_vertices, const 
   // M2S_XCHG_NONE leaves buffer k with shard k's cells only: the caller finds them through m2s_slab_bounds unless it asked for
   // another partition explicitly (and reads `slabs` back)
   if (partition == M2S_PART_AUTO && exchange == M2S_XCHG_NONE) partition = M2S_PART_CONTIGUOUS;
-  AdaptiveKey akey{};
+  AdaptiveKey akey;
+  memset(&akey, 0, sizeof(akey));   // compared bytewise, padding included
   if (partition == M2S_PART_ADAPTIVE && n > 1 && !empty) {
     akey.grid = *grid; akey.n_vertices = n_vertices; akey.n_indices = n_indices; akey.sign_method = sign_method; akey.n = n;
+    akey.mem_kind = mem_kind; akey.exchange = exchange; akey.peer_mode = mp.peer_mode;
+    for (int k = 0; k < n; ++k) akey.devices[k] = devices[k];
+    if (mem_kind == M2S_MEM_HOST && vertices && n_vertices) {
+      unsigned long long h = 1469598103934665603ull;
+      const unsigned char* vb = reinterpret_cast<const unsigned char*>(vertices);
+      const size_t nb = n_vertices * 12, take = std::min<size_t>(nb, 256);
+      for (size_t i = 0; i < take; ++i) h = (h ^ vb[i]) * 1099511628211ull;
+      for (size_t i = nb - take; i < nb; ++i) h = (h ^ vb[i]) * 1099511628211ull;
+      akey.mesh_tag = h;
+    } else {
+      akey.mesh_tag = (unsigned long long)(uintptr_t)vertices ^ ((unsigned long long)(uintptr_t)indices << 1);
+    }
     std::lock_guard<std::mutex> lk(g_adaptive_mu);
     auto it = g_adaptive.find(akey);
     if (it != g_adaptive.end())
@@ -498,7 +524,9 @@ int m2s_generate_grid_sdf_multi(const float* vertices, size_t n_vertices, const 
     // next call's slabs: equal shares of this call's cost (what shards: everything but the LBVH build, which every shard repeats)
     std::vector<uint64_t> prev((size_t)n + 1), next((size_t)n + 1);
     std::vector<float> cost((size_t)n);
-    for (int k = 0; k < n; ++k) { prev[k] = xb[k]; cost[k] = std::max(shard_timings[k].total_ms - shard_timings[k].accel_build_ms, 0.0f); }
+    // (the phases a shard computes — sign planes, seeds and cut lists, walk — not its total: that also holds the time it waited for a peer
+    // or a collective, and a slow link is not to be balanced as if it were work)
+    for (int k = 0; k < n; ++k) { prev[k] = xb[k]; cost[k] = std::max(shard_timings[k].sign_ms + shard_timings[k].seed_ms + shard_timings[k].distance_ms, 0.0f); }
     prev[n] = nx;
     uint32_t bl[3];
     choose_brick_shape(grid->cell_size, bl);
