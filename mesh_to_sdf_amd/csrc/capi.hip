@@ -1007,7 +1007,7 @@ int m2s_generate_grid_sdf(const float* vertices, size_t n_vertices, const void* 
       DeviceMesh rm{};
       rm.tris = raw;
       rm.n_tris = (uint32_t)n_tris;
-      int r2 = build_grid_sign_plane(ws, st->side_stream2, rm, g, &plane);
+      int r2 = build_grid_sign_plane(ws, st->side_stream2, rm, g, &plane, true);
       if (r2) return r2;
       M2S_HIP_CHECK(hipEventRecord(st->ev[2], st->side_stream2));
       st->early_planes = true;
@@ -1043,7 +1043,7 @@ int m2s_generate_grid_sdf(const float* vertices, size_t n_vertices, const void* 
     hipStream_t ss;
     rc = sign_stream_begin(*st, c.stream, c.sync, &ss);
     if (rc) return rc;
-    rc = build_grid_sign_plane(ws, ss, mesh, g, &plane);
+    rc = build_grid_sign_plane(ws, ss, mesh, g, &plane, true);
     if (rc) return rc;
     rc = sign_stream_end(*st, c.stream, ss);
     if (rc) return rc;
@@ -1416,7 +1416,7 @@ int m2s_mesh_generate_grid_sdf(m2s_mesh* m, const m2s_grid* grid, int sign_metho
       hipStream_t ss;
       rc = sign_stream_begin(*st, c.stream, c.sync, &ss);
       if (rc) return rc;
-      rc = build_grid_sign_plane(pw, ss, m->dm, g, &m->plane);
+      rc = build_grid_sign_plane(pw, ss, m->dm, g, &m->plane, false);   // kept per grid, whatever slab asks first
       if (rc) return rc;
       m->plane_grid = *grid;
       m->plane_valid = true;

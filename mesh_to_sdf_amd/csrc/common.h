@@ -229,8 +229,9 @@ int build_device_mesh(Arena& ws, hipStream_t st, const float* d_verts, size_t n_
 
 // sign.hip: grid-line ray parity -> one "inside" bit per voxel (bit plane in grid layout).
 size_t sign_workspace_bytes(const GridParams& g, size_t n_tris);
+// slab_only: the planes of the x-layers [g.xb, g.xe) (virtual slab) only — what a one-shot slab call reads; false: the whole grid
 int build_grid_sign_plane(Arena& ws, hipStream_t st, const DeviceMesh& mesh, const GridParams& g,
-                          const uint32_t** d_inside_plane);
+                          const uint32_t** d_inside_plane, bool slab_only);
 
 // distance.hip
 size_t grid_distance_workspace_bytes(const GridParams& g);

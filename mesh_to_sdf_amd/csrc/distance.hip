@@ -2245,8 +2245,15 @@ int prepare_grid_walk(Arena& ws, hipStream_t st, const DeviceMesh& mesh, const G
   plan->cut_lists = cut.lists; plan->cut_log = cut.log; plan->cut_ny = cut.ny; plan->cut_nz = cut.nz;
   plan->lane_walk = lane_walk;
   // split walk (packet walk only; M2S_SPLIT: -1 / 1 on, 0 off, 2 on with the flags raised from the start)
+  // Where it pays (tools/exp_split.py, exp_split_rank.py; walk with / without): the stragglers are the packets deep inside a body
+  // whose voxels see many triangles at (nearly) the same distance, and they weigh the more the finer the mesh is against the grid —
+  // blob-100k in 96^3 ... 192^3 1.79 -> 1.07, 1.57 -> 1.28, 1.81 -> 1.63 ms, in 256^3 2.25 -> 2.34 (a wash), the 64-layer slabs of
+  // 512^3 1.21 -> 1.26 (a loss: no tail to speak of, three more launches); blob-1M in 256^3 12.8 -> 9.5 ms, its slowest 8-GPU slab of
+  // 512^3 5.05 -> 4.05, its fastest 3.14 -> 3.16.  Automatic: from 0.45 triangles per packet brick of the WHOLE grid on.
   const Tuning& tn = tuning();
-  if (!brute && !lane_walk && mesh.n_nodes != 0 && tn.split != 0 && mesh.stats == nullptr && packets <= SPLIT_MAX_PACKETS) {
+  const double grid_bricks = (double)bricks_along(g.n[0], g.bl[0]) * bricks_along(g.n[1], g.bl[1]) * bricks_along(g.n[2], g.bl[2]);
+  const bool split_pays = tn.split > 0 || (double)mesh.n_tris >= 0.45 * grid_bricks;
+  if (!brute && !lane_walk && mesh.n_nodes != 0 && tn.split != 0 && split_pays && mesh.stats == nullptr && packets <= SPLIT_MAX_PACKETS) {
     SplitCtl sc;
     sc.cap_slots = split_cap_slots(packets);
     sc.cap_items = std::max(sc.cap_slots, std::min(sc.cap_slots * SPLIT_ITEMS_PER_SLOT, 1u << 20));

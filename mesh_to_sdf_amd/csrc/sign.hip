@@ -49,13 +49,31 @@ struct FreeAxes {
   static constexpr int W = AXIS == 2 ? 1 : 2;
 };
 
+// A call that computes an x-slab only needs the planes of the slab's layers: Y- and Z-lines lie inside one x-layer,
+// so a line outside the slab is never looked at (its markers would only be read by cells the call does not compute); X-lines cross
+// all layers and are all traced — their hits are slab-independent, t is measured from cell 0 — but the suffix scan along x stops
+// at the slab's first layer.  SlabX: the real x-layers of the slab ([lo, hi) is their hull; an interleaved slab owns the chunks
+// [lo + j * period, + 2^chunk_log) inside it); all == true: the whole grid (persistent meshes keep their planes per grid, not per slab).
+struct SlabX {
+  uint32_t lo, hi, chunk_log, period;
+  bool all;
+};
+__device__ __forceinline__ bool x_in_slab(const SlabX& sx, uint32_t x) {
+  if (sx.all) return true;
+  if (x < sx.lo || x >= sx.hi) return false;
+  return sx.chunk_log >= 31u || ((x - sx.lo) % sx.period) < (1u << sx.chunk_log);
+}
 template <int AXIS>
-__device__ __forceinline__ Window make_window(f3 mn, f3 mx, const GridParams& g) {
+__device__ __forceinline__ Window make_window(f3 mn, f3 mx, const GridParams& g, const SlabX& sx) {
   constexpr int U = FreeAxes<AXIS>::U, W = FreeAxes<AXIS>::W;
   const float bmn[3] = {mn.x, mn.y, mn.z}, bmx[3] = {mx.x, mx.y, mx.z};
   Window w;
   axis_range(bmn[U], bmx[U], g.first[U], g.size[U], g.n[U], &w.ulo, &w.uhi);
   axis_range(bmn[W], bmx[W], g.first[W], g.size[W], g.n[W], &w.wlo, &w.whi);
+  if (AXIS != 0 && !sx.all && w.ulo <= w.uhi) {      // U is x for the Y- and Z-lines: only the slab's layers
+    w.ulo = max(w.ulo, sx.lo);
+    w.uhi = min(w.uhi, sx.hi - 1u);
+  }
   if (w.wlo > w.whi) { w.ulo = 1; w.uhi = 0; }
   return w;
 }
@@ -65,9 +83,10 @@ __device__ __forceinline__ uint32_t window_count(const Window& w) {
 
 // One grid line (free-axis cell iu, iw) against one triangle.
 template <int AXIS>
-__device__ __forceinline__ void mark_line(f3 a, f3 b, f3 c, f3 mn, f3 mx, const GridParams& g, uint32_t iu,
+__device__ __forceinline__ void mark_line(f3 a, f3 b, f3 c, f3 mn, f3 mx, const GridParams& g, const SlabX& sx, uint32_t iu,
                                           uint32_t iw, uint32_t* __restrict__ plane) {
   constexpr int U = FreeAxes<AXIS>::U, W = FreeAxes<AXIS>::W;
+  if (AXIS != 0 && !x_in_slab(sx, iu)) return;        // (an interleaved slab: the layers between its chunks)
   uint32_t cell[3];
   cell[AXIS] = 0; cell[U] = iu; cell[W] = iw;
   const f3 o = {cell_center(g.first[0], g.size[0], cell[0]), cell_center(g.first[1], g.size[1], cell[1]),
@@ -91,15 +110,15 @@ struct BigList {
 };
 
 template <int AXIS>
-__device__ __forceinline__ void mark_axis(bool valid, uint32_t tri, f3 a, f3 b, f3 c, f3 mn, f3 mx, const GridParams& g,
+__device__ __forceinline__ void mark_axis(bool valid, uint32_t tri, f3 a, f3 b, f3 c, f3 mn, f3 mx, const GridParams& g, const SlabX& sx,
                                           uint32_t* __restrict__ plane, const BigList& list) {
   Window w = {1, 0, 1, 0};
-  if (valid) w = make_window<AXIS>(mn, mx, g);
+  if (valid) w = make_window<AXIS>(mn, mx, g, sx);
   const uint32_t cnt = window_count(w);
   const bool small = cnt <= SMALL_WINDOW;
   if (small) {
     for (uint32_t iu = w.ulo; iu <= w.uhi && cnt; ++iu)
-      for (uint32_t iw = w.wlo; iw <= w.whi; ++iw) mark_line<AXIS>(a, b, c, mn, mx, g, iu, iw, plane);
+      for (uint32_t iw = w.wlo; iw <= w.whi; ++iw) mark_line<AXIS>(a, b, c, mn, mx, g, sx, iu, iw, plane);
   }
   if (list.items != nullptr) {
     // Windows too large for one lane go onto a work list; k_ray_mark_big spreads their lines over the whole
@@ -131,11 +150,11 @@ __device__ __forceinline__ void mark_axis(bool valid, uint32_t tri, f3 a, f3 b, 
     const uint32_t nw = whi - wlo + 1u;
     const uint64_t total = (uint64_t)(uhi - ulo + 1u) * nw;
     for (uint64_t i = lane; i < total; i += 64)
-      mark_line<AXIS>(sa, sb, sc, smn, smx, g, ulo + (uint32_t)(i / nw), wlo + (uint32_t)(i % nw), plane);
+      mark_line<AXIS>(sa, sb, sc, smn, smx, g, sx, ulo + (uint32_t)(i / nw), wlo + (uint32_t)(i % nw), plane);
   }
 }
 
-__global__ __launch_bounds__(256) void k_ray_mark(DeviceMesh mesh, GridParams g, uint32_t* __restrict__ px,
+__global__ __launch_bounds__(256) void k_ray_mark(DeviceMesh mesh, GridParams g, SlabX sx, uint32_t* __restrict__ px,
                                                   uint32_t* __restrict__ py, uint32_t* __restrict__ pz, BigList list) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   const bool valid = t < mesh.n_tris;
@@ -147,25 +166,25 @@ __global__ __launch_bounds__(256) void k_ray_mark(DeviceMesh mesh, GridParams g,
     c = mk3(r.cx, r.cy, r.cz);
     triangle_bounding_box(a, b, c, &mn, &mx);
   }
-  mark_axis<0>(valid, t, a, b, c, mn, mx, g, px, list);
-  mark_axis<1>(valid, t, a, b, c, mn, mx, g, py, list);
-  mark_axis<2>(valid, t, a, b, c, mn, mx, g, pz, list);
+  mark_axis<0>(valid, t, a, b, c, mn, mx, g, sx, px, list);
+  mark_axis<1>(valid, t, a, b, c, mn, mx, g, sx, py, list);
+  mark_axis<2>(valid, t, a, b, c, mn, mx, g, sx, pz, list);
 }
 
 template <int AXIS>
-__device__ __forceinline__ void mark_chunk(const TriRec& r, const GridParams& g, uint32_t chunk, uint32_t* __restrict__ plane) {
+__device__ __forceinline__ void mark_chunk(const TriRec& r, const GridParams& g, const SlabX& sx, uint32_t chunk, uint32_t* __restrict__ plane) {
   const f3 a = mk3(r.ax, r.ay, r.az), b = mk3(r.bx, r.by, r.bz), c = mk3(r.cx, r.cy, r.cz);
   f3 mn, mx;
   triangle_bounding_box(a, b, c, &mn, &mx);
-  const Window w = make_window<AXIS>(mn, mx, g);
+  const Window w = make_window<AXIS>(mn, mx, g, sx);
   const uint32_t nw = w.whi - w.wlo + 1u, total = window_count(w);
   const uint32_t i0 = chunk * BIG_CHUNK, i1 = min(total, i0 + BIG_CHUNK);
   for (uint32_t i = i0 + threadIdx.x; i < i1; i += blockDim.x)
-    mark_line<AXIS>(a, b, c, mn, mx, g, w.ulo + i / nw, w.wlo + i % nw, plane);
+    mark_line<AXIS>(a, b, c, mn, mx, g, sx, w.ulo + i / nw, w.wlo + i % nw, plane);
 }
 
 // Chunks of the big windows, one per workgroup pass, over a fixed grid (the totals are only known on the device).
-__global__ __launch_bounds__(256) void k_ray_mark_big(DeviceMesh mesh, GridParams g, uint32_t* __restrict__ px,
+__global__ __launch_bounds__(256) void k_ray_mark_big(DeviceMesh mesh, GridParams g, SlabX sx, uint32_t* __restrict__ px,
                                                       uint32_t* __restrict__ py, uint32_t* __restrict__ pz, BigList list) {
   const unsigned long long ctr = *list.counter;
   const uint32_t n_items = (uint32_t)(ctr >> 32), n_chunks = (uint32_t)ctr;
@@ -178,33 +197,36 @@ __global__ __launch_bounds__(256) void k_ray_mark_big(DeviceMesh mesh, GridParam
     const uint2 it = list.items[lo];
     const TriRec r = mesh.tris[it.x & 0x3fffffffu];
     const uint32_t local = chunk - it.y, axis = it.x >> 30;
-    if (axis == 0) mark_chunk<0>(r, g, local, px);
-    else if (axis == 1) mark_chunk<1>(r, g, local, py);
-    else mark_chunk<2>(r, g, local, pz);
+    if (axis == 0) mark_chunk<0>(r, g, sx, local, px);
+    else if (axis == 1) mark_chunk<1>(r, g, sx, local, py);
+    else mark_chunk<2>(r, g, sx, local, pz);
   }
 }
 
 // Suffix XOR along x: thread = one (y, zw) word column, walking x from nx-1 down to 0.
-__global__ __launch_bounds__(256) void k_scan_x(uint32_t* __restrict__ p, uint32_t nx, size_t row_words /*ny*nzw*/) {
+// (down to layer x_stop only: a slab call never reads the layers in front of its first)
+__global__ __launch_bounds__(256) void k_scan_x(uint32_t* __restrict__ p, uint32_t nx, size_t row_words /*ny*nzw*/, uint32_t x_stop) {
   const size_t col = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (col >= row_words) return;
   uint32_t run = 0;
   int64_t x = (int64_t)nx - 1;
-  for (; x >= 7; x -= 8) {
+  const int64_t stop = (int64_t)x_stop;
+  for (; x >= stop + 7; x -= 8) {
     uint32_t v[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) v[k] = p[(size_t)(x - k) * row_words + col];
 #pragma unroll
     for (int k = 0; k < 8; ++k) { run ^= v[k]; p[(size_t)(x - k) * row_words + col] = run; }
   }
-  for (; x >= 0; --x) { run ^= p[(size_t)x * row_words + col]; p[(size_t)x * row_words + col] = run; }
+  for (; x >= stop; --x) { run ^= p[(size_t)x * row_words + col]; p[(size_t)x * row_words + col] = run; }
 }
 
-// Suffix XOR along y: thread = one (x, zw) pair.
-__global__ __launch_bounds__(256) void k_scan_y(uint32_t* __restrict__ p, uint32_t nx, uint32_t ny, uint32_t nzw) {
+// Suffix XOR along y: thread = one (layer, zw) pair; `layers` x-layers of the (virtual) slab g, or of the whole grid.
+__global__ __launch_bounds__(256) void k_scan_y(uint32_t* __restrict__ p, GridParams g, uint32_t layers, bool whole, uint32_t ny, uint32_t nzw) {
   const size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (id >= (size_t)nx * nzw) return;
-  const size_t x = id / nzw, zw = id % nzw;
+  if (id >= (size_t)layers * nzw) return;
+  const size_t v = id / nzw, zw = id % nzw;
+  const size_t x = whole ? v : (size_t)slab_x(g, (uint32_t)v);
   uint32_t* base = p + x * ny * nzw + zw;
   uint32_t run = 0;
   int64_t y = (int64_t)ny - 1;
@@ -221,9 +243,10 @@ __global__ __launch_bounds__(256) void k_scan_y(uint32_t* __restrict__ p, uint32
 // Suffix XOR along z inside each (x,y) row, then "at least two of three odd" (grid.rs:630-636).
 // The majority plane overwrites pz.
 __global__ __launch_bounds__(256) void k_scan_z_combine(const uint32_t* __restrict__ px, const uint32_t* __restrict__ py,
-                                                        uint32_t* __restrict__ pz, size_t rows, uint32_t nzw) {
-  const size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (row >= rows) return;
+                                                        uint32_t* __restrict__ pz, GridParams g, bool whole, size_t rows, uint32_t nzw) {
+  const size_t vrow = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // row of the (virtual) slab: layer * ny + y
+  if (vrow >= rows) return;
+  const size_t row = whole ? vrow : (size_t)slab_x(g, (uint32_t)(vrow / g.n[1])) * g.n[1] + vrow % g.n[1];
   uint32_t carry = 0;
   for (int64_t zw = (int64_t)nzw - 1; zw >= 0; --zw) {
     const size_t i = row * nzw + (size_t)zw;
@@ -241,9 +264,11 @@ __global__ __launch_bounds__(256) void k_scan_z_combine(const uint32_t* __restri
 // segmented suffix-XOR of the word parities done with shuffles.
 __global__ __launch_bounds__(256) void k_scan_z_combine_rows(const uint32_t* __restrict__ px,
                                                              const uint32_t* __restrict__ py, uint32_t* __restrict__ pz,
-                                                             size_t words, uint32_t nzw) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const bool valid = i < words;
+                                                             GridParams g, bool whole, size_t words, uint32_t nzw) {
+  const size_t vi = (size_t)blockIdx.x * blockDim.x + threadIdx.x;     // word of the (virtual) slab; a layer is a whole number of rows
+  const bool valid = vi < words;
+  const size_t layer_words = (size_t)g.n[1] * nzw;
+  const size_t i = (whole || !valid) ? vi : (size_t)slab_x(g, (uint32_t)(vi / layer_words)) * layer_words + vi % layer_words;
   uint32_t z = valid ? pz[i] : 0u;
   z ^= z >> 1; z ^= z >> 2; z ^= z >> 4; z ^= z >> 8; z ^= z >> 16;     // bit b = XOR of marker bits >= b
   const uint32_t zw = (uint32_t)(i & (nzw - 1));                          // word index inside the row
@@ -274,7 +299,7 @@ size_t sign_workspace_bytes(const GridParams& g, size_t n_tris) {
 }
 
 int build_grid_sign_plane(Arena& ws, hipStream_t st, const DeviceMesh& mesh, const GridParams& g,
-                          const uint32_t** d_inside_plane) {
+                          const uint32_t** d_inside_plane, bool slab_only) {
   const size_t words = (size_t)g.n[0] * g.n[1] * g.nzw;
   // the three planes and the work-list counter in ONE block: one memset instead of four launches (a launch costs the host ~8 us
   // and this sequence sits in front of the build's on the calling thread)
@@ -299,17 +324,29 @@ int build_grid_sign_plane(Arena& ws, hipStream_t st, const DeviceMesh& mesh, con
         return M2S_ERR_HIP_INTERNAL;
       }
     }
-    hipLaunchKernelGGL(k_ray_mark, dim3((mesh.n_tris + B - 1) / B), dim3(B), 0, st, mesh, g, px, py, pz, list);
-    if (list.items) hipLaunchKernelGGL(k_ray_mark_big, dim3(2048), dim3(B), 0, st, mesh, g, px, py, pz, list);
+    // the slab's real x-layers (see SlabX): hull [lo, hi), chunks of an interleaved slab inside it
+    const uint32_t vlayers = g.xe - g.xb;
+    const bool whole = !slab_only || vlayers == 0 || (g.xb == 0 && vlayers == g.n[0] && g.chunk_log >= 31u);
+    SlabX sx{0u, g.n[0], 31u, 0u, true};
+    if (!whole) {
+      sx.all = false;
+      sx.lo = g.xb;
+      sx.hi = slab_x(g, vlayers - 1u) + 1u;
+      sx.chunk_log = g.chunk_log;
+      sx.period = g.period ? g.period : 1u;
+    }
+    const uint32_t layers = whole ? g.n[0] : vlayers;
+    hipLaunchKernelGGL(k_ray_mark, dim3((mesh.n_tris + B - 1) / B), dim3(B), 0, st, mesh, g, sx, px, py, pz, list);
+    if (list.items) hipLaunchKernelGGL(k_ray_mark_big, dim3(2048), dim3(B), 0, st, mesh, g, sx, px, py, pz, list);
     const size_t row_words = (size_t)g.n[1] * g.nzw;
-    hipLaunchKernelGGL(k_scan_x, dim3((unsigned)((row_words + B - 1) / B)), dim3(B), 0, st, px, g.n[0], row_words);
-    const size_t ycols = (size_t)g.n[0] * g.nzw;
-    hipLaunchKernelGGL(k_scan_y, dim3((unsigned)((ycols + B - 1) / B)), dim3(B), 0, st, py, g.n[0], g.n[1], g.nzw);
-    const size_t rows = (size_t)g.n[0] * g.n[1];
+    hipLaunchKernelGGL(k_scan_x, dim3((unsigned)((row_words + B - 1) / B)), dim3(B), 0, st, px, g.n[0], row_words, whole ? 0u : sx.lo);
+    const size_t ycols = (size_t)layers * g.nzw;
+    hipLaunchKernelGGL(k_scan_y, dim3((unsigned)((ycols + B - 1) / B)), dim3(B), 0, st, py, g, layers, whole, g.n[1], g.nzw);
+    const size_t rows = (size_t)layers * g.n[1], slab_words = rows * g.nzw;
     if (g.nzw <= 64 && (g.nzw & (g.nzw - 1)) == 0)
-      hipLaunchKernelGGL(k_scan_z_combine_rows, dim3((unsigned)((words + B - 1) / B)), dim3(B), 0, st, px, py, pz, words, g.nzw);
+      hipLaunchKernelGGL(k_scan_z_combine_rows, dim3((unsigned)((slab_words + B - 1) / B)), dim3(B), 0, st, px, py, pz, g, whole, slab_words, g.nzw);
     else
-      hipLaunchKernelGGL(k_scan_z_combine, dim3((unsigned)((rows + B - 1) / B)), dim3(B), 0, st, px, py, pz, rows, g.nzw);
+      hipLaunchKernelGGL(k_scan_z_combine, dim3((unsigned)((rows + B - 1) / B)), dim3(B), 0, st, px, py, pz, g, whole, rows, g.nzw);
   }
   M2S_HIP_CHECK(hipGetLastError());
   return 0;
