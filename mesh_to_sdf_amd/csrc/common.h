@@ -79,6 +79,7 @@ static_assert(sizeof(TriPlanes) == 64, "TriPlanes must be 64 bytes");
 
 struct DeviceMesh {
   const TriRec* tris;   // n_tris records, Morton order
+  const float4* corners;    // n_tris x 3: the vertices alone, 48 B per triangle ((a, b.x) (b.yz, c.xy) (c.z, -, -, -)) — what the ray walks read
   const TriPlanes* planes;  // n_tris leaf pre-test records
   const float4* cen;    // n_tris triangle centroids (same order), for the jump-flooding seed pass
   const float4* cen_raw;     // the same centroids in INPUT triangle order (available before the sort)

@@ -296,8 +296,10 @@ __device__ __forceinline__ uint32_t stab_count(const DeviceMesh& mesh, f3 p) {
     if (nr.tri >= 0) {
       const uint32_t cnt = (nr.skip - node + 1u) >> 1;
       for (uint32_t k = 0; k < cnt; ++k) {
-        const TriRec tr = record_at_vec(mesh.tris, (uint32_t)nr.tri + k);
-        const f3 a = mk3(tr.ax, tr.ay, tr.az), b = mk3(tr.bx, tr.by, tr.bz), c = mk3(tr.cx, tr.cy, tr.cz);
+        uint32_t vi;                                   // (a wave-uniform index through a VGPR: a broadcast out of the vector L1, as record_at_vec)
+        asm("v_mov_b32_e32 %0, %1" : "=v"(vi) : "s"(3u * ((uint32_t)nr.tri + k)));
+        const float4 c0 = mesh.corners[vi], c1 = mesh.corners[vi + 1u], c2 = mesh.corners[vi + 2u];
+        const f3 a = mk3(c0.x, c0.y, c0.z), b = mk3(c0.w, c1.x, c1.y), c = mk3(c1.z, c1.w, c2.x);
         f3 mn, mx;
         triangle_bounding_box(a, b, c, &mn, &mx);     // the candidate rule is per triangle: ITS padded box
         float t;
@@ -1403,8 +1405,9 @@ __device__ __forceinline__ uint32_t stab_count_lane(const DeviceMesh& mesh, f3 p
     if (nr.tri >= 0) {
       const uint32_t cnt = (nr.skip - node + 1u) >> 1;
       for (uint32_t k = 0; k < cnt; ++k) {
-        const TriRec& tr = mesh.tris[(uint32_t)nr.tri + k];
-        const f3 a = mk3(tr.ax, tr.ay, tr.az), b = mk3(tr.bx, tr.by, tr.bz), c = mk3(tr.cx, tr.cy, tr.cz);
+        const uint32_t vi = 3u * ((uint32_t)nr.tri + k);
+        const float4 c0 = mesh.corners[vi], c1 = mesh.corners[vi + 1u], c2 = mesh.corners[vi + 2u];
+        const f3 a = mk3(c0.x, c0.y, c0.z), b = mk3(c0.w, c1.x, c1.y), c = mk3(c1.z, c1.w, c2.x);
         f3 mn, mx;
         triangle_bounding_box(a, b, c, &mn, &mx);     // the candidate rule is per triangle: ITS padded box
         float t;
