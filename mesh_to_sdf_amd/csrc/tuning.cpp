@@ -38,7 +38,6 @@ const Entry TABLE[] = {
     M2S_KNOB("M2S_SPLIT_MAX_RECORDS", K_U32, split_max_records),
     M2S_KNOB("M2S_SPLIT_ROUNDS", K_U32, split_rounds),
     M2S_KNOB("M2S_SPLIT_REPORT", K_INT, split_report),
-    M2S_KNOB("M2S_LEAF_MAX", K_U32, leaf_max),
     M2S_KNOB("M2S_HOST_PIECE_MB", K_U32, host_piece_mb),
     M2S_KNOB("M2S_PUSH_PIECES", K_U32, push_pieces),
     M2S_KNOB("M2S_PUSH_BLOCKS", K_U32, push_blocks),
@@ -67,7 +66,6 @@ void copy_field(Tuning& dst, const Tuning& src, const Entry& e) {
 }
 
 void sanitise(Tuning& t) {
-  if (t.leaf_max < 1) t.leaf_max = 1;
   if (t.split_rounds < 1) t.split_rounds = 1;
   if (t.split_rounds > 6) t.split_rounds = 6;
   if (t.push_pieces < 1) t.push_pieces = 1;
