@@ -204,3 +204,36 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp", "Makefile")):
                 txt = open(os.path.join(dp, f), errors="replace").read()
                 assert "import oracle" not in txt and "from oracle" not in txt and "m2s_oracle" not in txt, f
+
+
+def test_tuning_table_set_describe_and_errors(lib):
+    """The knob table (csrc/tuning.h): every knob is listed, set and reset through the ABI, nested settings come back, an unknown name
+    or an unparsable value is M2S_ERR_BAD_ARG with a message; the table and the DESIGN.md §9 table name the same knobs."""
+    knobs = _lib.describe_knobs()
+    hdr = open(os.path.join(ROOT, "mesh_to_sdf_amd", "csrc", "tuning.h")).read()
+    documented = set(re.findall(r"//\s+(M2S_[A-Z_0-9]+)\b", hdr))
+    assert set(knobs) == documented, (sorted(set(knobs) ^ documented))
+    design = open(os.path.join(ROOT, "DESIGN.md")).read()
+    section = design[design.index("## 9. Run-time knobs"):]
+    for name in knobs:
+        assert f"`{name}`" in section, f"{name} missing from DESIGN.md §9"
+    assert float(knobs["M2S_SPLIT_PATIENCE"]) == 1.5 and int(knobs["M2S_LANE_WALK"]) == -1
+    with _lib.knobs(M2S_LANE_WALK=1, M2S_BRUTE_MAX=0):
+        inner = _lib.describe_knobs()
+        assert int(inner["M2S_LANE_WALK"]) == 1 and float(inner["M2S_BRUTE_MAX"]) == 0.0
+        with _lib.knobs(M2S_LANE_WALK=0):
+            assert int(_lib.describe_knobs()["M2S_LANE_WALK"]) == 0
+        assert int(_lib.describe_knobs()["M2S_LANE_WALK"]) == 1
+    assert _lib.describe_knobs() == knobs
+    assert lib.m2s_tuning_set(b"M2S_NO_SUCH_KNOB", b"1") == -1
+    assert b"M2S_NO_SUCH_KNOB" in lib.m2s_last_error()
+    assert lib.m2s_tuning_set(b"M2S_CUT_FAR", b"zero") == -1
+    assert _lib.describe_knobs() == knobs
+    # out-of-range values are clamped, not taken literally
+    with _lib.knobs(M2S_SPLIT_ROUNDS=99):
+        assert int(_lib.describe_knobs()["M2S_SPLIT_ROUNDS"]) == 6
+    # one look at the environment in the whole library
+    csrc = os.path.join(ROOT, "mesh_to_sdf_amd", "csrc")
+    sites = [(f, n + 1) for f in sorted(os.listdir(csrc)) if f.endswith((".hip", ".cpp", ".h"))
+             for n, line in enumerate(open(os.path.join(csrc, f))) if re.search(r"\bgetenv\s*\(", line)]
+    assert sites == [("tuning.cpp", sites[0][1])], sites

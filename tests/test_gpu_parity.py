@@ -967,3 +967,29 @@ def test_many_small_triangles_per_voxel_lane_walk(sign):
     for a, b in ((0, 7), (7, 8), (8, 20)):
         generate_grid_sdf(v, Topology.TriangleList(idx), g, sign, x_slab=(a, b), out=out)
     assert_bit_equal(out, want, f"lane walk {sign.name} in slabs")
+
+
+@pytest.mark.parametrize("n,mesh", [(96, "blob-100k"), (128, "blob-100k"), (72, "blob-11k")])
+def test_split_walk_stragglers_only(n, mesh):
+    """The split walk as it runs by default on mid-size grids — stragglers only, chosen by the launch's own clock, so WHICH packets
+    are suspended differs from run to run — against the same walk without it: bit-identical, both sign rules, whole grid and an x-slab
+    (whose one-shot call marks the sign planes of its own layers only), several repetitions."""
+    import torch
+
+    if float(_lib.describe_knobs()["M2S_BRUTE_MAX"]) == 0.0:
+        pytest.skip("once is enough (the forced modes cover the mechanics)")
+    v, idx = meshes.blob(80, 71) if mesh == "blob-11k" else meshes.named(mesh)
+    lo, hi = meshes.extended_bbox(v, 0.1)
+    g = Grid.from_bounding_box(lo, hi, [n, n - 8, n + 4])
+    dv = torch.as_tensor(v, device="cuda")
+    topo = Topology.TriangleList(torch.as_tensor(idx.astype(np.int64), device="cuda").to(torch.int32))
+    for sign in (SignMethod.Raycast, SignMethod.Normal):
+        for slab in (None, (16, 48)):
+            with _lib.knobs(M2S_SPLIT=0, M2S_LANE_WALK=0, M2S_BRUTE_MAX=0):
+                want = generate_grid_sdf(dv, topo, g, sign, x_slab=slab).cpu().numpy()
+            for patience in (1.5, 0.25, 0.0):
+                with _lib.knobs(M2S_SPLIT=1, M2S_SPLIT_PATIENCE=patience, M2S_LANE_WALK=0, M2S_BRUTE_MAX=0):
+                    for rep in range(2):
+                        got = generate_grid_sdf(dv, topo, g, sign, x_slab=slab).cpu().numpy()
+                        sel = slice(None) if slab is None else slice(slab[0] * g.get_cell_count()[1] * g.get_cell_count()[2], slab[1] * g.get_cell_count()[1] * g.get_cell_count()[2])
+                        assert_bit_equal(got[sel], want[sel], f"{mesh} {n}^3 {sign.name} slab {slab} patience {patience} rep {rep}")
