@@ -2211,9 +2211,20 @@ int prepare_grid_walk(Arena& ws, hipStream_t st, const DeviceMesh& mesh, const G
   const int lane_env = tuning().lane_walk;   // -1 auto, 0 never, 1 always
   // measured crossover with the work-sharing lane walk (lane / packet walk, whole call, Raycast): blob-11k 32^3 0.77 / 0.86 ms, 48^3
   // 0.80 / 0.71; blob-100k 64^3 1.71 / 2.85, 96^3 2.19 / 2.12; blob-1M 128^3 8.8 / 12.1, 256^3 32.7 / 14.3: the lane walk wins while
-  // there are more than ~8 triangles per brick
+  // there are more than ~8 triangles per brick.  That is the packet walk WITHOUT the split walk (below), whose launch lasts as long as
+  // its heaviest packets; where those can be split — the launch must be deeper than the chip's wave slots for that — the packets
+  // win up to ~70 triangles per brick (lane walk / packets / packets split, whole call, tools/exp_lane_vs_split.py): blob-100k 88^3
+  // 1.97 / 2.17 / 1.41 ms; blob-1M 96^3 (72 per brick) 5.43 / 9.86 / 5.38, 112^3 7.52 / 11.6 / 6.94, 128^3 7.49 / 11.4 / 5.78,
+  // 192^3 15.1 / 10.7 / 7.60.
+  const Tuning& tn = tuning();
   const double real_bricks = (double)bricks_along(g.xe - g.xb, g.bl[0]) * bricks_along(g.n[1], g.bl[1]) * bricks_along(g.n[2], g.bl[2]);
-  const double lane_ratio = tuning().lane_ratio;
+  const double grid_bricks = (double)bricks_along(g.n[0], g.bl[0]) * bricks_along(g.n[1], g.bl[1]) * bricks_along(g.n[2], g.bl[2]);
+  const bool split_possible = !brute && mesh.n_nodes != 0 && tn.split != 0 && mesh.stats == nullptr && packets <= SPLIT_MAX_PACKETS;
+  // (automatic: a launch at least 1.25 x the chip's 8 192 wave slots deep, padding of the launch order not counted — the patience is measured from the time it takes to hand
+  // the packets out, and a launch that is resident at once has none: blob-100k 80^3, 8 000 packets, 2.33 -> 3.77 ms, blob-11k 64^3
+  // 0.54 -> 1.46 — and from 0.45 triangles per packet brick of the WHOLE grid on, see below)
+  const bool split_auto = split_possible && tn.split < 0 && real_bricks >= 10240.0 && (double)mesh.n_tris >= 0.45 * grid_bricks;
+  const double lane_ratio = split_auto ? tn.lane_ratio_split : tn.lane_ratio;
   const bool lane_walk = !brute && mesh.n_tris && (lane_env >= 0 ? lane_env == 1 : (double)mesh.n_tris > lane_ratio * real_bricks);
   // cut lists: the top of the tree is walked once per block of 2^log bricks per axis (k_cut)
   CutList cut = {nullptr, 0, 0, 0, 0, nullptr};
@@ -2252,11 +2263,8 @@ int prepare_grid_walk(Arena& ws, hipStream_t st, const DeviceMesh& mesh, const G
   // whose voxels see many triangles at (nearly) the same distance, and they weigh the more the finer the mesh is against the grid —
   // blob-100k in 96^3 ... 192^3 1.79 -> 1.07, 1.57 -> 1.28, 1.81 -> 1.63 ms, in 256^3 2.25 -> 2.34 (a wash), the 64-layer slabs of
   // 512^3 1.21 -> 1.26 (a loss: no tail to speak of, three more launches); blob-1M in 256^3 12.8 -> 9.5 ms, its slowest 8-GPU slab of
-  // 512^3 5.05 -> 4.05, its fastest 3.14 -> 3.16.  Automatic: from 0.45 triangles per packet brick of the WHOLE grid on.
-  const Tuning& tn = tuning();
-  const double grid_bricks = (double)bricks_along(g.n[0], g.bl[0]) * bricks_along(g.n[1], g.bl[1]) * bricks_along(g.n[2], g.bl[2]);
-  const bool split_pays = tn.split > 0 || (double)mesh.n_tris >= 0.45 * grid_bricks;
-  if (!brute && !lane_walk && mesh.n_nodes != 0 && tn.split != 0 && split_pays && mesh.stats == nullptr && packets <= SPLIT_MAX_PACKETS) {
+  // 512^3 5.05 -> 4.05, its fastest 3.14 -> 3.16.  Automatic: from 0.45 triangles per packet brick of the WHOLE grid on (split_auto, above).
+  if (!lane_walk && split_possible && (tn.split > 0 || split_auto)) {
     SplitCtl sc;
     sc.cap_slots = split_cap_slots(packets);
     sc.cap_items = std::max(sc.cap_slots, std::min(sc.cap_slots * SPLIT_ITEMS_PER_SLOT, 1u << 20));

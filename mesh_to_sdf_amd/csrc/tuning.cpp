@@ -23,6 +23,7 @@ const Entry TABLE[] = {
     M2S_KNOB("M2S_HOST_TIMES", K_INT, host_times),
     M2S_KNOB("M2S_LANE_WALK", K_INT, lane_walk),
     M2S_KNOB("M2S_LANE_RATIO", K_F64, lane_ratio),
+    M2S_KNOB("M2S_LANE_RATIO_SPLIT", K_F64, lane_ratio_split),
     M2S_KNOB("M2S_QUERY_LANE_COEFF", K_F64, query_lane_coeff),
     M2S_KNOB("M2S_BRUTE_MAX", K_F64, brute_max),
     M2S_KNOB("M2S_CUT_MIN_PACKETS", K_U32, cut_min_packets),

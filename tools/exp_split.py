@@ -12,7 +12,7 @@ from mesh_to_sdf_amd import Grid, M2STimings, SignMethod, Topology, _lib, genera
 
 mesh = sys.argv[1] if len(sys.argv) > 1 else "blob-100k"
 sizes = [int(c) for c in sys.argv[2:]] or [64, 96, 128, 160, 192, 256, 384, 512]
-configs = [("off", {"M2S_SPLIT": 0}), ("on (defaults: patience 1.5, subtrees of 16-128 records, 2 rounds)", {"M2S_SPLIT": 1}), ("automatic", {})]
+configs = [("off", {"M2S_SPLIT": 0}), ("on", {"M2S_SPLIT": 1}), ("on, nothing suspended", {"M2S_SPLIT": 1, "M2S_SPLIT_PATIENCE": 1e9}), ("automatic", {})]
 if os.environ.get("SPLIT_SWEEP"):
     configs += [(f"rounds {r} patience {pt} sub {lo}-{hi}", {"M2S_SPLIT": 1, "M2S_SPLIT_ROUNDS": r, "M2S_SPLIT_PATIENCE": pt, "M2S_SPLIT_MIN_RECORDS": lo, "M2S_SPLIT_MAX_RECORDS": hi})
                 for r, pt, lo, hi in ((3, 1.5, 16, 128), (2, 1.0, 16, 128), (2, 2.0, 16, 128), (2, 3.0, 16, 128), (2, 1.5, 32, 256), (2, 1.5, 64, 512))]
