@@ -548,13 +548,93 @@ __device__ __forceinline__ void emit_reserve(EmitState& em) {
   }
 }
 
+// ---- dense exact evaluations (DEFER) ----------------------------------------------------------
+// Where a brick meets many triangles (a grid coarse against the mesh: 128^3 x blob-100k) an exact evaluation serves 7 - 18 of the
+// wave's 64 lanes — the others' pre-test bound does not reach the triangle — and costs the wave its ~140 instructions all the same.
+// Here the leaf only QUEUES (voxel lane, triangle) pairs for the lanes that are reached (one LDS word per pair, written at the lane's
+// rank in the ballot), and whenever 64 pairs have come together every lane evaluates ONE of them: it fetches that voxel's point with
+// three lane permutes and the pair's triangle record with a gather (pairs of one triangle sit in neighbouring lanes: the same cache
+// line), and folds the result into the voxel's slot with an LDS minimum on the f32 bits (non-negative floats order like their
+// bits; a NaN's bits lie above +inf's and never win, as fminf never takes it).  The lanes' bounds are refreshed from the slots after
+// every batch: they lag by at most one batch, which costs pairs (cheap: a 64th of an evaluation each), never a result — the set of
+// triangles evaluated for a voxel only grows, the minimum of the same arithmetic is the same bits.
+// The slots hold what Best<MODE> holds: d2 bits; Normal fold: + d2pos bits and a NaN flag; nearest-with-normal: the 64-bit key
+// (d2 bits, triangle index, !positive) whose minimum is the lexicographic rule of rtree.rs:118-123 (as the lane walk's LaneShare).
+template <int MODE>
+struct DeferLayout {
+  static constexpr uint32_t SLOT_WORDS = MODE == MODE_NORMAL_FOLD ? 192u : MODE == MODE_NEAREST_NORMAL ? 128u : 64u;
+  static constexpr uint32_t DWORDS = (128u + SLOT_WORDS) / 2u;     // the LDS block of one wave, in 8-byte words
+};
+struct DeferQueue {
+  uint32_t* q;          // LDS: 128 pair words (ring), lane | triangle slot << 6
+  uint32_t* slot;       // LDS: the running results of the 64 voxels (DeferLayout)
+  uint32_t head, n;     // wave-uniform
+};
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+template <int MODE>
+__device__ __forceinline__ unsigned long long defer_key(const Best<MODE>& x) {
+  return ((unsigned long long)__float_as_uint(x.d2) << 32) | ((unsigned long long)(x.idx & 0x7fffffffu) << 1) | (x.pos ? 0ull : 1ull);
+}
+template <int MODE>
+__device__ __forceinline__ DeferQueue defer_begin(unsigned long long* lds) {
+  const uint32_t lane = threadIdx.x & 63u;
+  DeferQueue dq = {reinterpret_cast<uint32_t*>(lds), reinterpret_cast<uint32_t*>(lds) + 128, 0u, 0u};
+  if (MODE == MODE_NEAREST_NORMAL) reinterpret_cast<unsigned long long*>(dq.slot)[lane] = 0x7f800000ffffffffull;   // (+inf, none)
+  else {
+    dq.slot[lane] = 0x7f800000u;
+    if (MODE == MODE_NORMAL_FOLD) { dq.slot[64u + lane] = 0x7f800000u; dq.slot[128u + lane] = 0u; }
+  }
+  return dq;
+}
+// Evaluates up to 64 queued pairs (all of them when fewer are left) and refreshes the lanes' results from their slots.
+template <int MODE>
+__device__ __forceinline__ void defer_flush(const DeviceMesh& mesh, f3 p, DeferQueue& dq, Best<MODE>& best) {
+  const uint32_t lane = threadIdx.x & 63u;
+  wave_lds_sync();
+  const uint32_t take = min(dq.n, 64u);
+  const bool valid = lane < take;
+  const uint32_t e = valid ? dq.q[(dq.head + lane) & 127u] : 0u;
+  const uint32_t v = e & 63u, t = e >> 6;
+  const f3 pv = mk3(__shfl(p.x, (int)v), __shfl(p.y, (int)v), __shfl(p.z, (int)v));
+  Best<MODE> one;
+  eval_triangle<MODE>(one, pv, mesh.tris[t]);
+  if (valid) {
+    if (MODE == MODE_NEAREST_NORMAL) atomicMin(&reinterpret_cast<unsigned long long*>(dq.slot)[v], defer_key<MODE>(one));
+    else {
+      atomicMin(&dq.slot[v], __float_as_uint(one.d2));
+      if (MODE == MODE_NORMAL_FOLD) {
+        atomicMin(&dq.slot[64u + v], __float_as_uint(one.d2pos));
+        if (one.nan) dq.slot[128u + v] = 1u;
+      }
+    }
+  }
+  dq.head = (dq.head + take) & 127u;
+  dq.n -= take;
+  wave_lds_sync();
+  if (MODE == MODE_NEAREST_NORMAL) {
+    const unsigned long long kk = reinterpret_cast<const unsigned long long*>(dq.slot)[lane];
+    if (kk < defer_key<MODE>(best)) { best.d2 = __uint_as_float((uint32_t)(kk >> 32)); best.idx = (uint32_t)(kk >> 1) & 0x7fffffffu; best.pos = (kk & 1ull) == 0ull; }
+  } else {
+    best.d2 = fminf(best.d2, __uint_as_float(dq.slot[lane]));
+    if (MODE == MODE_NORMAL_FOLD) { best.d2pos = fminf(best.d2pos, __uint_as_float(dq.slot[64u + lane])); best.nan |= dq.slot[128u + lane] != 0u; }
+  }
+}
+template <int MODE>
+__device__ __forceinline__ void defer_drain(const DeviceMesh& mesh, f3 p, DeferQueue& dq, Best<MODE>& best) {
+  while (dq.n != 0u) defer_flush<MODE>(mesh, p, dq, best);
+}
+
 // The pre-order records [off, end) of the oriented-bound tree for the 64 points of a wave: position wave-uniform (SGPR), node
 // records and pre-test planes through scalar loads, a subtree left when no lane's bound reaches it.  BUDGET: the walk may stop
 // early (sp.suspended, off = the first record not yet looked at).  EMIT: a suspended walk — surviving subtrees of em.min_bytes ..
 // em.max_bytes are written to the next round's list instead of being entered.
-template <int MODE, bool STATS, bool BUDGET, bool EMIT = false, bool HANDOVER = false>
+template <int MODE, bool STATS, bool BUDGET, bool EMIT = false, bool HANDOVER = false, bool DEFER = false>
 __device__ __forceinline__ void walk_span(const DeviceMesh& mesh, f3 p, float slack, Best<MODE>& best, float& thr, uint32_t& off,
-                                          uint32_t end, WalkStats& st, SplitState& sp, EmitState* emp = nullptr) {
+                                          uint32_t end, WalkStats& st, SplitState& sp, EmitState* emp = nullptr, DeferQueue* dqp = nullptr) {
   // The walk addresses NodeExt by BYTE offset (its skip links are stored that way): the scalar loads then take
   // the offset operand directly and the loop carries no address arithmetic.
   constexpr uint32_t NB = (uint32_t)sizeof(NodeExt);
@@ -579,12 +659,25 @@ __device__ __forceinline__ void walk_span(const DeviceMesh& mesh, f3 p, float sl
         if (STATS) ++st.ext;
         const TriPlanes tp = record_at(mesh.planes, (uint32_t)nr.tri + k);   // scalar: small, needed for every leaf triangle
         const bool reach = !(planes_dist2(p, tp) > thr);
-        if (__ballot(reach) != 0ull) {   // some lane's bound reaches the triangle itself
-          if (STATS) { ++st.leaf; st.pairs += (uint32_t)__popcll(__ballot(reach)); }
-          if (BUDGET && M2S_SPLIT_DEBUG >= 2) sp.units += 4u;
-          const TriRec tr = record_at_vec(mesh.tris, (uint32_t)nr.tri + k);
-          eval_triangle_leaf<MODE>(best, p, tr, reach);
-          thr = prune_bound(best.d2, slack);
+        const unsigned long long rb = __ballot(reach);
+        if (rb != 0ull) {   // some lane's bound reaches the triangle itself
+          if (STATS) { ++st.leaf; st.pairs += (uint32_t)__popcll(rb); }
+          if (DEFER) {
+            DeferQueue& dq = *dqp;
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(rb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)rb, 0u));
+            if (reach) dq.q[(dq.head + dq.n + rank) & 127u] = (threadIdx.x & 63u) | (((uint32_t)nr.tri + k) << 6);
+            dq.n += (uint32_t)__popcll(rb);
+            if (dq.n >= 64u) {
+              if (BUDGET && M2S_SPLIT_DEBUG >= 2) sp.units += 4u;
+              defer_flush<MODE>(mesh, p, dq, best);
+              thr = prune_bound(best.d2, slack);
+            }
+          } else {
+            if (BUDGET && M2S_SPLIT_DEBUG >= 2) sp.units += 4u;
+            const TriRec tr = record_at_vec(mesh.tris, (uint32_t)nr.tri + k);
+            eval_triangle_leaf<MODE>(best, p, tr, reach);
+            thr = prune_bound(best.d2, slack);
+          }
         }
       }
       off = nr.skip;
@@ -663,7 +756,7 @@ __device__ __forceinline__ void store_grid_result(float* __restrict__ out, size_
 // the packet starts from a triangle near its own centre (jump-flooding seed pass below).
 // (eight waves per SIMD: the split variant's bookkeeping would otherwise take the kernel to 106 SGPRs — seven waves, - 12 %; the
 // compiler parks what does not fit in spare VGPR lanes)
-template <bool GRID, int MODE, int SIGN, bool STATS, bool SPLIT>
+template <bool GRID, int MODE, int SIGN, bool STATS, bool SPLIT, bool DEFER = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_packet(DeviceMesh mesh, GridParams g, const float4* __restrict__ qsorted,
                                                const uint32_t* __restrict__ perm, uint32_t n_q,
                                                const uint32_t* __restrict__ plane, float* __restrict__ out,
@@ -713,6 +806,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     const float slack = 4.0e-6f * scale + (MODE == MODE_NORMAL_FOLD ? 2.5e-6f : 0.0f);
     SplitState sp;
     if (SPLIT) split_arm(sp, split, 0u, true);
+    __shared__ unsigned long long defer_lds[DEFER ? DeferLayout<MODE>::DWORDS : 1];
+    DeferQueue dq = {nullptr, nullptr, 0u, 0u};
+    if (DEFER) dq = defer_begin<MODE>(defer_lds);
 
     // pre-order ranges to walk: the brick's cut list (grid path), or the whole tree.  The list is 64 bytes that nobody has
     // touched before (written by k_cut, read once): it is requested here, in front of the seed evaluation, so that the ~1 us of
@@ -791,8 +887,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
         off = (uint32_t)__builtin_amdgcn_readlane((int)cut_off_v, (int)(1u + range));
         const uint32_t end = (uint32_t)__builtin_amdgcn_readlane((int)cut_end_v, (int)(1u + range));
         if (STATS) st_rbytes += end - off;
-        walk_span<MODE, STATS, SPLIT, false, SPLIT>(mesh, p, slack, best, thr, off, end, st, sp);
+        walk_span<MODE, STATS, SPLIT, false, SPLIT, DEFER>(mesh, p, slack, best, thr, off, end, st, sp, nullptr, &dq);
       }
+      if (DEFER) defer_drain<MODE>(mesh, p, dq, best);   // what is still queued (a suspended packet hands over complete minima)
       if (SPLIT && sp.suspended && M2S_SPLIT_DEBUG >= 4) {
         // (range has been stepped once more by the loop's increment)
         if (!split_handover<MODE>(split, packet, range - 1u, off, best, err)) atomicOr(err, ERRF_SPLIT_OVERFLOW);   // cannot happen: a slot per packet
@@ -881,6 +978,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     WalkStats st;
     SplitState idle;
     EmitState em;
+    __shared__ unsigned long long defer_lds[DeferLayout<MODE>::DWORDS];
+    wave_lds_sync();                                                         // (the previous item's slots have been read)
+    DeferQueue dq = defer_begin<MODE>(defer_lds);
     if (continuation) {
       // the packet's ranges again (k_packet's decode), from range `third` on
       uint32_t n_ranges = 1, cut_off_v = 0, cut_end_v = (lane == 1) ? mesh.n_nodes * NB : 0u;
@@ -897,19 +997,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
       for (uint32_t range = third; range < n_ranges; ++range) {
         if (range != third) off = (uint32_t)__builtin_amdgcn_readlane((int)cut_off_v, (int)(1u + range));
         const uint32_t end = (uint32_t)__builtin_amdgcn_readlane((int)cut_end_v, (int)(1u + range));
-        walk_span<MODE, false, false, true>(mesh, p, slack, best, thr, off, end, st, idle, &em);
+        walk_span<MODE, false, false, true, false, true>(mesh, p, slack, best, thr, off, end, st, idle, &em, &dq);
       }
       emit_close(em);
     } else {
       SplitState sp;
       split_arm(sp, split, round, !final);
-      walk_span<MODE, false, true>(mesh, p, slack, best, thr, off, third, st, sp);
+      walk_span<MODE, false, true, false, false, true>(mesh, p, slack, best, thr, off, third, st, sp, nullptr, &dq);
       if (sp.suspended) {
         emit_begin(em, split, round + 1u, packet, slot);
-        walk_span<MODE, false, false, true>(mesh, p, slack, best, thr, off, sp.resume_end, st, idle, &em);
+        walk_span<MODE, false, false, true, false, true>(mesh, p, slack, best, thr, off, sp.resume_end, st, idle, &em, &dq);
         emit_close(em);
       }
     }
+    defer_drain<MODE>(mesh, p, dq, best);
     // NaN never enters a minimum (fminf drops it), so the words stay ordered like non-negative floats
     if (__float_as_uint(best.d2) < d2_in) atomicMin(&acc[lane], __float_as_uint(best.d2));
     if (MODE == MODE_NORMAL_FOLD) {
@@ -2017,7 +2118,7 @@ void launch_packet(hipStream_t st, const DeviceMesh& mesh, const GridParams& g, 
                    uint32_t n_q, const uint32_t* plane, float* out, int* err, uint32_t n_packets,
                    const uint32_t* seed_in = nullptr, uint32_t seed_shift = 0, uint32_t seed_ny = 0,
                    uint32_t seed_nz = 0, const GridParams* seed_lattice = nullptr, CutList cut = {nullptr, 0, 0, 0, 0, nullptr},
-                   const PeerOut* peers_in = nullptr, const SplitCtl* split_in = nullptr) {
+                   const PeerOut* peers_in = nullptr, const SplitCtl* split_in = nullptr, bool defer = false) {
   PeerOut peers{};
   if (peers_in) peers = *peers_in;
   SplitCtl split{};
@@ -2026,6 +2127,12 @@ void launch_packet(hipStream_t st, const DeviceMesh& mesh, const GridParams& g, 
   const uint32_t grid_blocks = ((n_packets + per - 1) / per) * per;    // a whole number of runs per XCD (xcd_remap)
   if (mesh.stats != nullptr)   // M2S_STATS: the counting variant (a few SALU ops more per node); never suspended, so that a packet's counters are whole
     hipLaunchKernelGGL((k_packet<GRID, MODE, SIGN, true, false>), dim3(grid_blocks), dim3(64), 0, st, mesh, g,
+                       qs, perm, n_q, plane, out, err, n_packets, seed_in, seed_shift, seed_ny, seed_nz, seed_lattice, cut, peers, split);
+  else if (defer && GRID && MODE != MODE_NEAREST_NORMAL && split.cnt != nullptr)
+    hipLaunchKernelGGL((k_packet<GRID, MODE == MODE_NEAREST_NORMAL ? MODE_UNSIGNED : MODE, SIGN, false, GRID, true>), dim3(grid_blocks), dim3(64), 0, st, mesh, g,
+                       qs, perm, n_q, plane, out, err, n_packets, seed_in, seed_shift, seed_ny, seed_nz, seed_lattice, cut, peers, split);
+  else if (defer)
+    hipLaunchKernelGGL((k_packet<GRID, MODE, SIGN, false, false, true>), dim3(grid_blocks), dim3(64), 0, st, mesh, g,
                        qs, perm, n_q, plane, out, err, n_packets, seed_in, seed_shift, seed_ny, seed_nz, seed_lattice, cut, peers, split);
   else if (GRID && MODE != MODE_NEAREST_NORMAL && split.cnt != nullptr)
     hipLaunchKernelGGL((k_packet<GRID, MODE == MODE_NEAREST_NORMAL ? MODE_UNSIGNED : MODE, SIGN, false, GRID>), dim3(grid_blocks), dim3(64), 0, st, mesh, g,
@@ -2285,6 +2392,8 @@ int prepare_grid_walk(Arena& ws, hipStream_t st, const DeviceMesh& mesh, const G
     plan->split = sc;
     plan->split_forced = tn.split == 2;
   }
+  // dense exact evaluations (packet walk, unsigned distances): M2S_DEFER -1 automatic, 0 never, 1 always
+  plan->defer = tn.defer != 0;
   return 0;
 }
 
@@ -2364,15 +2473,15 @@ int launch_grid_walk(hipStream_t st, const DeviceMesh& mesh, const GridParams& g
   if (split) hipLaunchKernelGGL(k_split_init, dim3(1), dim3(64), 0, st, split->cnt, plan.split_forced ? 1u : 0u);
   if (mode == MODE_UNSIGNED && d_inside_plane) {
     if (brute) launch_brute<true, MODE_UNSIGNED, SIGN_GRID_PLANE>(st, mesh, g, nullptr, 0, d_inside_plane, d_out, d_err, packets, peers);
-    else launch_packet<true, MODE_UNSIGNED, SIGN_GRID_PLANE>(st, mesh, g, nullptr, nullptr, 0, d_inside_plane, d_out, d_err, packets, seed1, sh1, s1ny, s1nz, nullptr, cut, peers, split);
+    else launch_packet<true, MODE_UNSIGNED, SIGN_GRID_PLANE>(st, mesh, g, nullptr, nullptr, 0, d_inside_plane, d_out, d_err, packets, seed1, sh1, s1ny, s1nz, nullptr, cut, peers, split, plan.defer);
     if (split) launch_split_rounds<MODE_UNSIGNED, SIGN_GRID_PLANE>(st, mesh, g, d_inside_plane, d_out, d_err, *split, cut, peers);
   } else if (mode == MODE_UNSIGNED) {
     if (brute) launch_brute<true, MODE_UNSIGNED, SIGN_NONE>(st, mesh, g, nullptr, 0, nullptr, d_out, d_err, packets, peers);
-    else launch_packet<true, MODE_UNSIGNED, SIGN_NONE>(st, mesh, g, nullptr, nullptr, 0, nullptr, d_out, d_err, packets, seed1, sh1, s1ny, s1nz, nullptr, cut, peers, split);
+    else launch_packet<true, MODE_UNSIGNED, SIGN_NONE>(st, mesh, g, nullptr, nullptr, 0, nullptr, d_out, d_err, packets, seed1, sh1, s1ny, s1nz, nullptr, cut, peers, split, plan.defer);
     if (split) launch_split_rounds<MODE_UNSIGNED, SIGN_NONE>(st, mesh, g, nullptr, d_out, d_err, *split, cut, peers);
   } else {
     if (brute) launch_brute<true, MODE_NORMAL_FOLD, SIGN_NONE>(st, mesh, g, nullptr, 0, nullptr, d_out, d_err, packets, peers);
-    else launch_packet<true, MODE_NORMAL_FOLD, SIGN_NONE>(st, mesh, g, nullptr, nullptr, 0, nullptr, d_out, d_err, packets, seed1, sh1, s1ny, s1nz, nullptr, cut, peers, split);
+    else launch_packet<true, MODE_NORMAL_FOLD, SIGN_NONE>(st, mesh, g, nullptr, nullptr, 0, nullptr, d_out, d_err, packets, seed1, sh1, s1ny, s1nz, nullptr, cut, peers, split, plan.defer);
     if (split) launch_split_rounds<MODE_NORMAL_FOLD, SIGN_NONE>(st, mesh, g, nullptr, d_out, d_err, *split, cut, peers);
   }
   M2S_HIP_CHECK(hipGetLastError());
@@ -2637,10 +2746,10 @@ int launch_query_walk(Arena& ws, hipStream_t st, const DeviceMesh& mesh, const f
     M2S_HIP_CHECK(hipGetLastError());
     return 0;
   }
-  if (mode == MODE_UNSIGNED && sign_src == SIGN_RAYS3) launch_packet<false, MODE_UNSIGNED, SIGN_RAYS3>(st, mesh, g, sorted, perm, nq, table, d_out, d_err, launched, seeds, 0, 0, 0, d_lat, cut);
-  else if (mode == MODE_UNSIGNED) launch_packet<false, MODE_UNSIGNED, SIGN_NONE>(st, mesh, g, sorted, perm, nq, table, d_out, d_err, launched, seeds, 0, 0, 0, d_lat, cut);
-  else if (mode == MODE_NORMAL_FOLD) launch_packet<false, MODE_NORMAL_FOLD, SIGN_NONE>(st, mesh, g, sorted, perm, nq, table, d_out, d_err, launched, seeds, 0, 0, 0, d_lat, cut);
-  else launch_packet<false, MODE_NEAREST_NORMAL, SIGN_NONE>(st, mesh, g, sorted, perm, nq, table, d_out, d_err, launched, seeds, 0, 0, 0, d_lat, cut);
+  if (mode == MODE_UNSIGNED && sign_src == SIGN_RAYS3) launch_packet<false, MODE_UNSIGNED, SIGN_RAYS3>(st, mesh, g, sorted, perm, nq, table, d_out, d_err, launched, seeds, 0, 0, 0, d_lat, cut, nullptr, nullptr, tuning().defer != 0);
+  else if (mode == MODE_UNSIGNED) launch_packet<false, MODE_UNSIGNED, SIGN_NONE>(st, mesh, g, sorted, perm, nq, table, d_out, d_err, launched, seeds, 0, 0, 0, d_lat, cut, nullptr, nullptr, tuning().defer != 0);
+  else if (mode == MODE_NORMAL_FOLD) launch_packet<false, MODE_NORMAL_FOLD, SIGN_NONE>(st, mesh, g, sorted, perm, nq, table, d_out, d_err, launched, seeds, 0, 0, 0, d_lat, cut, nullptr, nullptr, tuning().defer != 0);
+  else launch_packet<false, MODE_NEAREST_NORMAL, SIGN_NONE>(st, mesh, g, sorted, perm, nq, table, d_out, d_err, launched, seeds, 0, 0, 0, d_lat, cut, nullptr, nullptr, tuning().defer != 0);
   M2S_HIP_CHECK(hipGetLastError());
   return 0;
 }

@@ -39,6 +39,7 @@ const Entry TABLE[] = {
     M2S_KNOB("M2S_SPLIT_MAX_RECORDS", K_U32, split_max_records),
     M2S_KNOB("M2S_SPLIT_ROUNDS", K_U32, split_rounds),
     M2S_KNOB("M2S_SPLIT_REPORT", K_INT, split_report),
+    M2S_KNOB("M2S_DEFER", K_INT, defer),
     M2S_KNOB("M2S_HOST_PIECE_MB", K_U32, host_piece_mb),
     M2S_KNOB("M2S_PUSH_PIECES", K_U32, push_pieces),
     M2S_KNOB("M2S_PUSH_BLOCKS", K_U32, push_blocks),
