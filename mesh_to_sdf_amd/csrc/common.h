@@ -262,7 +262,7 @@ struct GridWalkPlan {
   bool lane_walk = false;
   SplitCtl split;                  // packet walk only
   bool split_forced = false;       // M2S_SPLIT=2: the flags start raised (tests)
-  bool defer = false;              // packet walk: exact evaluations queued and run densely (distance.hip DeferQueue)
+  int defer = 0;                   // packet walk: 1 exact evaluations queued and run densely, 2 + direct where most lanes are reached (distance.hip DeferQueue)
   uint32_t* brute_acc = nullptr;   // tiny problems (grid_is_tiny): per-voxel minima of k_brute_split; no seeds, no lists, no tree
 };
 bool grid_is_tiny(const GridParams& g, size_t n_tris, int algorithm);

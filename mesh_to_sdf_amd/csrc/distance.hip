@@ -565,6 +565,12 @@ struct DeferLayout {
   static constexpr uint32_t SLOT_WORDS = MODE == MODE_NORMAL_FOLD ? 192u : MODE == MODE_NEAREST_NORMAL ? 128u : 64u;
   static constexpr uint32_t DWORDS = (128u + SLOT_WORDS) / 2u;     // the LDS block of one wave, in 8-byte words
 };
+// DEFER = 2: a triangle that DEFER_DIRECT_LANES or more lanes reach is evaluated wave-wide at once, as without the queue.  For grids
+// much finer than the mesh — 1024^3 over a flat 100 k-triangle sheet, 0.006 triangles per brick: far from the surface ONE triangle
+// is the nearest for most of a brick, 47 of 64 lanes per evaluation — the queue has nothing to compact (walk, direct / queued /
+// both: sheet-100k 1024^3 69.0 / 71.9 / 65.4 ms, blob-100k 1024^3 35.6 / 34.0 / 33.6).  Its own variant, because the second
+// evaluation body costs the dense regime 3 - 6 % by being there (128^3 x blob-100k 1.02 -> 1.09 ms, 256^3 1.74 -> 1.80).
+constexpr uint32_t DEFER_DIRECT_LANES = 48;
 struct DeferQueue {
   uint32_t* q;          // LDS: 128 pair words (ring), lane | triangle slot << 6
   uint32_t* slot;       // LDS: the running results of the 64 voxels (DeferLayout)
@@ -632,7 +638,7 @@ __device__ __forceinline__ void defer_drain(const DeviceMesh& mesh, f3 p, DeferQ
 // records and pre-test planes through scalar loads, a subtree left when no lane's bound reaches it.  BUDGET: the walk may stop
 // early (sp.suspended, off = the first record not yet looked at).  EMIT: a suspended walk — surviving subtrees of em.min_bytes ..
 // em.max_bytes are written to the next round's list instead of being entered.
-template <int MODE, bool STATS, bool BUDGET, bool EMIT = false, bool HANDOVER = false, bool DEFER = false>
+template <int MODE, bool STATS, bool BUDGET, bool EMIT = false, bool HANDOVER = false, int DEFER = 0>
 __device__ __forceinline__ void walk_span(const DeviceMesh& mesh, f3 p, float slack, Best<MODE>& best, float& thr, uint32_t& off,
                                           uint32_t end, WalkStats& st, SplitState& sp, EmitState* emp = nullptr, DeferQueue* dqp = nullptr) {
   // The walk addresses NodeExt by BYTE offset (its skip links are stored that way): the scalar loads then take
@@ -662,7 +668,7 @@ __device__ __forceinline__ void walk_span(const DeviceMesh& mesh, f3 p, float sl
         const unsigned long long rb = __ballot(reach);
         if (rb != 0ull) {   // some lane's bound reaches the triangle itself
           if (STATS) { ++st.leaf; st.pairs += (uint32_t)__popcll(rb); }
-          if (DEFER) {
+          if (DEFER != 0 && !(DEFER == 2 && (uint32_t)__popcll(rb) >= DEFER_DIRECT_LANES)) {
             DeferQueue& dq = *dqp;
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(rb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)rb, 0u));
             if (reach) dq.q[(dq.head + dq.n + rank) & 127u] = (threadIdx.x & 63u) | (((uint32_t)nr.tri + k) << 6);
@@ -756,7 +762,7 @@ __device__ __forceinline__ void store_grid_result(float* __restrict__ out, size_
 // the packet starts from a triangle near its own centre (jump-flooding seed pass below).
 // (eight waves per SIMD: the split variant's bookkeeping would otherwise take the kernel to 106 SGPRs — seven waves, - 12 %; the
 // compiler parks what does not fit in spare VGPR lanes)
-template <bool GRID, int MODE, int SIGN, bool STATS, bool SPLIT, bool DEFER = false>
+template <bool GRID, int MODE, int SIGN, bool STATS, bool SPLIT, int DEFER = 0>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_packet(DeviceMesh mesh, GridParams g, const float4* __restrict__ qsorted,
                                                const uint32_t* __restrict__ perm, uint32_t n_q,
                                                const uint32_t* __restrict__ plane, float* __restrict__ out,
@@ -997,16 +1003,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
       for (uint32_t range = third; range < n_ranges; ++range) {
         if (range != third) off = (uint32_t)__builtin_amdgcn_readlane((int)cut_off_v, (int)(1u + range));
         const uint32_t end = (uint32_t)__builtin_amdgcn_readlane((int)cut_end_v, (int)(1u + range));
-        walk_span<MODE, false, false, true, false, true>(mesh, p, slack, best, thr, off, end, st, idle, &em, &dq);
+        walk_span<MODE, false, false, true, false, 1>(mesh, p, slack, best, thr, off, end, st, idle, &em, &dq);
       }
       emit_close(em);
     } else {
       SplitState sp;
       split_arm(sp, split, round, !final);
-      walk_span<MODE, false, true, false, false, true>(mesh, p, slack, best, thr, off, third, st, sp, nullptr, &dq);
+      walk_span<MODE, false, true, false, false, 1>(mesh, p, slack, best, thr, off, third, st, sp, nullptr, &dq);
       if (sp.suspended) {
         emit_begin(em, split, round + 1u, packet, slot);
-        walk_span<MODE, false, false, true, false, true>(mesh, p, slack, best, thr, off, sp.resume_end, st, idle, &em, &dq);
+        walk_span<MODE, false, false, true, false, 1>(mesh, p, slack, best, thr, off, sp.resume_end, st, idle, &em, &dq);
         emit_close(em);
       }
     }
@@ -2118,7 +2124,7 @@ void launch_packet(hipStream_t st, const DeviceMesh& mesh, const GridParams& g, 
                    uint32_t n_q, const uint32_t* plane, float* out, int* err, uint32_t n_packets,
                    const uint32_t* seed_in = nullptr, uint32_t seed_shift = 0, uint32_t seed_ny = 0,
                    uint32_t seed_nz = 0, const GridParams* seed_lattice = nullptr, CutList cut = {nullptr, 0, 0, 0, 0, nullptr},
-                   const PeerOut* peers_in = nullptr, const SplitCtl* split_in = nullptr, bool defer = false) {
+                   const PeerOut* peers_in = nullptr, const SplitCtl* split_in = nullptr, int defer = 0) {
   PeerOut peers{};
   if (peers_in) peers = *peers_in;
   SplitCtl split{};
@@ -2129,10 +2135,13 @@ void launch_packet(hipStream_t st, const DeviceMesh& mesh, const GridParams& g, 
     hipLaunchKernelGGL((k_packet<GRID, MODE, SIGN, true, false>), dim3(grid_blocks), dim3(64), 0, st, mesh, g,
                        qs, perm, n_q, plane, out, err, n_packets, seed_in, seed_shift, seed_ny, seed_nz, seed_lattice, cut, peers, split);
   else if (defer && GRID && MODE != MODE_NEAREST_NORMAL && split.cnt != nullptr)
-    hipLaunchKernelGGL((k_packet<GRID, MODE == MODE_NEAREST_NORMAL ? MODE_UNSIGNED : MODE, SIGN, false, GRID, true>), dim3(grid_blocks), dim3(64), 0, st, mesh, g,
+    hipLaunchKernelGGL((k_packet<GRID, MODE == MODE_NEAREST_NORMAL ? MODE_UNSIGNED : MODE, SIGN, false, GRID, 1>), dim3(grid_blocks), dim3(64), 0, st, mesh, g,
+                       qs, perm, n_q, plane, out, err, n_packets, seed_in, seed_shift, seed_ny, seed_nz, seed_lattice, cut, peers, split);
+  else if (defer == 2 && GRID)
+    hipLaunchKernelGGL((k_packet<GRID, MODE, SIGN, false, false, GRID ? 2 : 1>), dim3(grid_blocks), dim3(64), 0, st, mesh, g,
                        qs, perm, n_q, plane, out, err, n_packets, seed_in, seed_shift, seed_ny, seed_nz, seed_lattice, cut, peers, split);
   else if (defer)
-    hipLaunchKernelGGL((k_packet<GRID, MODE, SIGN, false, false, true>), dim3(grid_blocks), dim3(64), 0, st, mesh, g,
+    hipLaunchKernelGGL((k_packet<GRID, MODE, SIGN, false, false, 1>), dim3(grid_blocks), dim3(64), 0, st, mesh, g,
                        qs, perm, n_q, plane, out, err, n_packets, seed_in, seed_shift, seed_ny, seed_nz, seed_lattice, cut, peers, split);
   else if (GRID && MODE != MODE_NEAREST_NORMAL && split.cnt != nullptr)
     hipLaunchKernelGGL((k_packet<GRID, MODE == MODE_NEAREST_NORMAL ? MODE_UNSIGNED : MODE, SIGN, false, GRID>), dim3(grid_blocks), dim3(64), 0, st, mesh, g,
@@ -2318,11 +2327,12 @@ int prepare_grid_walk(Arena& ws, hipStream_t st, const DeviceMesh& mesh, const G
   const int lane_env = tuning().lane_walk;   // -1 auto, 0 never, 1 always
   // measured crossover with the work-sharing lane walk (lane / packet walk, whole call, Raycast): blob-11k 32^3 0.77 / 0.86 ms, 48^3
   // 0.80 / 0.71; blob-100k 64^3 1.71 / 2.85, 96^3 2.19 / 2.12; blob-1M 128^3 8.8 / 12.1, 256^3 32.7 / 14.3: the lane walk wins while
-  // there are more than ~8 triangles per brick.  That is the packet walk WITHOUT the split walk (below), whose launch lasts as long as
-  // its heaviest packets; where those can be split — the launch must be deeper than the chip's wave slots for that — the packets
-  // win up to ~70 triangles per brick (lane walk / packets / packets split, whole call, tools/exp_lane_vs_split.py): blob-100k 88^3
-  // 1.97 / 2.17 / 1.41 ms; blob-1M 96^3 (72 per brick) 5.43 / 9.86 / 5.38, 112^3 7.52 / 11.6 / 6.94, 128^3 7.49 / 11.4 / 5.78,
-  // 192^3 15.1 / 10.7 / 7.60.
+  // there are more than ~8 triangles per brick.  (Round 4, with the packets' exact evaluations run densely — DeferQueue — the
+  // crossover is ~18: blob-100k 64^3, 24 per brick, 1.60 / 2.04; 80^3, 12.5, 1.79 / 1.67; blob-11k 32^3, 22, 0.73 / 0.67.)  That is the
+  // packet walk WITHOUT the split walk (below), whose launch lasts as long as its heaviest packets; where those can be split — the
+  // launch must be deeper than the chip's wave slots for that — the packets win beyond 70 triangles per brick (lane walk / packets /
+  // packets split, whole call, tools/exp_lane_vs_split.py, profiles/r04_lane_vs_split.txt): blob-100k 88^3 1.99 / 1.61 / 1.14 ms;
+  // blob-1M 96^3 (72 per brick) 5.44 / 8.41 / 4.68, 128^3 7.53 / 9.43 / 4.95, 192^3 15.1 / 8.49 / 6.39.
   const Tuning& tn = tuning();
   const double real_bricks = (double)bricks_along(g.xe - g.xb, g.bl[0]) * bricks_along(g.n[1], g.bl[1]) * bricks_along(g.n[2], g.bl[2]);
   const double grid_bricks = (double)bricks_along(g.n[0], g.bl[0]) * bricks_along(g.n[1], g.bl[1]) * bricks_along(g.n[2], g.bl[2]);
@@ -2393,7 +2403,8 @@ int prepare_grid_walk(Arena& ws, hipStream_t st, const DeviceMesh& mesh, const G
     plan->split_forced = tn.split == 2;
   }
   // dense exact evaluations (packet walk, unsigned distances): M2S_DEFER -1 automatic, 0 never, 1 always
-  plan->defer = tn.defer != 0;
+  // 1: queued, 2: queued, but direct where most of the wave is reached (grids much finer than the mesh: see DEFER_DIRECT_LANES)
+  plan->defer = tn.defer == 0 ? 0 : tn.defer > 0 ? tn.defer : ((double)mesh.n_tris < 0.02 * grid_bricks ? 2 : 1);
   return 0;
 }
 
@@ -2746,10 +2757,10 @@ int launch_query_walk(Arena& ws, hipStream_t st, const DeviceMesh& mesh, const f
     M2S_HIP_CHECK(hipGetLastError());
     return 0;
   }
-  if (mode == MODE_UNSIGNED && sign_src == SIGN_RAYS3) launch_packet<false, MODE_UNSIGNED, SIGN_RAYS3>(st, mesh, g, sorted, perm, nq, table, d_out, d_err, launched, seeds, 0, 0, 0, d_lat, cut, nullptr, nullptr, tuning().defer != 0);
-  else if (mode == MODE_UNSIGNED) launch_packet<false, MODE_UNSIGNED, SIGN_NONE>(st, mesh, g, sorted, perm, nq, table, d_out, d_err, launched, seeds, 0, 0, 0, d_lat, cut, nullptr, nullptr, tuning().defer != 0);
-  else if (mode == MODE_NORMAL_FOLD) launch_packet<false, MODE_NORMAL_FOLD, SIGN_NONE>(st, mesh, g, sorted, perm, nq, table, d_out, d_err, launched, seeds, 0, 0, 0, d_lat, cut, nullptr, nullptr, tuning().defer != 0);
-  else launch_packet<false, MODE_NEAREST_NORMAL, SIGN_NONE>(st, mesh, g, sorted, perm, nq, table, d_out, d_err, launched, seeds, 0, 0, 0, d_lat, cut, nullptr, nullptr, tuning().defer != 0);
+  if (mode == MODE_UNSIGNED && sign_src == SIGN_RAYS3) launch_packet<false, MODE_UNSIGNED, SIGN_RAYS3>(st, mesh, g, sorted, perm, nq, table, d_out, d_err, launched, seeds, 0, 0, 0, d_lat, cut, nullptr, nullptr, tuning().defer != 0 ? 1 : 0);
+  else if (mode == MODE_UNSIGNED) launch_packet<false, MODE_UNSIGNED, SIGN_NONE>(st, mesh, g, sorted, perm, nq, table, d_out, d_err, launched, seeds, 0, 0, 0, d_lat, cut, nullptr, nullptr, tuning().defer != 0 ? 1 : 0);
+  else if (mode == MODE_NORMAL_FOLD) launch_packet<false, MODE_NORMAL_FOLD, SIGN_NONE>(st, mesh, g, sorted, perm, nq, table, d_out, d_err, launched, seeds, 0, 0, 0, d_lat, cut, nullptr, nullptr, tuning().defer != 0 ? 1 : 0);
+  else launch_packet<false, MODE_NEAREST_NORMAL, SIGN_NONE>(st, mesh, g, sorted, perm, nq, table, d_out, d_err, launched, seeds, 0, 0, 0, d_lat, cut, nullptr, nullptr, tuning().defer != 0 ? 1 : 0);
   M2S_HIP_CHECK(hipGetLastError());
   return 0;
 }

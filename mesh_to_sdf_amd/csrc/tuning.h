@@ -16,8 +16,8 @@ struct Tuning {
   int host_times = 0;               // M2S_HOST_TIMES   1: where the host time of a call goes, on stderr
   // ---- which walk (tests force each flavour; the defaults are measured crossovers, distance.hip)
   int lane_walk = -1;               // M2S_LANE_WALK    -1 automatic, 0 never, 1 always: one voxel / query per lane instead of one packet per wave
-  double lane_ratio = 8.0;          // M2S_LANE_RATIO   grid: lane walk above this many triangles per packet brick
-  double lane_ratio_split = 70.0;   // M2S_LANE_RATIO_SPLIT   ... and above this many where the packet walk's stragglers can be split (below)
+  double lane_ratio = 18.0;         // M2S_LANE_RATIO   grid: lane walk above this many triangles per packet brick
+  double lane_ratio_split = 100.0;  // M2S_LANE_RATIO_SPLIT   ... and above this many where the packet walk's stragglers can be split (below)
   double query_lane_coeff = 3500.0; // M2S_QUERY_LANE_COEFF   queries: lane walk below coeff * T^0.55 queries
   double brute_max = -1.0;          // M2S_BRUTE_MAX    tree-less path for cells x triangles (queries x triangles) up to this; < 0: automatic, 0: never
   uint32_t cut_min_packets = 100000;// M2S_CUT_MIN_PACKETS   grid: cut lists from this many packets on
@@ -35,7 +35,7 @@ struct Tuning {
   uint32_t split_max_records = 128; // M2S_SPLIT_MAX_RECORDS  ... and at most this many (larger ones it opens itself)
   uint32_t split_rounds = 2;        // M2S_SPLIT_ROUNDS follow-up launches: the continuations of the suspended packets, then their subtrees (with more rounds, subtrees may be suspended in their turn; the last round walks to the end)
   int split_report = 0;             // M2S_SPLIT_REPORT 1: suspended packets and items per round of every grid walk, on stderr (synchronises)
-  int defer = -1;                   // M2S_DEFER        -1 automatic, 0 never, 1 always: the packet walk queues (voxel, triangle) pairs and evaluates them 64 at a time
+  int defer = -1;                   // M2S_DEFER        -1 automatic, 0 never, 1 the packet walk queues (voxel, triangle) pairs and evaluates them 64 at a time, 2 + wave-wide at once where >= 48 lanes are reached
   // ---- host-pointer calls and peer delivery
   uint32_t host_piece_mb = 32;      // M2S_HOST_PIECE_MB   x-pieces of the result streamed to the host while the next is walked
   uint32_t push_pieces = 4;         // M2S_PUSH_PIECES     x-pieces of a slab pushed to the peers while the next is walked

@@ -9,6 +9,7 @@ from mesh_to_sdf_amd import Grid, M2STimings, SignMethod, Topology, _lib, genera
 cases = (("blob-100k", (96, 128, 160, 192, 256, 384, 512)), ("blob-1M", (128, 192, 256, 512)), ("blob-11k", (64, 96, 128, 256)))
 if len(sys.argv) > 1:
     cases = ((sys.argv[1], tuple(int(c) for c in sys.argv[2:])),)
+sign = SignMethod.Normal if os.environ.get("SIGN") == "Normal" else SignMethod.Raycast
 for mesh, sizes in cases:
     v, idx = meshes.blob(80, 71) if mesh == "blob-11k" else meshes.named(mesh)
     lo, hi = meshes.extended_bbox(v, 0.1)
@@ -17,14 +18,14 @@ for mesh, sizes in cases:
     for n in sizes:
         grid = Grid.from_bounding_box(lo, hi, [n, n, n])
         out = torch.empty(n ** 3, dtype=torch.float32, device="cuda")
-        line = f"{mesh} {n:>4}^3 ({idx.size // 3 / (n / 4) ** 3:6.2f} triangles per brick) Raycast:"
+        line = f"{mesh} {n:>4}^3 ({idx.size // 3 / (n / 4) ** 3:6.2f} triangles per brick) {sign.name}:"
         ref = None
         for name, kn in (("packets", {"M2S_LANE_WALK": 0, "M2S_DEFER": 0}), ("packets, dense evaluations", {"M2S_LANE_WALK": 0, "M2S_DEFER": 1}), ("automatic", {})):
             with _lib.knobs(**kn):
                 best = None
                 for _ in range(7):
                     t = M2STimings()
-                    generate_grid_sdf(dv, topo, grid, SignMethod.Raycast, out=out, timings=t)
+                    generate_grid_sdf(dv, topo, grid, sign, out=out, timings=t)
                     if best is None or t.distance_ms < best.distance_ms:
                         best = t
             if ref is None:
