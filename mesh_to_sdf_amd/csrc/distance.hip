@@ -314,6 +314,62 @@ __device__ __forceinline__ uint32_t stab_count(const DeviceMesh& mesh, f3 p) {
   return count;
 }
 
+// The same count with the ray-triangle tests run densely (cf. DeferQueue below): the packet's 64 sorted queries are neighbours, not
+// a brick — a leaf triangle's padded box is met by a few lanes' rays, and its test (box, 18 + ~40 instructions) ran wave-wide for
+// them.  Here a leaf queues (lane, triangle) for the lanes whose ray meets the leaf's box, 64 pairs are tested at a time (each lane
+// one pair: the owner's point by lane permutes, the corners by a gather), and a hit bumps the owner's LDS counter.  Same candidates
+// per lane (a lane whose ray misses the leaf's box cannot meet a triangle's box inside it), same test: the same count.
+// `lds`: 192 words of this wave's.
+template <int AXIS>
+__device__ __forceinline__ uint32_t stab_count_dense(const DeviceMesh& mesh, f3 p, uint32_t* lds) {
+  const uint32_t lane = threadIdx.x & 63u;
+  uint32_t* q = lds;
+  uint32_t* hits = lds + 128;
+  uint32_t head = 0, n = 0;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  hits[lane] = 0u;
+  auto flush = [&]() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const uint32_t take = min(n, 64u);
+    const bool valid = lane < take;
+    const uint32_t e = valid ? q[(head + lane) & 127u] : 0u;
+    const uint32_t v = e & 63u, vi = 3u * (e >> 6);
+    const f3 pv = mk3(__shfl(p.x, (int)v), __shfl(p.y, (int)v), __shfl(p.z, (int)v));
+    const float4 c0 = mesh.corners[vi], c1 = mesh.corners[vi + 1u], c2 = mesh.corners[vi + 2u];
+    const f3 a = mk3(c0.x, c0.y, c0.z), b = mk3(c0.w, c1.x, c1.y), c = mk3(c1.z, c1.w, c2.x);
+    f3 mn, mx;
+    triangle_bounding_box(a, b, c, &mn, &mx);     // the candidate rule is per triangle: ITS padded box
+    float t;
+    const bool h = ray_meets_box<AXIS>(pv, mn, mx) & ray_triangle_aligned<AXIS>(pv, a, b, c, &t);
+    if (valid & h) atomicAdd(&hits[v], 1u);
+    head = (head + take) & 127u;
+    n -= take;
+  };
+  uint32_t node = 0;
+  while (node < mesh.n_nodes) {
+    node = __builtin_amdgcn_readfirstlane(node);
+    const NodeRec nr = record_at(mesh.nodes, node);
+    const bool hit = ray_meets_box<AXIS>(p, mk3(nr.mnx, nr.mny, nr.mnz), mk3(nr.mxx, nr.mxy, nr.mxz));
+    const unsigned long long hb = __ballot(hit);
+    if (hb == 0ull) { node = nr.skip; continue; }
+    if (nr.tri >= 0) {
+      const uint32_t cnt = (nr.skip - node + 1u) >> 1;
+      const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(hb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hb, 0u));
+      for (uint32_t k = 0; k < cnt; ++k) {
+        if (hit) q[(head + n + rank) & 127u] = lane | (((uint32_t)nr.tri + k) << 6);
+        n += (uint32_t)__popcll(hb);
+        if (n >= 64u) flush();
+      }
+      node = nr.skip;
+    } else {
+      node = node + 1;
+    }
+  }
+  while (n != 0u) flush();
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  return hits[lane];
+}
+
 // ---- cut lists ------------------------------------------------------------------------------
 // A third of a packet's node tests fall on nodes much larger than the packet (512^3 x blob-100k: 46 of 158 on nodes
 // wider than 28 voxels, 69 on nodes wider than 14), and neighbouring packets repeat them with the same outcome.
@@ -938,9 +994,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
       // best of three (bvh.rs:131-141, rtree_bvh.rs:161-171): where the +X and +Y parities agree they ARE the majority, so the +Z
       // walk only runs for a packet in which some lane's first two rays disagree (never, for a watertight mesh, but for rays
       // through an edge; 10 M queries x blob-100k: a third of the 2 ms of stabbing).  The vote's result is the same.
-      const uint32_t cx = stab_count<0>(mesh, p), cy = stab_count<1>(mesh, p);
+      __shared__ uint32_t ray_lds[DEFER != 0 ? 192 : 1];
+      const uint32_t cx = DEFER != 0 ? stab_count_dense<0>(mesh, p, ray_lds) : stab_count<0>(mesh, p);
+      const uint32_t cy = DEFER != 0 ? stab_count_dense<1>(mesh, p, ray_lds) : stab_count<1>(mesh, p);
       uint32_t cz = cx;
-      if (__ballot(((cx ^ cy) & 1u) != 0u) != 0ull) cz = stab_count<2>(mesh, p);
+      if (__ballot(((cx ^ cy) & 1u) != 0u) != 0ull) cz = DEFER != 0 ? stab_count_dense<2>(mesh, p, ray_lds) : stab_count<2>(mesh, p);
       negate = ((cx & 1u) + (cy & 1u) + (cz & 1u)) > 1u;
     }
   }
