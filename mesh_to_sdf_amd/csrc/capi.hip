@@ -336,6 +336,9 @@ static int stats_end(hipStream_t stream, const unsigned long long* d_stats) {
           h[3], h[0] / w, h[1] / w, h[2] / w, h[4] / w, h[5] / w, h[6] / w);
   fprintf(stderr, "[m2s stats]   longest packet: %llu node tests, %llu exact triangle tests (the launch cannot end before its chain does); most work units in one packet %llu, mean %.1f\n", h[72], h[73], h[74],
           (h[0] + h[1] + 4.0 * h[2]) / w);
+  if (h[0] && h[1] && h[2])
+    fprintf(stderr, "[m2s stats]   lanes served: %.1f of 64 want the node per node test, %.1f reach the leaf per pre-test, %.1f reach the triangle per exact evaluation (queued pairs per packet: %.0f)\n",
+            (double)h[75] / h[0], (double)h[76] / h[1], (double)h[77] / h[2], (double)h[77] / w);
   {  // work units (node tests + pre-tests + 4 x exact evaluations) per packet, in octaves
     char line[512] = "";
     for (int o = 0; o < 24; ++o)

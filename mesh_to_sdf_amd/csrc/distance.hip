@@ -451,6 +451,7 @@ __device__ __forceinline__ uint32_t query_lattice_cell(const GridParams& L, floa
 // Wave-uniform counters of one packet's walk (SGPRs; only the M2S_STATS variant keeps them).
 struct WalkStats {
   uint32_t box = 0, ext = 0, leaf = 0, pruned = 0, slab = 0, sphere = 0, pairs = 0;
+  uint32_t node_lanes = 0, pre_lanes = 0;   // lanes whose bound reaches the node / that take part in a leaf's pre-test by that measure
 };
 
 // ---- split walk -------------------------------------------------------------------------------
@@ -705,6 +706,7 @@ __device__ __forceinline__ void walk_span(const DeviceMesh& mesh, f3 p, float sl
     const NodeExt nr = record_at_bytes<NodeExt>(mesh.ext, off);
     if (STATS) ++st.box;
     const float ed2 = ext_dist2(p, nr);
+    if (STATS) st.node_lanes += (uint32_t)__popcll(__ballot(!(ed2 > thr)));
     if (STATS && __ballot(!(ed2 > thr)) == 0ull) {
       ++st.pruned;
       const float vx = p.x - nr.cx, vy = p.y - nr.cy, vz = p.z - nr.cz;
@@ -718,7 +720,7 @@ __device__ __forceinline__ void walk_span(const DeviceMesh& mesh, f3 p, float sl
     if (nr.tri >= 0) {
       const uint32_t cnt = (nr.skip - off + NB) / (2u * NB);    // triangles of this (possibly collapsed) leaf
       for (uint32_t k = 0; k < cnt; ++k) {
-        if (STATS) ++st.ext;
+        if (STATS) { ++st.ext; st.pre_lanes += (uint32_t)__popcll(__ballot(!(ed2 > thr))); }
         const TriPlanes tp = record_at(mesh.planes, (uint32_t)nr.tri + k);   // scalar: small, needed for every leaf triangle
         const bool reach = !(planes_dist2(p, tp) > thr);
         const unsigned long long rb = __ballot(reach);
@@ -971,6 +973,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     atomicMax(&mesh.stats[72], (unsigned long long)st.box);
     atomicMax(&mesh.stats[73], (unsigned long long)st.leaf);
     atomicMax(&mesh.stats[74], (unsigned long long)(st.box + st.ext + 4u * st.leaf));
+    atomicAdd(&mesh.stats[75], (unsigned long long)st.node_lanes);
+    atomicAdd(&mesh.stats[76], (unsigned long long)st.pre_lanes);
+    atomicAdd(&mesh.stats[77], (unsigned long long)st.pairs);
     unsigned long long* q = mesh.stats + 8 + 8 * st_band;
     atomicAdd(&q[0], (unsigned long long)st.box);
     atomicAdd(&q[1], (unsigned long long)st.ext);
