@@ -2197,7 +2197,7 @@ void launch_packet(hipStream_t st, const DeviceMesh& mesh, const GridParams& g, 
   if (mesh.stats != nullptr)   // M2S_STATS: the counting variant (a few SALU ops more per node); never suspended, so that a packet's counters are whole
     hipLaunchKernelGGL((k_packet<GRID, MODE, SIGN, true, false>), dim3(grid_blocks), dim3(64), 0, st, mesh, g,
                        qs, perm, n_q, plane, out, err, n_packets, seed_in, seed_shift, seed_ny, seed_nz, seed_lattice, cut, peers, split);
-  else if (defer && GRID && MODE != MODE_NEAREST_NORMAL && split.cnt != nullptr)
+  else if (GRID && MODE != MODE_NEAREST_NORMAL && split.cnt != nullptr)   // (a split walk always queues its evaluations: the follow-up rounds do)
     hipLaunchKernelGGL((k_packet<GRID, MODE == MODE_NEAREST_NORMAL ? MODE_UNSIGNED : MODE, SIGN, false, GRID, 1>), dim3(grid_blocks), dim3(64), 0, st, mesh, g,
                        qs, perm, n_q, plane, out, err, n_packets, seed_in, seed_shift, seed_ny, seed_nz, seed_lattice, cut, peers, split);
   else if (defer == 2 && GRID)
@@ -2205,9 +2205,6 @@ void launch_packet(hipStream_t st, const DeviceMesh& mesh, const GridParams& g, 
                        qs, perm, n_q, plane, out, err, n_packets, seed_in, seed_shift, seed_ny, seed_nz, seed_lattice, cut, peers, split);
   else if (defer)
     hipLaunchKernelGGL((k_packet<GRID, MODE, SIGN, false, false, 1>), dim3(grid_blocks), dim3(64), 0, st, mesh, g,
-                       qs, perm, n_q, plane, out, err, n_packets, seed_in, seed_shift, seed_ny, seed_nz, seed_lattice, cut, peers, split);
-  else if (GRID && MODE != MODE_NEAREST_NORMAL && split.cnt != nullptr)
-    hipLaunchKernelGGL((k_packet<GRID, MODE == MODE_NEAREST_NORMAL ? MODE_UNSIGNED : MODE, SIGN, false, GRID>), dim3(grid_blocks), dim3(64), 0, st, mesh, g,
                        qs, perm, n_q, plane, out, err, n_packets, seed_in, seed_shift, seed_ny, seed_nz, seed_lattice, cut, peers, split);
   else
     hipLaunchKernelGGL((k_packet<GRID, MODE, SIGN, false, false>), dim3(grid_blocks), dim3(64), 0, st, mesh, g,
@@ -2844,10 +2841,12 @@ void warm_distance(hipStream_t st) {
   hipLaunchKernelGGL(k_warm_distance, dim3(1), dim3(64), 0, st);
   // ... and resolves a kernel FUNCTION at its own first launch (~0.3 ms each): ask for the attributes of the ones a first call uses
   const void* fns[] = {
-      (const void*)k_packet<true, MODE_UNSIGNED, SIGN_GRID_PLANE, false, true>,
-      (const void*)k_packet<true, MODE_NORMAL_FOLD, SIGN_NONE, false, true>,
-      (const void*)k_packet<false, MODE_UNSIGNED, SIGN_RAYS3, false, false>,
-      (const void*)k_packet<false, MODE_NEAREST_NORMAL, SIGN_NONE, false, false>,
+      (const void*)k_packet<true, MODE_UNSIGNED, SIGN_GRID_PLANE, false, false, 1>,
+      (const void*)k_packet<true, MODE_UNSIGNED, SIGN_GRID_PLANE, false, true, 1>,
+      (const void*)k_packet<true, MODE_NORMAL_FOLD, SIGN_NONE, false, false, 1>,
+      (const void*)k_packet<true, MODE_NORMAL_FOLD, SIGN_NONE, false, true, 1>,
+      (const void*)k_packet<false, MODE_UNSIGNED, SIGN_RAYS3, false, false, 1>,
+      (const void*)k_packet<false, MODE_NEAREST_NORMAL, SIGN_NONE, false, false, 1>,
       (const void*)k_split_init,
       (const void*)k_split_round<MODE_UNSIGNED>,
       (const void*)k_split_round<MODE_NORMAL_FOLD>,
@@ -2859,7 +2858,7 @@ void warm_distance(hipStream_t st) {
       (const void*)k_lane_q<MODE_UNSIGNED, SIGN_RAYS3>,
       (const void*)k_jfa_splat,
       (const void*)k_jfa_load,
-      (const void*)k_jfa_pass,
+      (const void*)k_jfa_pass32,
       (const void*)k_seed_remap,
       (const void*)k_qbounds,
       (const void*)k_qbounds_final,

@@ -11,7 +11,11 @@ from mesh_to_sdf_amd import AccelerationMethod, Grid, SignMethod, Topology, _lib
 MODES = {"default": {}, "packet + cut lists": {"M2S_CUT_MIN_PACKETS": 8, "M2S_QUERY_CUT_MIN": 1, "M2S_LANE_WALK": 0, "M2S_BRUTE_MAX": 0, "M2S_SPLIT": 0},
          "packet + split": {"M2S_LANE_WALK": 0, "M2S_BRUTE_MAX": 0, "M2S_SPLIT": 2, "M2S_SPLIT_BUDGET": 40, },
          "packet + cut lists + split": {"M2S_CUT_MIN_PACKETS": 8, "M2S_QUERY_CUT_MIN": 1, "M2S_LANE_WALK": 0, "M2S_BRUTE_MAX": 0, "M2S_SPLIT": 2, "M2S_SPLIT_BUDGET": 60},
-         "lane walk": {"M2S_LANE_WALK": 1, "M2S_BRUTE_MAX": 0}}
+         "lane walk": {"M2S_LANE_WALK": 1, "M2S_BRUTE_MAX": 0},
+         # the packet walk's exact evaluations: wave-wide at once (round 3), and queued + direct (the default form is queued)
+         "packet, direct evaluations": {"M2S_LANE_WALK": 0, "M2S_BRUTE_MAX": 0, "M2S_DEFER": 0},
+         "packet + cut lists + split, queued + direct evaluations": {"M2S_CUT_MIN_PACKETS": 8, "M2S_QUERY_CUT_MIN": 1, "M2S_LANE_WALK": 0, "M2S_BRUTE_MAX": 0, "M2S_SPLIT": 2,
+                                                                     "M2S_SPLIT_BUDGET": 60, "M2S_DEFER": 2}}
 
 
 def with_mode(env, fn):
