@@ -900,7 +900,10 @@ int build_device_mesh(Arena& ws, hipStream_t st, const float* d_verts, size_t n_
   const unsigned B = 256;
   // triangles per collapsed leaf: 2 is the optimum of every BASELINE config (round 3, blob-1M in 512^3: 1 / 2 / 3 / 4 / 6 / 8 -> 27.1 / 25.2 /
   // 25.5 / 26.1 / 27.2 / 29.0 ms of walk); coarse grids over fine meshes would take 4 - 8 for 5 - 10 %, but a persistent mesh has no grid
-  constexpr uint32_t leaf_max = 2;
+#ifndef M2S_LEAF_MAX
+#define M2S_LEAF_MAX 2
+#endif
+  constexpr uint32_t leaf_max = M2S_LEAF_MAX;
   hipLaunchKernelGGL(k_tri_setup, dim3(cdiv(n_tris, B)), dim3(B), 0, st, d_verts, (uint32_t)n_verts, d_indices,
                      index_bytes, topology, (uint32_t)n_tris, raw, boxes, cen_raw, scene, 8, d_err);
   if (records_only) {

@@ -620,7 +620,7 @@ __device__ __forceinline__ void emit_reserve(EmitState& em) {
 template <int MODE>
 struct DeferLayout {
   static constexpr uint32_t SLOT_WORDS = MODE == MODE_NORMAL_FOLD ? 192u : MODE == MODE_NEAREST_NORMAL ? 128u : 64u;
-  static constexpr uint32_t DWORDS = (128u + SLOT_WORDS) / 2u;     // the LDS block of one wave, in 8-byte words
+  static constexpr uint32_t DWORDS = (256u + SLOT_WORDS) / 2u;     // the LDS block of one wave, in 8-byte words: two rings + the slots
 };
 // DEFER = 2: a triangle that DEFER_DIRECT_LANES or more lanes reach is evaluated wave-wide at once, as without the queue.  For grids
 // much finer than the mesh — 1024^3 over a flat 100 k-triangle sheet, 0.006 triangles per brick: far from the surface ONE triangle
@@ -629,9 +629,11 @@ struct DeferLayout {
 // evaluation body costs the dense regime 3 - 6 % by being there (128^3 x blob-100k 1.02 -> 1.09 ms, 256^3 1.74 -> 1.80).
 constexpr uint32_t DEFER_DIRECT_LANES = 48;
 struct DeferQueue {
-  uint32_t* q;          // LDS: 128 pair words (ring), lane | triangle slot << 6
+  uint32_t* q;          // LDS: 128 pair words (ring), lane | triangle slot << 6: pairs that passed the pre-test
   uint32_t* slot;       // LDS: the running results of the 64 voxels (DeferLayout)
   uint32_t head, n;     // wave-uniform
+  uint32_t* q1;         // LDS: 128 pair words (ring): pairs whose lane's bound reaches the LEAF, waiting for the pre-test (DEFER = 3)
+  uint32_t head1, n1;
 };
 __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -645,7 +647,7 @@ __device__ __forceinline__ unsigned long long defer_key(const Best<MODE>& x) {
 template <int MODE>
 __device__ __forceinline__ DeferQueue defer_begin(unsigned long long* lds) {
   const uint32_t lane = threadIdx.x & 63u;
-  DeferQueue dq = {reinterpret_cast<uint32_t*>(lds), reinterpret_cast<uint32_t*>(lds) + 128, 0u, 0u};
+  DeferQueue dq = {reinterpret_cast<uint32_t*>(lds), reinterpret_cast<uint32_t*>(lds) + 256, 0u, 0u, reinterpret_cast<uint32_t*>(lds) + 128, 0u, 0u};
   if (MODE == MODE_NEAREST_NORMAL) reinterpret_cast<unsigned long long*>(dq.slot)[lane] = 0x7f800000ffffffffull;   // (+inf, none)
   else {
     dq.slot[lane] = 0x7f800000u;
@@ -686,8 +688,36 @@ __device__ __forceinline__ void defer_flush(const DeviceMesh& mesh, f3 p, DeferQ
     if (MODE == MODE_NORMAL_FOLD) { best.d2pos = fminf(best.d2pos, __uint_as_float(dq.slot[64u + lane])); best.nan |= dq.slot[128u + lane] != 0u; }
   }
 }
+// DEFER = 3: the leaf pre-test run densely too.  It costs the wave its 20 instructions (and a 64-byte scalar load) per leaf triangle
+// for the 11 (128^3 x blob-100k) ... 30 (headline) of 64 lanes whose bound reaches the leaf at all — the node test has just said
+// which.  Those lanes are queued per leaf triangle (first ring), 64 such pairs are pre-tested at a time — the owner's point and bound
+// by lane permutes, the planes by a gather — and the ones that pass move on to the second ring, the exact evaluations' (above).
+// Returns true if that ring was flushed (the lanes' bounds have moved).
 template <int MODE>
-__device__ __forceinline__ void defer_drain(const DeviceMesh& mesh, f3 p, DeferQueue& dq, Best<MODE>& best) {
+__device__ __forceinline__ bool defer_pretest(const DeviceMesh& mesh, f3 p, float thr, DeferQueue& dq, Best<MODE>& best) {
+  const uint32_t lane = threadIdx.x & 63u;
+  wave_lds_sync();
+  const uint32_t take = min(dq.n1, 64u);
+  const bool valid = lane < take;
+  const uint32_t e = valid ? dq.q1[(dq.head1 + lane) & 127u] : 0u;
+  const uint32_t v = e & 63u, t = e >> 6;
+  const f3 pv = mk3(__shfl(p.x, (int)v), __shfl(p.y, (int)v), __shfl(p.z, (int)v));
+  const float tv = __shfl(thr, (int)v);
+  const bool pass = valid & !(planes_dist2(pv, mesh.planes[t]) > tv);
+  dq.head1 = (dq.head1 + take) & 127u;
+  dq.n1 -= take;
+  const unsigned long long rb = __ballot(pass);
+  if (rb == 0ull) return false;
+  const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(rb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)rb, 0u));
+  if (pass) dq.q[(dq.head + dq.n + rank) & 127u] = e;
+  dq.n += (uint32_t)__popcll(rb);
+  if (dq.n < 64u) return false;
+  defer_flush<MODE>(mesh, p, dq, best);
+  return true;
+}
+template <int MODE>
+__device__ __forceinline__ void defer_drain(const DeviceMesh& mesh, f3 p, float slack, DeferQueue& dq, Best<MODE>& best) {
+  while (dq.n1 != 0u) defer_pretest<MODE>(mesh, p, prune_bound(best.d2, slack), dq, best);
   while (dq.n != 0u) defer_flush<MODE>(mesh, p, dq, best);
 }
 
@@ -719,6 +749,21 @@ __device__ __forceinline__ void walk_span(const DeviceMesh& mesh, f3 p, float sl
     if (__ballot(!(ed2 > thr)) == 0ull) { off = nr.skip; continue; }   // a NaN bound keeps the node
     if (nr.tri >= 0) {
       const uint32_t cnt = (nr.skip - off + NB) / (2u * NB);    // triangles of this (possibly collapsed) leaf
+      if (DEFER == 3) {
+        DeferQueue& dq = *dqp;
+        const bool want = !(ed2 > thr);
+        const unsigned long long wb = __ballot(want);
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(wb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)wb, 0u));
+        const uint32_t wn = (uint32_t)__popcll(wb);
+        for (uint32_t k = 0; k < cnt; ++k) {
+          if (want) dq.q1[(dq.head1 + dq.n1 + rank) & 127u] = (threadIdx.x & 63u) | (((uint32_t)nr.tri + k) << 6);
+          dq.n1 += wn;
+          if (dq.n1 >= 64u) {
+            if (BUDGET && M2S_SPLIT_DEBUG >= 2) sp.units += 4u;
+            if (defer_pretest<MODE>(mesh, p, thr, dq, best)) thr = prune_bound(best.d2, slack);
+          }
+        }
+      } else
       for (uint32_t k = 0; k < cnt; ++k) {
         if (STATS) { ++st.ext; st.pre_lanes += (uint32_t)__popcll(__ballot(!(ed2 > thr))); }
         const TriPlanes tp = record_at(mesh.planes, (uint32_t)nr.tri + k);   // scalar: small, needed for every leaf triangle
@@ -953,7 +998,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
         if (STATS) st_rbytes += end - off;
         walk_span<MODE, STATS, SPLIT, false, SPLIT, DEFER>(mesh, p, slack, best, thr, off, end, st, sp, nullptr, &dq);
       }
-      if (DEFER) defer_drain<MODE>(mesh, p, dq, best);   // what is still queued (a suspended packet hands over complete minima)
+      if (DEFER) defer_drain<MODE>(mesh, p, slack, dq, best);   // what is still queued (a suspended packet hands over complete minima)
       if (SPLIT && sp.suspended && M2S_SPLIT_DEBUG >= 4) {
         // (range has been stepped once more by the loop's increment)
         if (!split_handover<MODE>(split, packet, range - 1u, off, best, err)) atomicOr(err, ERRF_SPLIT_OVERFLOW);   // cannot happen: a slot per packet
@@ -1066,20 +1111,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
       for (uint32_t range = third; range < n_ranges; ++range) {
         if (range != third) off = (uint32_t)__builtin_amdgcn_readlane((int)cut_off_v, (int)(1u + range));
         const uint32_t end = (uint32_t)__builtin_amdgcn_readlane((int)cut_end_v, (int)(1u + range));
-        walk_span<MODE, false, false, true, false, 1>(mesh, p, slack, best, thr, off, end, st, idle, &em, &dq);
+        walk_span<MODE, false, false, true, false, 3>(mesh, p, slack, best, thr, off, end, st, idle, &em, &dq);
       }
       emit_close(em);
     } else {
       SplitState sp;
       split_arm(sp, split, round, !final);
-      walk_span<MODE, false, true, false, false, 1>(mesh, p, slack, best, thr, off, third, st, sp, nullptr, &dq);
+      walk_span<MODE, false, true, false, false, 3>(mesh, p, slack, best, thr, off, third, st, sp, nullptr, &dq);
       if (sp.suspended) {
         emit_begin(em, split, round + 1u, packet, slot);
-        walk_span<MODE, false, false, true, false, 1>(mesh, p, slack, best, thr, off, sp.resume_end, st, idle, &em, &dq);
+        walk_span<MODE, false, false, true, false, 3>(mesh, p, slack, best, thr, off, sp.resume_end, st, idle, &em, &dq);
         emit_close(em);
       }
     }
-    defer_drain<MODE>(mesh, p, dq, best);
+    defer_drain<MODE>(mesh, p, slack, dq, best);
     // NaN never enters a minimum (fminf drops it), so the words stay ordered like non-negative floats
     if (__float_as_uint(best.d2) < d2_in) atomicMin(&acc[lane], __float_as_uint(best.d2));
     if (MODE == MODE_NORMAL_FOLD) {
@@ -2197,6 +2242,12 @@ void launch_packet(hipStream_t st, const DeviceMesh& mesh, const GridParams& g, 
   if (mesh.stats != nullptr)   // M2S_STATS: the counting variant (a few SALU ops more per node); never suspended, so that a packet's counters are whole
     hipLaunchKernelGGL((k_packet<GRID, MODE, SIGN, true, false>), dim3(grid_blocks), dim3(64), 0, st, mesh, g,
                        qs, perm, n_q, plane, out, err, n_packets, seed_in, seed_shift, seed_ny, seed_nz, seed_lattice, cut, peers, split);
+  else if (defer == 3 && GRID && MODE != MODE_NEAREST_NORMAL && split.cnt != nullptr)
+    hipLaunchKernelGGL((k_packet<GRID, MODE == MODE_NEAREST_NORMAL ? MODE_UNSIGNED : MODE, SIGN, false, GRID, GRID ? 3 : 1>), dim3(grid_blocks), dim3(64), 0, st, mesh, g,
+                       qs, perm, n_q, plane, out, err, n_packets, seed_in, seed_shift, seed_ny, seed_nz, seed_lattice, cut, peers, split);
+  else if (defer == 3)
+    hipLaunchKernelGGL((k_packet<GRID, MODE, SIGN, false, false, 3>), dim3(grid_blocks), dim3(64), 0, st, mesh, g,
+                       qs, perm, n_q, plane, out, err, n_packets, seed_in, seed_shift, seed_ny, seed_nz, seed_lattice, cut, peers, split);
   else if (GRID && MODE != MODE_NEAREST_NORMAL && split.cnt != nullptr)   // (a split walk always queues its evaluations: the follow-up rounds do)
     hipLaunchKernelGGL((k_packet<GRID, MODE == MODE_NEAREST_NORMAL ? MODE_UNSIGNED : MODE, SIGN, false, GRID, 1>), dim3(grid_blocks), dim3(64), 0, st, mesh, g,
                        qs, perm, n_q, plane, out, err, n_packets, seed_in, seed_shift, seed_ny, seed_nz, seed_lattice, cut, peers, split);
@@ -2464,7 +2515,11 @@ int prepare_grid_walk(Arena& ws, hipStream_t st, const DeviceMesh& mesh, const G
   }
   // dense exact evaluations (packet walk, unsigned distances): M2S_DEFER -1 automatic, 0 never, 1 always
   // 1: queued, 2: queued, but direct where most of the wave is reached (grids much finer than the mesh: see DEFER_DIRECT_LANES)
-  plan->defer = tn.defer == 0 ? 0 : tn.defer > 0 ? tn.defer : ((double)mesh.n_tris < 0.02 * grid_bricks ? 2 : 1);
+  // 3: the pre-tests queued too (defer_pretest) — from 0.045 triangles per brick on: walk, queued evaluations / + queued pre-tests, blob-100k
+  // 128^3 1.02 / 0.83 ms, 256^3 1.74 / 1.48, 512^3 (0.048 per brick) 6.85 / 6.54, 768^3 (0.014) 16.9 / 17.7; blob-1M 512^3 21.9 / 18.2; blob-11k
+  // 256^3 (0.04) 0.60 / 0.63; sheet-100k 512^3 (0.05) 13.2 / 12.0.  (Both forms of pre-test in one kernel, chosen per leaf by the number of lanes that
+  // want it, cost the dense regime what they gained the sparse one: 128^3 0.83 -> 0.92, 768^3 17.7 -> 16.9.)
+  plan->defer = tn.defer == 0 ? 0 : tn.defer > 0 ? tn.defer : ((double)mesh.n_tris < 0.02 * grid_bricks ? 2 : (double)mesh.n_tris < 0.045 * grid_bricks ? 1 : 3);
   return 0;
 }
 
@@ -2817,10 +2872,10 @@ int launch_query_walk(Arena& ws, hipStream_t st, const DeviceMesh& mesh, const f
     M2S_HIP_CHECK(hipGetLastError());
     return 0;
   }
-  if (mode == MODE_UNSIGNED && sign_src == SIGN_RAYS3) launch_packet<false, MODE_UNSIGNED, SIGN_RAYS3>(st, mesh, g, sorted, perm, nq, table, d_out, d_err, launched, seeds, 0, 0, 0, d_lat, cut, nullptr, nullptr, tuning().defer != 0 ? 1 : 0);
-  else if (mode == MODE_UNSIGNED) launch_packet<false, MODE_UNSIGNED, SIGN_NONE>(st, mesh, g, sorted, perm, nq, table, d_out, d_err, launched, seeds, 0, 0, 0, d_lat, cut, nullptr, nullptr, tuning().defer != 0 ? 1 : 0);
-  else if (mode == MODE_NORMAL_FOLD) launch_packet<false, MODE_NORMAL_FOLD, SIGN_NONE>(st, mesh, g, sorted, perm, nq, table, d_out, d_err, launched, seeds, 0, 0, 0, d_lat, cut, nullptr, nullptr, tuning().defer != 0 ? 1 : 0);
-  else launch_packet<false, MODE_NEAREST_NORMAL, SIGN_NONE>(st, mesh, g, sorted, perm, nq, table, d_out, d_err, launched, seeds, 0, 0, 0, d_lat, cut, nullptr, nullptr, tuning().defer != 0 ? 1 : 0);
+  if (mode == MODE_UNSIGNED && sign_src == SIGN_RAYS3) launch_packet<false, MODE_UNSIGNED, SIGN_RAYS3>(st, mesh, g, sorted, perm, nq, table, d_out, d_err, launched, seeds, 0, 0, 0, d_lat, cut, nullptr, nullptr, tuning().defer == 0 ? 0 : tuning().defer == 1 ? 1 : 3);
+  else if (mode == MODE_UNSIGNED) launch_packet<false, MODE_UNSIGNED, SIGN_NONE>(st, mesh, g, sorted, perm, nq, table, d_out, d_err, launched, seeds, 0, 0, 0, d_lat, cut, nullptr, nullptr, tuning().defer == 0 ? 0 : tuning().defer == 1 ? 1 : 3);
+  else if (mode == MODE_NORMAL_FOLD) launch_packet<false, MODE_NORMAL_FOLD, SIGN_NONE>(st, mesh, g, sorted, perm, nq, table, d_out, d_err, launched, seeds, 0, 0, 0, d_lat, cut, nullptr, nullptr, tuning().defer == 0 ? 0 : tuning().defer == 1 ? 1 : 3);
+  else launch_packet<false, MODE_NEAREST_NORMAL, SIGN_NONE>(st, mesh, g, sorted, perm, nq, table, d_out, d_err, launched, seeds, 0, 0, 0, d_lat, cut, nullptr, nullptr, tuning().defer == 0 ? 0 : tuning().defer == 1 ? 1 : 3);
   M2S_HIP_CHECK(hipGetLastError());
   return 0;
 }

@@ -35,7 +35,7 @@ struct Tuning {
   uint32_t split_max_records = 128; // M2S_SPLIT_MAX_RECORDS  ... and at most this many (larger ones it opens itself)
   uint32_t split_rounds = 2;        // M2S_SPLIT_ROUNDS follow-up launches: the continuations of the suspended packets, then their subtrees (with more rounds, subtrees may be suspended in their turn; the last round walks to the end)
   int split_report = 0;             // M2S_SPLIT_REPORT 1: suspended packets and items per round of every grid walk, on stderr (synchronises)
-  int defer = -1;                   // M2S_DEFER        -1 automatic, 0 never, 1 the packet walk queues (voxel, triangle) pairs and evaluates them 64 at a time, 2 + wave-wide at once where >= 48 lanes are reached
+  int defer = -1;                   // M2S_DEFER        the packet walk's leaf work: -1 automatic (by triangles per brick: 2 / 1 / 3), 0 wave-wide at once, 1 exact evaluations queued as (voxel, triangle) pairs and run 64 at a time, 2 + wave-wide where >= 48 lanes are reached, 3 the pre-tests queued too
   // ---- host-pointer calls and peer delivery
   uint32_t host_piece_mb = 32;      // M2S_HOST_PIECE_MB   x-pieces of the result streamed to the host while the next is walked
   uint32_t push_pieces = 4;         // M2S_PUSH_PIECES     x-pieces of a slab pushed to the peers while the next is walked

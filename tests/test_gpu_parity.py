@@ -19,16 +19,16 @@ F = np.float32
 TOL = 1e-5  # north_star tolerance (absolute, f32 distances); signs must match exactly
 
 
-@pytest.fixture(autouse=True, params=["default", "cut lists on every grid", "lane walks", "split walks", "direct evaluations", "queued + direct evaluations"])
+@pytest.fixture(autouse=True, params=["default", "cut lists on every grid", "lane walks", "split walks", "direct evaluations", "queued evaluations", "queued + direct evaluations"])
 def cut_lists_mode(request):
     """The cut lists (k_cut) are used from 100 000 packets per launch upwards and the packet walk of generic queries from a
     few million queries; the second run of every test lowers the thresholds and forces the packet walks, so that the nasty
     small inputs below (degenerate, non-finite, huge, anisotropic, sliced, duplicated) meet packets and cut lists too; the third
     run forces the lane walks (k_lane, k_lane_q) on everything that is small enough for them to be quick.  In the default run
-    the tiny grids (cells x triangles <= M2S_BRUTE_MAX) take the tree-less k_brute_split.  The packet walks queue their exact
-    evaluations as (voxel, triangle) pairs and run them 64 at a time (distance.hip DeferQueue; the default): the last two runs force
-    the other two forms, every reached triangle wave-wide at once (round 3's walk, and the one M2S_STATS counts) and the mixed form of
-    grids far finer than the mesh."""
+    the tiny grids (cells x triangles <= M2S_BRUTE_MAX) take the tree-less k_brute_split.  The packet walks queue their leaf
+    pre-tests and their exact evaluations as (voxel, triangle) pairs and run them 64 at a time (distance.hip DeferQueue; what these
+    small inputs take by default): the last three runs force the other forms — every reached triangle wave-wide at once (round 3's
+    walk, and the one M2S_STATS counts), only the evaluations queued, and the mixed form of grids far finer than the mesh."""
     import os
 
     mode = request.param
@@ -41,7 +41,7 @@ def cut_lists_mode(request):
         pytest.skip("a report against minutes of CPU propagation: once is enough (the kernels' modes are covered by the other tests)")
     if mode == "lane walks" and big:
         pytest.skip("the lane walk is not meant for this size")
-    if mode in ("direct evaluations", "queued + direct evaluations") and big and "512" not in request.node.name:
+    if mode in ("direct evaluations", "queued evaluations", "queued + direct evaluations") and big and "512" not in request.node.name:
         pytest.skip("the evaluation forms differ per packet, not per size: the small inputs and one large grid cover them")
     if mode == "split walks" and big:
         pytest.skip("a budget of 24 work units is for small inputs (test_split_walk_* covers the large ones with realistic budgets)")
@@ -57,6 +57,8 @@ def cut_lists_mode(request):
         forced = {"M2S_SPLIT": 2, "M2S_SPLIT_BUDGET": 24, "M2S_SPLIT_MIN_RECORDS": 4, "M2S_SPLIT_MAX_RECORDS": 64, "M2S_SPLIT_ROUNDS": 3, "M2S_LANE_WALK": 0, "M2S_BRUTE_MAX": 0}
     elif mode == "direct evaluations":
         forced = {"M2S_DEFER": 0, "M2S_LANE_WALK": 0, "M2S_BRUTE_MAX": 0}
+    elif mode == "queued evaluations":
+        forced = {"M2S_DEFER": 1, "M2S_LANE_WALK": 0, "M2S_BRUTE_MAX": 0}
     elif mode == "queued + direct evaluations":
         forced = {"M2S_DEFER": 2, "M2S_LANE_WALK": 0, "M2S_BRUTE_MAX": 0}
     with _lib.knobs(**forced):

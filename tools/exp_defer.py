@@ -20,7 +20,7 @@ for mesh, sizes in cases:
         out = torch.empty(n ** 3, dtype=torch.float32, device="cuda")
         line = f"{mesh} {n:>4}^3 ({idx.size // 3 / (n / 4) ** 3:6.2f} triangles per brick) {sign.name}:"
         ref = None
-        for name, kn in (("packets", {"M2S_LANE_WALK": 0, "M2S_DEFER": 0}), ("packets, dense evaluations", {"M2S_LANE_WALK": 0, "M2S_DEFER": 1}), ("automatic", {})):
+        for name, kn in (("packets", {"M2S_LANE_WALK": 0, "M2S_DEFER": 0}), ("packets, dense evaluations", {"M2S_LANE_WALK": 0, "M2S_DEFER": 1}), ("packets, dense pre-tests and evaluations", {"M2S_LANE_WALK": 0, "M2S_DEFER": 3}), ("automatic", {})):
             with _lib.knobs(**kn):
                 best = None
                 for _ in range(7):

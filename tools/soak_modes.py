@@ -12,8 +12,10 @@ MODES = {"default": {}, "packet + cut lists": {"M2S_CUT_MIN_PACKETS": 8, "M2S_QU
          "packet + split": {"M2S_LANE_WALK": 0, "M2S_BRUTE_MAX": 0, "M2S_SPLIT": 2, "M2S_SPLIT_BUDGET": 40, },
          "packet + cut lists + split": {"M2S_CUT_MIN_PACKETS": 8, "M2S_QUERY_CUT_MIN": 1, "M2S_LANE_WALK": 0, "M2S_BRUTE_MAX": 0, "M2S_SPLIT": 2, "M2S_SPLIT_BUDGET": 60},
          "lane walk": {"M2S_LANE_WALK": 1, "M2S_BRUTE_MAX": 0},
-         # the packet walk's exact evaluations: wave-wide at once (round 3), and queued + direct (the default form is queued)
+         # the packet walk's pre-tests and exact evaluations: wave-wide at once (round 3), evaluations queued, both queued, queued + direct
          "packet, direct evaluations": {"M2S_LANE_WALK": 0, "M2S_BRUTE_MAX": 0, "M2S_DEFER": 0},
+         "packet, queued evaluations": {"M2S_LANE_WALK": 0, "M2S_BRUTE_MAX": 0, "M2S_DEFER": 1},
+         "packet + cut lists, queued pre-tests and evaluations": {"M2S_CUT_MIN_PACKETS": 8, "M2S_QUERY_CUT_MIN": 1, "M2S_LANE_WALK": 0, "M2S_BRUTE_MAX": 0, "M2S_SPLIT": 0, "M2S_DEFER": 3},
          "packet + cut lists + split, queued + direct evaluations": {"M2S_CUT_MIN_PACKETS": 8, "M2S_QUERY_CUT_MIN": 1, "M2S_LANE_WALK": 0, "M2S_BRUTE_MAX": 0, "M2S_SPLIT": 2,
                                                                      "M2S_SPLIT_BUDGET": 60, "M2S_DEFER": 2}}
 
