@@ -846,7 +846,7 @@ size_t bvh_workspace_bytes(size_t n_tris) {
 
 int build_device_mesh(Arena& ws, hipStream_t st, const float* d_verts, size_t n_verts, const void* d_indices,
                       size_t n_indices, int index_bytes, int topology, size_t n_tris, int* d_err, DeviceMesh* out,
-                      const std::function<int(const float4*, const TriRec*, int)>* after_setup, bool records_only) {
+                      const std::function<int(const float4*, const TriRec*, int)>* after_setup, bool records_only, uint32_t leaf_max) {
   (void)n_indices;
   out->cen_raw = nullptr;
   out->slot_of = nullptr;
@@ -858,6 +858,7 @@ int build_device_mesh(Arena& ws, hipStream_t st, const float* d_verts, size_t n_
   out->ext = nullptr;
   out->stats = nullptr;
   out->scene = nullptr;
+  out->leaf_max = 2;
   if (n_tris > (1u << 25)) {   // the walks address 96-byte records through 32-bit byte offsets
     set_error("mesh has %zu triangles; this build handles up to 33 554 432", n_tris);
     return M2S_ERR_BAD_ARG;
@@ -900,10 +901,10 @@ int build_device_mesh(Arena& ws, hipStream_t st, const float* d_verts, size_t n_
   const unsigned B = 256;
   // triangles per collapsed leaf: 2 is the optimum of every BASELINE config (round 3, blob-1M in 512^3: 1 / 2 / 3 / 4 / 6 / 8 -> 27.1 / 25.2 /
   // 25.5 / 26.1 / 27.2 / 29.0 ms of walk); coarse grids over fine meshes would take 4 - 8 for 5 - 10 %, but a persistent mesh has no grid
-#ifndef M2S_LEAF_MAX
-#define M2S_LEAF_MAX 2
-#endif
-  constexpr uint32_t leaf_max = M2S_LEAF_MAX;
+  // (round 4: with the leaf work queued and run densely — distance.hip DeferQueue — a grid coarse against the mesh takes 4 or 8: the caller's
+  // `leaf_max`, grid_leaf_max)
+  leaf_max = std::min(std::max(leaf_max, 1u), 16u);
+  out->leaf_max = leaf_max;
   hipLaunchKernelGGL(k_tri_setup, dim3(cdiv(n_tris, B)), dim3(B), 0, st, d_verts, (uint32_t)n_verts, d_indices,
                      index_bytes, topology, (uint32_t)n_tris, raw, boxes, cen_raw, scene, 8, d_err);
   if (records_only) {

@@ -89,6 +89,7 @@ struct DeviceMesh {
   unsigned long long* stats;  // optional traversal counters (M2S_STATS=1), else nullptr
   uint32_t n_tris;
   uint32_t n_nodes;
+  uint32_t leaf_max;    // subtrees of at most this many triangles are walked as one leaf (2: persistent meshes; a one-shot grid call chooses by its grid, grid_leaf_max)
   const int* scene;     // 6 order-encoded ints: min xyz / max xyz of the triangle box centres (see bvh.hip)
 };
 
@@ -226,7 +227,9 @@ size_t bvh_workspace_bytes(size_t n_tris);
 // (enqueue the side work — the seed passes — on another stream behind that event; bvh.hip says why there).
 int build_device_mesh(Arena& ws, hipStream_t st, const float* d_verts, size_t n_verts, const void* d_indices,
                       size_t n_indices, int index_bytes, int topology, size_t n_tris, int* d_err, DeviceMesh* out,
-                      const std::function<int(const float4*, const TriRec*, int)>* after_setup = nullptr, bool records_only = false);
+                      const std::function<int(const float4*, const TriRec*, int)>* after_setup = nullptr, bool records_only = false,
+                      uint32_t leaf_max = 2);
+uint32_t grid_leaf_max(const GridParams& g, size_t n_tris);   // distance.hip: the leaf size a one-shot grid call builds its tree with
 
 // sign.hip: grid-line ray parity -> one "inside" bit per voxel (bit plane in grid layout).
 size_t sign_workspace_bytes(const GridParams& g, size_t n_tris);

@@ -2450,10 +2450,17 @@ int prepare_grid_walk(Arena& ws, hipStream_t st, const DeviceMesh& mesh, const G
   const bool split_possible = !brute && mesh.n_nodes != 0 && tn.split != 0 && mesh.stats == nullptr && packets <= SPLIT_MAX_PACKETS;
   // (automatic: a launch at least 1.25 x the chip's 8 192 wave slots deep, padding of the launch order not counted — the patience is measured from the time it takes to hand
   // the packets out, and a launch that is resident at once has none: blob-100k 80^3, 8 000 packets, 2.33 -> 3.77 ms, blob-11k 64^3
-  // 0.54 -> 1.46 — and from 0.45 triangles per packet brick of the WHOLE grid on, see below)
-  const bool split_auto = split_possible && tn.split < 0 && real_bricks >= 10240.0 && (double)mesh.n_tris >= 0.45 * grid_bricks;
+  // 0.54 -> 1.46)
+  // With the leaf work queued and leaves of 4 - 8 triangles on coarse grids (end of round 4) the walks are two to three times shorter and
+  // their tails with them, and the follow-up rounds' ~0.1 ms only pay on large meshes in coarse grids (walk without / with: blob-1M 112^3 2.80 /
+  // 2.55 ms, 128^3 2.72 / 2.12, 160^3 2.54 / 2.40, 192^3 3.16 / 3.06, 256^3 4.79 / 4.98; blob-100k 96^3 0.57 / 0.55, 112^3 0.59 / 0.75, 128^3
+  // 0.55 / 0.63, 160^3 0.86 / 0.80, 256^3 1.59 / 1.55; the 64-layer slabs of 512^3 x blob-1M 2.44 ... 2.99 / 2.57 ... 2.89): automatic from
+  // 300 000 triangles and 5 per brick of the whole grid on.
+  const bool split_auto = split_possible && tn.split < 0 && real_bricks >= 10240.0 && mesh.n_tris >= 300000u && (double)mesh.n_tris >= 5.0 * grid_bricks;
   const double lane_ratio = split_auto ? tn.lane_ratio_split : tn.lane_ratio;
-  const bool lane_walk = !brute && mesh.n_tris && (lane_env >= 0 ? lane_env == 1 : (double)mesh.n_tris > lane_ratio * real_bricks);
+  // (a tree with larger leaves — a one-shot call over a coarse grid, grid_leaf_max — is built for the packets: blob-100k 32^3, 195 triangles per
+  // brick, lane walk over leaves of 2 / packets over leaves of 8: 1.68 / 1.67 ms, 48^3 1.74 / 1.18; blob-1M 48^3 5.23 / 4.83, 80^3 5.41 / 4.62)
+  const bool lane_walk = !brute && mesh.n_tris && (lane_env >= 0 ? lane_env == 1 : (mesh.leaf_max <= 2u && (double)mesh.n_tris > lane_ratio * real_bricks));
   // cut lists: the top of the tree is walked once per block of 2^log bricks per axis (k_cut)
   CutList cut = {nullptr, 0, 0, 0, 0, nullptr};
   // k_cut costs about 0.25 us per brick plus a latency floor of ~0.1 ms; measured crossover (blob-100k / blob-6k,
@@ -2654,6 +2661,20 @@ void cut_word_roundtrip(uint32_t n_nodes, uint32_t start, uint32_t len, uint32_t
 // never).  Measured (tools/exp_small_queries.py, whole one-shot calls, all pairs / build + walk): 11 k triangles x 1 ... 1 000 queries
 // 0.085 - 0.15 / 0.25 - 0.70 ms, x 10 000 0.47 (0.83 with rays) / 0.55 (0.66); 100 k triangles x 64 0.13 - 0.22 / 1.0 - 1.3 ms, x 1 000
 // 0.46 (0.81) / 0.74 (0.94), x 10 000 3.2 (5.8) / 0.9 (1.0): 240 G pairs/s for the distance alone, 135 G with the rays.
+// The leaf size of a one-shot grid call's tree (M2S_LEAF_MAX overrides).  A larger leaf trades node tests for leaf pre-tests; with
+// those queued per (voxel, triangle) pair the optimum moved up wherever a brick meets more than a triangle or so (walk, leaves of 2 / 4 /
+// 8, tools/exp_lane_vs_split.py with M2S_LEAF_MAX): blob-100k 64^3 (24 triangles per brick) 1.15 / 0.79 / 0.59 ms, 96^3 (7.2, split) 0.69 /
+// 0.57 / 0.54, 128^3 (3.05) 0.87 / 0.74 / -; blob-1M 128^3 (30, split) 2.89 / 2.33 / 2.11, 256^3 (3.8) 6.10 / 5.22 / -; blob-11k 64^3 (2.7) 0.25 /
+// 0.21 / 0.20, 96^3 (0.8) 0.22 / 0.20 / 0.21; blob-100k 256^3 (0.38) 1.55 / 1.52 / -, 512^3 (0.048) 6.48 / 7.88 / -.  Persistent meshes
+// have no grid to go by and keep 2.
+uint32_t grid_leaf_max(const GridParams& g, size_t n_tris) {
+  const Tuning& tn = tuning();
+  if (tn.leaf_max != 0) return tn.leaf_max;
+  const double bricks = (double)bricks_along(g.n[0], g.bl[0]) * bricks_along(g.n[1], g.bl[1]) * bricks_along(g.n[2], g.bl[2]);
+  const double per_brick = (double)n_tris / std::max(1.0, bricks);
+  return per_brick >= 40.0 ? 16u : per_brick >= 3.0 ? 8u : per_brick >= 0.6 ? 4u : 2u;   // (16: blob-100k 32^3, 195 per brick, 1.31 -> 1.11 ms; blob-1M 80^3 3.14 -> 2.53)
+}
+
 bool query_is_tiny(size_t n_q, size_t n_tris, int algorithm, int sign_src) {
   if (algorithm != 0 || n_tris == 0 || n_q == 0 || sign_src == SIGN_XRAY_ALL) return false;
   const double limit = tuning().brute_max >= 0.0 ? tuning().brute_max : (sign_src == SIGN_RAYS3 ? 6.0e7 : 1.2e8);

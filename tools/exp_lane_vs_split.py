@@ -6,7 +6,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from mesh_to_sdf_amd import Grid, M2STimings, SignMethod, Topology, _lib, generate_grid_sdf, meshes
 
-for mesh, sizes in (("blob-100k", (64, 80, 88, 96, 112)), ("blob-1M", (96, 112, 128, 160, 192, 224)), ("blob-11k", (32, 40, 48, 56, 64, 96))):
+CASES = (("blob-100k", (24, 32, 48, 64)), ("blob-1M", (48, 64, 80)), ("blob-11k", (12, 16, 24, 32))) if os.environ.get("DENSE") else None
+for mesh, sizes in CASES or (("blob-100k", (64, 80, 88, 96, 112)), ("blob-1M", (96, 112, 128, 160, 192, 224)), ("blob-11k", (32, 40, 48, 56, 64, 96))):
     v, idx = meshes.blob(80, 71) if mesh == "blob-11k" else meshes.named(mesh)
     lo, hi = meshes.extended_bbox(v, 0.1)
     dv = torch.as_tensor(v, device="cuda")

@@ -11,10 +11,11 @@ from mesh_to_sdf_amd import AccelerationMethod, Grid, SignMethod, Topology, _lib
 MODES = {"default": {}, "packet + cut lists": {"M2S_CUT_MIN_PACKETS": 8, "M2S_QUERY_CUT_MIN": 1, "M2S_LANE_WALK": 0, "M2S_BRUTE_MAX": 0, "M2S_SPLIT": 0},
          "packet + split": {"M2S_LANE_WALK": 0, "M2S_BRUTE_MAX": 0, "M2S_SPLIT": 2, "M2S_SPLIT_BUDGET": 40, },
          "packet + cut lists + split": {"M2S_CUT_MIN_PACKETS": 8, "M2S_QUERY_CUT_MIN": 1, "M2S_LANE_WALK": 0, "M2S_BRUTE_MAX": 0, "M2S_SPLIT": 2, "M2S_SPLIT_BUDGET": 60},
-         "lane walk": {"M2S_LANE_WALK": 1, "M2S_BRUTE_MAX": 0},
+         "lane walk": {"M2S_LANE_WALK": 1, "M2S_BRUTE_MAX": 0, "M2S_LEAF_MAX": 2},
          # the packet walk's pre-tests and exact evaluations: wave-wide at once (round 3), evaluations queued, both queued, queued + direct
          "packet, direct evaluations": {"M2S_LANE_WALK": 0, "M2S_BRUTE_MAX": 0, "M2S_DEFER": 0},
-         "packet, queued evaluations": {"M2S_LANE_WALK": 0, "M2S_BRUTE_MAX": 0, "M2S_DEFER": 1},
+         "packet, queued evaluations, leaves of 2": {"M2S_LANE_WALK": 0, "M2S_BRUTE_MAX": 0, "M2S_DEFER": 1, "M2S_LEAF_MAX": 2},
+         "packet, leaves of 16": {"M2S_LANE_WALK": 0, "M2S_BRUTE_MAX": 0, "M2S_LEAF_MAX": 16},
          "packet + cut lists, queued pre-tests and evaluations": {"M2S_CUT_MIN_PACKETS": 8, "M2S_QUERY_CUT_MIN": 1, "M2S_LANE_WALK": 0, "M2S_BRUTE_MAX": 0, "M2S_SPLIT": 0, "M2S_DEFER": 3},
          "packet + cut lists + split, queued + direct evaluations": {"M2S_CUT_MIN_PACKETS": 8, "M2S_QUERY_CUT_MIN": 1, "M2S_LANE_WALK": 0, "M2S_BRUTE_MAX": 0, "M2S_SPLIT": 2,
                                                                      "M2S_SPLIT_BUDGET": 60, "M2S_DEFER": 2}}
