@@ -859,6 +859,7 @@ int build_device_mesh(Arena& ws, hipStream_t st, const float* d_verts, size_t n_
   out->stats = nullptr;
   out->scene = nullptr;
   out->leaf_max = 2;
+  out->slot_first = nullptr;
   if (n_tris > (1u << 25)) {   // the walks address 96-byte records through 32-bit byte offsets
     set_error("mesh has %zu triangles; this build handles up to 33 554 432", n_tris);
     return M2S_ERR_BAD_ARG;
@@ -960,12 +961,32 @@ int build_device_mesh(Arena& ws, hipStream_t st, const float* d_verts, size_t n_
                      (uint32_t)(2 * n_tris - 1), ext);
   M2S_HIP_CHECK(hipGetLastError());
   out->tris = tris;
+  out->slot_first = slot_first;
   out->corners = corners;
   out->cen = cen;
   out->planes = planes;
   out->nodes = nodes;
   out->ext = ext;
   out->scene = scene;
+  return 0;
+}
+
+__global__ __launch_bounds__(256) void k_releaf(NodeRec* __restrict__ nodes, NodeExt* __restrict__ ext, const uint32_t* __restrict__ slot_first,
+                                                uint32_t n_nodes, uint32_t leaf_max) {
+  const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+  if (slot >= n_nodes) return;
+  const uint32_t cnt = (nodes[slot].skip - slot + 1u) >> 1;
+  const int tri = cnt <= leaf_max ? (int)slot_first[slot] : -1;
+  nodes[slot].tri = tri;
+  ext[slot].tri = tri;
+}
+int set_leaf_size(hipStream_t st, DeviceMesh* mesh, uint32_t leaf_max) {
+  leaf_max = std::min(std::max(leaf_max, 1u), 16u);
+  if (mesh->n_nodes == 0 || mesh->slot_first == nullptr || mesh->leaf_max == leaf_max) return 0;
+  hipLaunchKernelGGL(k_releaf, dim3(cdiv(mesh->n_nodes, 256)), dim3(256), 0, st, const_cast<NodeRec*>(mesh->nodes), const_cast<NodeExt*>(mesh->ext),
+                     mesh->slot_first, mesh->n_nodes, leaf_max);
+  M2S_HIP_CHECK(hipGetLastError());
+  mesh->leaf_max = leaf_max;
   return 0;
 }
 

@@ -818,6 +818,10 @@ struct m2s_mesh {
   uint32_t acc_launches = 0;
   int* d_err_async = nullptr;     // device error word of asynchronous calls (inside `mem`), read by m2s_mesh_drain_timings
   bool async_readers = false;     // asynchronous walks may still be reading the sign planes
+  // walks of the tree that a later call cannot see as finished: asynchronous ones (until m2s_mesh_drain_timings) and ones on another stream
+  bool tree_async = false;
+  hipStream_t tree_stream = nullptr;
+  bool tree_used = false;
 };
 
 // Folds the finished entries of m->pending into the accumulators and recycles their events.
@@ -1396,6 +1400,19 @@ int m2s_mesh_generate_grid_sdf(m2s_mesh* m, const m2s_grid* grid, int sign_metho
   M2S_HIP_CHECK(hipEventRecord(st->ev[1], c.stream));
   st->planes_done = nullptr;
   st->have_raw_seeds = false;
+  {
+    // The leaf size this grid's walks want (grid_leaf_max: leaves of 4 - 16 triangles where a brick meets several): the resident tree is
+    // re-marked when it differs — one 5 us launch; walks that are not ordered before this stream must have finished first.
+    const uint32_t want = grid_leaf_max(g, m->n_tris);
+    if (want != m->dm.leaf_max) {
+      if (m->tree_async || (m->tree_used && m->tree_stream != c.stream)) { M2S_HIP_CHECK(hipDeviceSynchronize()); m->tree_async = false; }
+      rc = set_leaf_size(c.stream, &m->dm, want);
+      if (rc) return rc;
+    }
+    m->tree_stream = c.stream;
+    m->tree_used = true;
+    if (!c.sync) m->tree_async = true;
+  }
   bool built_planes = false;
   const uint32_t* plane = nullptr;
   if (sign_method == M2S_SIGN_RAYCAST) {
@@ -1548,6 +1565,10 @@ int m2s_mesh_generate_sdf(m2s_mesh* m, const float* queries, size_t n_queries, i
   M2S_HIP_CHECK(hipEventRecord(st->ev[0], c.stream));
   M2S_HIP_CHECK(hipEventRecord(st->ev[1], c.stream));
   M2S_HIP_CHECK(hipEventRecord(st->ev[2], c.stream));
+  if (m->tree_used && m->tree_stream != c.stream) m->tree_async = true;   // (a later re-marking of the leaves must not overtake this walk: set_leaf_size)
+  m->tree_stream = c.stream;
+  m->tree_used = true;
+  if (!c.sync) m->tree_async = true;
   rc = launch_query_distance(ws, c.stream, m->dm, d_q, n_queries, mode, sign_src, algorithm, d_out, d_err);
   if (rc) return rc;
   M2S_HIP_CHECK(hipEventRecord(st->ev[3], c.stream));

@@ -89,7 +89,8 @@ struct DeviceMesh {
   unsigned long long* stats;  // optional traversal counters (M2S_STATS=1), else nullptr
   uint32_t n_tris;
   uint32_t n_nodes;
-  uint32_t leaf_max;    // subtrees of at most this many triangles are walked as one leaf (2: persistent meshes; a one-shot grid call chooses by its grid, grid_leaf_max)
+  uint32_t leaf_max;    // subtrees of at most this many triangles are walked as one leaf (a grid call chooses by its grid: grid_leaf_max; set_leaf_size re-marks a resident tree)
+  const uint32_t* slot_first;   // pre-order slot -> first triangle of its subtree (what a collapsed leaf's `tri` holds)
   const int* scene;     // 6 order-encoded ints: min xyz / max xyz of the triangle box centres (see bvh.hip)
 };
 
@@ -229,7 +230,10 @@ int build_device_mesh(Arena& ws, hipStream_t st, const float* d_verts, size_t n_
                       size_t n_indices, int index_bytes, int topology, size_t n_tris, int* d_err, DeviceMesh* out,
                       const std::function<int(const float4*, const TriRec*, int)>* after_setup = nullptr, bool records_only = false,
                       uint32_t leaf_max = 2);
-uint32_t grid_leaf_max(const GridParams& g, size_t n_tris);   // distance.hip: the leaf size a one-shot grid call builds its tree with
+uint32_t grid_leaf_max(const GridParams& g, size_t n_tris);   // distance.hip: the leaf size a grid call wants its tree to have
+// Re-marks the leaves of a resident tree (persistent meshes): the node records of a subtree of at most `leaf_max` triangles get `tri` = its first
+// triangle, all others -1 — what k_emit would have written.  One small launch on `st`; nothing else of the tree depends on the leaf size.
+int set_leaf_size(hipStream_t st, DeviceMesh* mesh, uint32_t leaf_max);
 
 // sign.hip: grid-line ray parity -> one "inside" bit per voxel (bit plane in grid layout).
 size_t sign_workspace_bytes(const GridParams& g, size_t n_tris);

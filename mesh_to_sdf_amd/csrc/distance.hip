@@ -2665,8 +2665,8 @@ void cut_word_roundtrip(uint32_t n_nodes, uint32_t start, uint32_t len, uint32_t
 // those queued per (voxel, triangle) pair the optimum moved up wherever a brick meets more than a triangle or so (walk, leaves of 2 / 4 /
 // 8, tools/exp_lane_vs_split.py with M2S_LEAF_MAX): blob-100k 64^3 (24 triangles per brick) 1.15 / 0.79 / 0.59 ms, 96^3 (7.2, split) 0.69 /
 // 0.57 / 0.54, 128^3 (3.05) 0.87 / 0.74 / -; blob-1M 128^3 (30, split) 2.89 / 2.33 / 2.11, 256^3 (3.8) 6.10 / 5.22 / -; blob-11k 64^3 (2.7) 0.25 /
-// 0.21 / 0.20, 96^3 (0.8) 0.22 / 0.20 / 0.21; blob-100k 256^3 (0.38) 1.55 / 1.52 / -, 512^3 (0.048) 6.48 / 7.88 / -.  Persistent meshes
-// have no grid to go by and keep 2.
+// 0.21 / 0.20, 96^3 (0.8) 0.22 / 0.20 / 0.21; blob-100k 256^3 (0.38) 1.55 / 1.52 / -, 512^3 (0.048) 6.48 / 7.88 / -.  A persistent mesh's tree is
+// re-marked by the grid call that wants another size (set_leaf_size).
 uint32_t grid_leaf_max(const GridParams& g, size_t n_tris) {
   const Tuning& tn = tuning();
   if (tn.leaf_max != 0) return tn.leaf_max;

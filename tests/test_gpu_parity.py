@@ -690,6 +690,33 @@ def test_persistent_mesh_matches_one_shot(suzanne):
         Mesh(v, Topology.TriangleList([0, 1, 99999]))
 
 
+def test_persistent_mesh_leaf_size_follows_the_grid():
+    """A resident tree is re-marked with the leaf size each grid wants (grid_leaf_max: 2 / 4 / 8 / 16 triangles by triangles per brick,
+    capi.hip set_leaf_size); grids of every class in a row, queries and asynchronous slab calls in between, against one-shot calls."""
+    import torch
+
+    from mesh_to_sdf_amd import Mesh
+
+    v, idx = meshes.named("blob-6k")
+    topo = Topology.TriangleList(idx)
+    q = meshes.uniform_queries(*meshes.extended_bbox(v, 0.2), 3000)
+    dv, di = torch.as_tensor(v, device="cuda"), torch.as_tensor(idx.astype(np.int64), device="cuda")
+    with Mesh(dv, Topology.TriangleList(di)) as m:
+        for n in (96, 24, 12, 48, 64, 12, 96):                      # 0.4, 27, 220, 3.4, 1.4, 220, 0.4 triangles per brick: leaves of 2, 8, 16, 8, 4, 16, 2
+            g = grid_of(v, [n, n, n])
+            for sign in (SignMethod.Raycast, SignMethod.Normal):
+                got = m.generate_grid_sdf(g, sign)
+                assert_bit_equal(got.cpu().numpy(), generate_grid_sdf(v, topo, g, sign), f"mesh grid {n}^3 {sign.name}")
+            name, am, accel, sign = ACCELS[n % len(ACCELS)]
+            assert_bit_equal(m.generate_sdf(q, am).cpu().numpy() if hasattr(m.generate_sdf(q, am), "cpu") else m.generate_sdf(q, am),
+                             generate_sdf(v, topo, q, am), f"queries after {n}^3: {name}")
+            out = torch.full((g.get_total_cell_count(),), float("nan"), device="cuda")
+            for x0, x1 in ((0, n // 3), (n // 3, n)):
+                m.generate_grid_sdf(g, SignMethod.Raycast, x_slab=(x0, x1), out=out, synchronous=False)
+            m.drain_timings()
+            assert_bit_equal(out.cpu().numpy(), generate_grid_sdf(v, topo, g), f"async slabs {n}^3")
+
+
 def test_sharded_driver_single_process(suzanne):
     # the multi-GPU driver with world size 1 (no process group): chunk plan + persistent mesh + async calls
     import torch
