@@ -1198,7 +1198,7 @@ int m2s_generate_sdf(const float* vertices, size_t n_vertices, const void* indic
   };
   DeviceMesh mesh;
   rc = build_device_mesh(ws, c.stream, sm.d_verts, n_vertices, sm.d_indices, n_indices, index_bytes, topology, n_tris, d_err, &mesh,
-                         &seeds_beside_build, false);
+                         &seeds_beside_build, false, query_leaf_max(n_queries, n_tris, sign_src));
   if (rc) return rc;
   hc.lap("build enqueued (code objects on a first call)");
   M2S_HIP_CHECK(hipEventRecord(st->ev[1], c.stream));
@@ -1565,10 +1565,18 @@ int m2s_mesh_generate_sdf(m2s_mesh* m, const float* queries, size_t n_queries, i
   M2S_HIP_CHECK(hipEventRecord(st->ev[0], c.stream));
   M2S_HIP_CHECK(hipEventRecord(st->ev[1], c.stream));
   M2S_HIP_CHECK(hipEventRecord(st->ev[2], c.stream));
-  if (m->tree_used && m->tree_stream != c.stream) m->tree_async = true;   // (a later re-marking of the leaves must not overtake this walk: set_leaf_size)
-  m->tree_stream = c.stream;
-  m->tree_used = true;
-  if (!c.sync) m->tree_async = true;
+  {
+    // the leaf size this query set wants (query_leaf_max); as in m2s_mesh_generate_grid_sdf
+    const uint32_t want = query_is_tiny(n_queries, m->n_tris, algorithm, sign_src) ? m->dm.leaf_max : query_leaf_max(n_queries, m->n_tris, sign_src);
+    if (want != m->dm.leaf_max) {
+      if (m->tree_async || (m->tree_used && m->tree_stream != c.stream)) { M2S_HIP_CHECK(hipDeviceSynchronize()); m->tree_async = false; }
+      rc = set_leaf_size(c.stream, &m->dm, want);
+      if (rc) return rc;
+    }
+    m->tree_stream = c.stream;
+    m->tree_used = true;
+    if (!c.sync) m->tree_async = true;
+  }
   rc = launch_query_distance(ws, c.stream, m->dm, d_q, n_queries, mode, sign_src, algorithm, d_out, d_err);
   if (rc) return rc;
   M2S_HIP_CHECK(hipEventRecord(st->ev[3], c.stream));

@@ -230,6 +230,8 @@ int build_device_mesh(Arena& ws, hipStream_t st, const float* d_verts, size_t n_
                       size_t n_indices, int index_bytes, int topology, size_t n_tris, int* d_err, DeviceMesh* out,
                       const std::function<int(const float4*, const TriRec*, int)>* after_setup = nullptr, bool records_only = false,
                       uint32_t leaf_max = 2);
+bool query_walk_is_lane(size_t n_q, size_t n_tris, int sign_src);       // distance.hip: sparse query sets take the lane walk
+uint32_t query_leaf_max(size_t n_q, size_t n_tris, int sign_src);       // ... and the leaf size a query call wants its tree to have
 uint32_t grid_leaf_max(const GridParams& g, size_t n_tris);   // distance.hip: the leaf size a grid call wants its tree to have
 // Re-marks the leaves of a resident tree (persistent meshes): the node records of a subtree of at most `leaf_max` triangles get `tri` = its first
 // triangle, all others -1 — what k_emit would have written.  One small launch on `st`; nothing else of the tree depends on the leaf size.

@@ -2661,6 +2661,23 @@ void cut_word_roundtrip(uint32_t n_nodes, uint32_t start, uint32_t len, uint32_t
 // never).  Measured (tools/exp_small_queries.py, whole one-shot calls, all pairs / build + walk): 11 k triangles x 1 ... 1 000 queries
 // 0.085 - 0.15 / 0.25 - 0.70 ms, x 10 000 0.47 (0.83 with rays) / 0.55 (0.66); 100 k triangles x 64 0.13 - 0.22 / 1.0 - 1.3 ms, x 1 000
 // 0.46 (0.81) / 0.74 (0.94), x 10 000 3.2 (5.8) / 0.9 (1.0): 240 G pairs/s for the distance alone, 135 G with the rays.
+// Sparse query sets take the lane walk (k_lane_q): fewer than M2S_QUERY_LANE_COEFF (2.5) queries per triangle.
+bool query_walk_is_lane(size_t n_q, size_t n_tris, int sign_src) {
+  const int lane_env = tuning().lane_walk;   // -1 auto, 0 never, 1 always
+  return n_tris && sign_src != SIGN_XRAY_ALL && (lane_env >= 0 ? lane_env == 1 : (double)n_q < tuning().query_lane_coeff * (double)n_tris);
+}
+// The leaf size a query call wants (M2S_LEAF_MAX overrides): 2 for the lane walk (every lane pays for its own leaf), for the packets by
+// queries per triangle — packets of few queries per triangle are large against the triangles, as bricks of a coarse grid are (packets, leaves of
+// 2 / 4 / 8, RtreeBvh, whole call, tools/exp_query_walks.py): blob-100k 1 M queries 1.91 / 1.56 / 1.39 ms, 3 M 2.37 / 2.02 / 1.91, 10 M 3.93 / 3.60 / 3.74;
+// blob-11k 300 k 0.66 / 0.63 / 0.63, 3 M 1.00 / 0.95 / 1.04, 10 M 2.19 / 2.30 / 2.77.
+uint32_t query_leaf_max(size_t n_q, size_t n_tris, int sign_src) {
+  const Tuning& tn = tuning();
+  if (tn.leaf_max != 0) return tn.leaf_max;
+  if (n_tris == 0 || query_walk_is_lane(n_q, n_tris, sign_src)) return 2u;
+  const double per_tri = (double)n_q / (double)n_tris;
+  return per_tri < 50.0 ? 8u : per_tri < 500.0 ? 4u : 2u;
+}
+
 // The leaf size of a one-shot grid call's tree (M2S_LEAF_MAX overrides).  A larger leaf trades node tests for leaf pre-tests; with
 // those queued per (voxel, triangle) pair the optimum moved up wherever a brick meets more than a triangle or so (walk, leaves of 2 / 4 /
 // 8, tools/exp_lane_vs_split.py with M2S_LEAF_MAX): blob-100k 64^3 (24 triangles per brick) 1.15 / 0.79 / 0.59 ms, 96^3 (7.2, split) 0.69 /
@@ -2764,10 +2781,10 @@ int prepare_query_walk(Arena& ws, hipStream_t st, const float* d_queries, size_t
   // RtreeBvh): blob-100k 100 k queries 1.36 / 3.65 ms, 1 M 2.70 / 3.45, 3 M 5.00 / 4.38, 10 M 12.3 / 6.7 (crossover ~2 M);
   // blob-1M 1 M 6.3 / 12.8 ms, 10 M 26.4 / 22.4 (~7 M).  Below it the packet walk lasts as long as its worst packet's chain of
   // dependent loads (2.7 ms), above it the lane walk's divergence costs more than the packets' union.  n* ~ 3500 T^0.55 fits both.
-  const int lane_env = tuning().lane_walk;   // -1 auto, 0 never, 1 always
-  const double lane_coeff = tuning().query_lane_coeff;
-  const bool lane_walk = n_tris && sign_src != SIGN_XRAY_ALL &&
-                         (lane_env >= 0 ? lane_env == 1 : (double)n_q < lane_coeff * pow((double)n_tris, 0.55));
+  // (End of round 4, leaf work queued and leaves of 4 - 8 for the packets — query_leaf_max: lane / packets, whole call: blob-100k 100 k queries 1.12 /
+  // 1.53 ms, 300 k 1.47 / 1.46, 1 M 2.13 / 1.39, 10 M 10.9 / 3.60; blob-11k 30 k 0.72 / 0.66, 300 k 0.80 / 0.63: the crossover is at ~2.5 queries
+  // per triangle now.)
+  const bool lane_walk = query_walk_is_lane(n_q, n_tris, sign_src);
   // packets = leaves of the bucket k-d tree over the sorted keys (k_qcells); the launch has room for twice the consecutive
   // count, and k_qtable_mode falls back to consecutive packets should there be more
   const uint32_t* table = nullptr;

@@ -18,7 +18,7 @@ struct Tuning {
   int lane_walk = -1;               // M2S_LANE_WALK    -1 automatic, 0 never, 1 always: one voxel / query per lane instead of one packet per wave
   double lane_ratio = 60.0;         // M2S_LANE_RATIO   grid: lane walk above this many triangles per packet brick
   double lane_ratio_split = 100.0;  // M2S_LANE_RATIO_SPLIT   ... and above this many where the packet walk's stragglers can be split (below)
-  double query_lane_coeff = 3500.0; // M2S_QUERY_LANE_COEFF   queries: lane walk below coeff * T^0.55 queries
+  double query_lane_coeff = 2.5;    // M2S_QUERY_LANE_COEFF   queries: lane walk below this many queries per triangle
   uint32_t leaf_max = 0;            // M2S_LEAF_MAX     triangles per collapsed leaf of the tree a grid call walks (1 .. 16; a resident tree is re-marked); 0: by triangles per brick (2 / 4 / 8 / 16)
   double brute_max = -1.0;          // M2S_BRUTE_MAX    tree-less path for cells x triangles (queries x triangles) up to this; < 0: automatic, 0: never
   uint32_t cut_min_packets = 100000;// M2S_CUT_MIN_PACKETS   grid: cut lists from this many packets on
