@@ -25,6 +25,7 @@
 
 #include "../../include/m2s.h"
 #include "common.h"
+#include "tuning.h"
 #include "geo.hip.h"
 
 namespace m2s {
@@ -933,7 +934,13 @@ int build_device_mesh(Arena& ws, hipStream_t st, const float* d_verts, size_t n_
     const int rc = (*after_setup)(cen_raw, raw, 1);
     if (rc) return rc;
   }
-  if (n > 2) {
+  // A tree whose leaves hold 8 - 16 triangles keeps the top two or three levels of a 64-triangle treelet, and its walk is short: the pass (roots + treelets, 55 us
+  // of the build's 250 at 100 k triangles, 300 of 1 170 at 1 M) costs such a call more than its ~5 % of the walk (whole call with / without, tools/exp_treelets.py:
+  // blob-100k 64^3 0.88 / 0.85 ms, 128^3 0.82 / 0.78; blob-1M 128^3 3.41 / 3.17, 256^3 6.26 / 6.17; blob-11k 48^3 0.43 / 0.40).  With leaves of 4 it is a wash at
+  // 100 k triangles (160^3 1.13 / 1.14), a loss at 1 M (384^3 11.3 / 11.6) and still a gain for small meshes (blob-11k 64^3 - 96^3 0.39 / 0.37): M2S_TREELETS -1.
+  const int treelets = tuning().treelets;
+  const bool skip_treelets = leaf_max >= 8u || (leaf_max >= 4u && n_tris < 32768u);
+  if (n > 2 && (treelets > 0 || (treelets < 0 && !skip_treelets))) {
     // treelet pass: the nodes of at most TREELET_MAX triangles are rebuilt by sweep splits (their keys rewritten), then the hierarchy is derived
     int2* roots = reinterpret_cast<int2*>(child);   // child[] is not used by the kernels below before k_karras rewrites it
     hipLaunchKernelGGL(k_roots_from_keys, dim3(cdiv(n_tris, B)), dim3(B), 0, st, (const uint64_t*)keys2, n, roots, scene + 7);

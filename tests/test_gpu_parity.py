@@ -49,12 +49,12 @@ def cut_lists_mode(request):
     forced = {}
     if mode == "cut lists on every grid":
         # M2S_BRUTE_MAX=0: no brute-force shortcut for tiny problems (the default mode takes it): the walks must see them
-        forced = {"M2S_CUT_MIN_PACKETS": 8, "M2S_QUERY_CUT_MIN": 1, "M2S_LANE_WALK": 0, "M2S_BRUTE_MAX": 0, "M2S_SPLIT": 0}
+        forced = {"M2S_CUT_MIN_PACKETS": 8, "M2S_QUERY_CUT_MIN": 1, "M2S_LANE_WALK": 0, "M2S_BRUTE_MAX": 0, "M2S_SPLIT": 0, "M2S_TREELETS": 0}   # (and a tree without the treelet pass)
     elif mode == "lane walks":
         forced = {"M2S_LANE_WALK": 1, "M2S_BRUTE_MAX": 0, "M2S_LEAF_MAX": 3}
     elif mode == "split walks":
         # every packet that lasts longer than a few node tests hands the rest of its ranges to other waves (distance.hip, split walk)
-        forced = {"M2S_SPLIT": 2, "M2S_SPLIT_BUDGET": 24, "M2S_SPLIT_MIN_RECORDS": 4, "M2S_SPLIT_MAX_RECORDS": 64, "M2S_SPLIT_ROUNDS": 3, "M2S_LANE_WALK": 0, "M2S_BRUTE_MAX": 0}
+        forced = {"M2S_SPLIT": 2, "M2S_SPLIT_BUDGET": 24, "M2S_SPLIT_MIN_RECORDS": 4, "M2S_SPLIT_MAX_RECORDS": 64, "M2S_SPLIT_ROUNDS": 3, "M2S_LANE_WALK": 0, "M2S_BRUTE_MAX": 0, "M2S_TREELETS": 1}
     elif mode == "direct evaluations":
         forced = {"M2S_DEFER": 0, "M2S_LANE_WALK": 0, "M2S_BRUTE_MAX": 0, "M2S_LEAF_MAX": 2}    # (leaves of 2: round 3's tree)
     elif mode == "queued evaluations":

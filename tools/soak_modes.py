@@ -8,8 +8,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from mesh_to_sdf_amd import AccelerationMethod, Grid, SignMethod, Topology, _lib, generate_grid_sdf, generate_sdf, interleaved_slab, meshes
 
-MODES = {"default": {}, "packet + cut lists": {"M2S_CUT_MIN_PACKETS": 8, "M2S_QUERY_CUT_MIN": 1, "M2S_LANE_WALK": 0, "M2S_BRUTE_MAX": 0, "M2S_SPLIT": 0},
-         "packet + split": {"M2S_LANE_WALK": 0, "M2S_BRUTE_MAX": 0, "M2S_SPLIT": 2, "M2S_SPLIT_BUDGET": 40, },
+MODES = {"default": {}, "packet + cut lists": {"M2S_CUT_MIN_PACKETS": 8, "M2S_QUERY_CUT_MIN": 1, "M2S_LANE_WALK": 0, "M2S_BRUTE_MAX": 0, "M2S_SPLIT": 0, "M2S_TREELETS": 0},
+         "packet + split": {"M2S_LANE_WALK": 0, "M2S_BRUTE_MAX": 0, "M2S_SPLIT": 2, "M2S_SPLIT_BUDGET": 40, "M2S_TREELETS": 1},
          "packet + cut lists + split": {"M2S_CUT_MIN_PACKETS": 8, "M2S_QUERY_CUT_MIN": 1, "M2S_LANE_WALK": 0, "M2S_BRUTE_MAX": 0, "M2S_SPLIT": 2, "M2S_SPLIT_BUDGET": 60},
          "lane walk": {"M2S_LANE_WALK": 1, "M2S_BRUTE_MAX": 0, "M2S_LEAF_MAX": 2},
          # the packet walk's pre-tests and exact evaluations: wave-wide at once (round 3), evaluations queued, both queued, queued + direct
