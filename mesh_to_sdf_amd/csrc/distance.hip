@@ -494,9 +494,6 @@ struct WalkStats {
 // five wait states before a memory instruction may read it — without them a follow-up round loaded its flag from garbage addresses.
 constexpr uint32_t SPLIT_CHECK_EVERY = 64;
 constexpr uint32_t SPLIT_CONTINUATION = 0x80000000u;   // item tag (with the slot): a suspended packet, not a subtree
-#ifndef M2S_SPLIT_DEBUG
-#define M2S_SPLIT_DEBUG 4   // experiment: 1 nothing in the walk, 2 + work accounting, 3 + flag checks, 4 everything
-#endif
 struct SplitState {
   uint32_t units = 0, next_check = 0xffffffffu;   // work done so far; next look at the flag (never, unless armed)
   const uint32_t* flag_addr = nullptr;            // this XCD's flag of the launch (k_packet: the time it went up, odd; rounds: 1)
@@ -759,7 +756,7 @@ __device__ __forceinline__ void walk_span(const DeviceMesh& mesh, f3 p, float sl
           if (want) dq.q1[(dq.head1 + dq.n1 + rank) & 127u] = (threadIdx.x & 63u) | (((uint32_t)nr.tri + k) << 6);
           dq.n1 += wn;
           if (dq.n1 >= 64u) {
-            if (BUDGET && M2S_SPLIT_DEBUG >= 2) sp.units += 4u;
+            if (BUDGET) sp.units += 4u;
             if (defer_pretest<MODE>(mesh, p, thr, dq, best)) thr = prune_bound(best.d2, slack);
           }
         }
@@ -777,12 +774,12 @@ __device__ __forceinline__ void walk_span(const DeviceMesh& mesh, f3 p, float sl
             if (reach) dq.q[(dq.head + dq.n + rank) & 127u] = (threadIdx.x & 63u) | (((uint32_t)nr.tri + k) << 6);
             dq.n += (uint32_t)__popcll(rb);
             if (dq.n >= 64u) {
-              if (BUDGET && M2S_SPLIT_DEBUG >= 2) sp.units += 4u;
+              if (BUDGET) sp.units += 4u;
               defer_flush<MODE>(mesh, p, dq, best);
               thr = prune_bound(best.d2, slack);
             }
           } else {
-            if (BUDGET && M2S_SPLIT_DEBUG >= 2) sp.units += 4u;
+            if (BUDGET) sp.units += 4u;
             const TriRec tr = record_at_vec(mesh.tris, (uint32_t)nr.tri + k);
             eval_triangle_leaf<MODE>(best, p, tr, reach);
             thr = prune_bound(best.d2, slack);
@@ -790,9 +787,9 @@ __device__ __forceinline__ void walk_span(const DeviceMesh& mesh, f3 p, float sl
         }
       }
       off = nr.skip;
-      if (BUDGET && M2S_SPLIT_DEBUG >= 2) {
+      if (BUDGET) {
         sp.units += 3u + cnt;
-        if (M2S_SPLIT_DEBUG >= 3 && sp.units >= sp.next_check) {
+        if (sp.units >= sp.next_check) {
           // (no exit of its own: a second way out of this loop cost the walk 11 % although it was never taken; the loop ends by its
           // own condition)
           bool go;
@@ -999,7 +996,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
         walk_span<MODE, STATS, SPLIT, false, SPLIT, DEFER>(mesh, p, slack, best, thr, off, end, st, sp, nullptr, &dq);
       }
       if (DEFER) defer_drain<MODE>(mesh, p, slack, dq, best);   // what is still queued (a suspended packet hands over complete minima)
-      if (SPLIT && sp.suspended && M2S_SPLIT_DEBUG >= 4) {
+      if (SPLIT && sp.suspended) {
         // (range has been stepped once more by the loop's increment)
         if (!split_handover<MODE>(split, packet, range - 1u, off, best, err)) atomicOr(err, ERRF_SPLIT_OVERFLOW);   // cannot happen: a slot per packet
         return;                                                                // k_split_finish writes this packet's voxels
