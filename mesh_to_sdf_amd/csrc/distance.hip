@@ -2517,8 +2517,8 @@ int prepare_grid_walk(Arena& ws, hipStream_t st, const DeviceMesh& mesh, const G
     plan->split = sc;
     plan->split_forced = tn.split == 2;
   }
-  // dense exact evaluations (packet walk, unsigned distances): M2S_DEFER -1 automatic, 0 never, 1 always
-  // 1: queued, 2: queued, but direct where most of the wave is reached (grids much finer than the mesh: see DEFER_DIRECT_LANES)
+  // The packet walk's leaf work (DeferQueue; M2S_DEFER forces a form): 0 wave-wide at once, 1 the exact evaluations queued per (voxel, triangle) pair,
+  // 2: queued, but at once where most of the wave is reached (grids much finer than the mesh: see DEFER_DIRECT_LANES),
   // 3: the pre-tests queued too (defer_pretest) — from 0.045 triangles per brick on: walk, queued evaluations / + queued pre-tests, blob-100k
   // 128^3 1.02 / 0.83 ms, 256^3 1.74 / 1.48, 512^3 (0.048 per brick) 6.85 / 6.54, 768^3 (0.014) 16.9 / 17.7; blob-1M 512^3 21.9 / 18.2; blob-11k
   // 256^3 (0.04) 0.60 / 0.63; sheet-100k 512^3 (0.05) 13.2 / 12.0.  (Both forms of pre-test in one kernel, chosen per leaf by the number of lanes that
