@@ -37,7 +37,7 @@ def cut_lists_mode(request):
         pytest.skip("large enough to use the cut lists anyway")
     if mode != "default" and "four_million" in request.node.name:
         pytest.skip("the test switches the walks itself")
-    if mode != "default" and any(t in request.node.name for t in ("parity_sheet100k_256", "parity_blob1m")):
+    if mode != "default" and "reference_propagation_parity" in request.node.name:
         pytest.skip("a report against minutes of CPU propagation: once is enough (the kernels' modes are covered by the other tests)")
     if mode == "lane walks" and big:
         pytest.skip("the lane walk is not meant for this size")
