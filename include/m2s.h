@@ -273,7 +273,11 @@ int m2s_ipc_close(void* device_ptr, int device);
  * own client regenerates the grid on every parameter change, mesh_to_sdf_client/src/sdf.rs:32-137 —
  * or that splits one grid into several x-slab calls can build once and reuse:
  * triangle records + LBVH stay resident on `opts->device`; the sign planes of the last grid are cached.
- * Results are identical to the one-shot entry points. */
+ * Results are identical to the one-shot entry points.
+ * A call may re-mark the resident tree's leaves for its own grid / query set (how many triangles a leaf holds follows the triangles
+ * per brick, or the queries per triangle: a 5 us launch on the call's stream).  When that happens while earlier asynchronous
+ * calls, or calls on another stream, may still be walking the tree, the call synchronises the device first; callers that keep
+ * several streams busy on one mesh avoid it by giving them grids of the same density class (the x-slabs of one grid always are). */
 typedef struct m2s_mesh m2s_mesh;
 int m2s_mesh_create(const float* vertices, size_t n_vertices, const void* indices, size_t n_indices, int index_bytes,
                     int topology, const m2s_opts* opts, m2s_mesh** out_mesh);

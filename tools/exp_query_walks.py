@@ -16,7 +16,7 @@ for nq in (30000, 100000, 300000, 1000000, 3000000, 10000000):
     q = torch.as_tensor(meshes.uniform_queries(lo, hi, nq), device="cuda")
     line = f"{mesh} x {nq:>8} queries RtreeBvh:"
     ref = None
-    for name, kn in (("automatic", {}), ("lane", {"M2S_LANE_WALK": 1, "M2S_BRUTE_MAX": 0}), ("packets, leaves of 2", {"M2S_LANE_WALK": 0, "M2S_BRUTE_MAX": 0, "M2S_LEAF_MAX": 2}),
+    for name, kn in (("automatic", {}), ("automatic, no treelets", {"M2S_TREELETS": 0}), ("lane", {"M2S_LANE_WALK": 1, "M2S_BRUTE_MAX": 0}), ("packets, leaves of 2", {"M2S_LANE_WALK": 0, "M2S_BRUTE_MAX": 0, "M2S_LEAF_MAX": 2}),
                      ("leaves of 4", {"M2S_LANE_WALK": 0, "M2S_BRUTE_MAX": 0, "M2S_LEAF_MAX": 4}), ("leaves of 8", {"M2S_LANE_WALK": 0, "M2S_BRUTE_MAX": 0, "M2S_LEAF_MAX": 8})):
         with _lib.knobs(**kn):
             best = None
