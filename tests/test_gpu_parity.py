@@ -6,6 +6,8 @@ the reference's label-PROPAGATION semantics the documented <0.5 % of cells diffe
 header fact 2) and the test reports the histogram and asserts the one-sided property.
 Needs a real MI355X: run with `-m gpu`.  Nothing here reads /root/reference.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -35,7 +37,7 @@ def cut_lists_mode(request):
     big = any(t in request.node.name for t in ("full_size", "10M", "512", "1024", "config", "256"))
     if mode != "default" and "full_size" in request.node.name:
         pytest.skip("large enough to use the cut lists anyway")
-    if mode != "default" and "four_million" in request.node.name:
+    if mode != "default" and ("four_million" in request.node.name or "far_field" in request.node.name):
         pytest.skip("the test switches the walks itself")
     if mode != "default" and "reference_propagation_parity" in request.node.name:
         pytest.skip("a report against minutes of CPU propagation: once is enough (the kernels' modes are covered by the other tests)")
@@ -715,6 +717,18 @@ def test_persistent_mesh_leaf_size_follows_the_grid():
                 m.generate_grid_sdf(g, SignMethod.Raycast, x_slab=(x0, x1), out=out, synchronous=False)
             m.drain_timings()
             assert_bit_equal(out.cpu().numpy(), generate_grid_sdf(v, topo, g), f"async slabs {n}^3")
+
+
+def test_far_field_every_form_equals_all_pairs():
+    """tools/soak_far.py, 80 cases: a small mesh in a box 3 - 100 mesh sizes wide (off-centre: large coordinates), where a voxel sees many triangles
+    at almost the same distance and the pruning margins decide what is evaluated; five walk forms against the all-pairs kernel, bit for bit."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "soak_far.py"), "--seeds", "80", "--seconds", "120"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "80 cases" in r.stdout and ", 0 differences" in r.stdout, r.stdout[-500:]
 
 
 def test_sharded_driver_single_process(suzanne):
