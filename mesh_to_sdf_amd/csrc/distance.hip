@@ -2931,12 +2931,12 @@ void warm_distance(hipStream_t st) {
   hipLaunchKernelGGL(k_warm_distance, dim3(1), dim3(64), 0, st);
   // ... and resolves a kernel FUNCTION at its own first launch (~0.3 ms each): ask for the attributes of the ones a first call uses
   const void* fns[] = {
-      (const void*)k_packet<true, MODE_UNSIGNED, SIGN_GRID_PLANE, false, false, 1>,
-      (const void*)k_packet<true, MODE_UNSIGNED, SIGN_GRID_PLANE, false, true, 1>,
-      (const void*)k_packet<true, MODE_NORMAL_FOLD, SIGN_NONE, false, false, 1>,
-      (const void*)k_packet<true, MODE_NORMAL_FOLD, SIGN_NONE, false, true, 1>,
-      (const void*)k_packet<false, MODE_UNSIGNED, SIGN_RAYS3, false, false, 1>,
-      (const void*)k_packet<false, MODE_NEAREST_NORMAL, SIGN_NONE, false, false, 1>,
+      (const void*)k_packet<true, MODE_UNSIGNED, SIGN_GRID_PLANE, false, false, 3>,
+      (const void*)k_packet<true, MODE_UNSIGNED, SIGN_GRID_PLANE, false, false, 2>,
+      (const void*)k_packet<true, MODE_NORMAL_FOLD, SIGN_NONE, false, false, 3>,
+      (const void*)k_packet<true, MODE_NORMAL_FOLD, SIGN_NONE, false, false, 2>,
+      (const void*)k_packet<false, MODE_UNSIGNED, SIGN_RAYS3, false, false, 3>,
+      (const void*)k_packet<false, MODE_NEAREST_NORMAL, SIGN_NONE, false, false, 3>,
       (const void*)k_split_init,
       (const void*)k_split_round<MODE_UNSIGNED>,
       (const void*)k_split_round<MODE_NORMAL_FOLD>,
