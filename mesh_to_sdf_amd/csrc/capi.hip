@@ -1694,4 +1694,20 @@ int m2s_debug_cut_code(uint32_t n_nodes, uint32_t start, uint32_t len, uint32_t 
   return M2S_OK;
 }
 
+// Test hook (not part of include/m2s.h): the leaf size a call would ask of its tree — out[0] for a grid call over `grid` (grid_leaf_max: by
+// triangles per 4^3-voxel brick of the whole grid), out[1] for a query call of n_queries (query_leaf_max: 2 under the lane walk, else by queries per
+// triangle), out[2] = 1 if that query call takes the lane walk.  Host arithmetic only; tests/test_capi_cpu.py pins the rules DESIGN.md states.
+int m2s_debug_leaf_sizes(const m2s_grid* grid, size_t n_tris, size_t n_queries, uint32_t out[3]) {
+  g_err[0] = 0;
+  if (!grid || !out) return fail(M2S_ERR_BAD_ARG, "NULL argument");
+  GridParams g;
+  size_t slab_cells = 0;
+  const int rc = fill_grid_params(grid, nullptr, &g, &slab_cells);
+  if (rc) return rc;
+  out[0] = grid_leaf_max(g, n_tris);
+  out[1] = query_leaf_max(n_queries, n_tris, SIGN_RAYS3);
+  out[2] = query_walk_is_lane(n_queries, n_tris, SIGN_RAYS3) ? 1u : 0u;
+  return M2S_OK;
+}
+
 }  // extern "C"

@@ -135,6 +135,35 @@ def test_balanced_slabs_equalise_a_known_cost_profile():
         assert e.value.code == _lib.ERR_BAD_ARG
 
 
+def test_leaf_size_rules(lib):
+    """The leaf size a call asks of its tree (distance.hip grid_leaf_max / query_leaf_max; DESIGN.md section 4 "Leaf size by grid", section 9): host
+    arithmetic of the library itself through the test hook m2s_debug_leaf_sizes."""
+    from mesh_to_sdf_amd import Grid
+
+    fn = lib.m2s_debug_leaf_sizes
+    fn.restype = C.c_int
+    out = (C.c_uint32 * 3)()
+
+    def ask(n, n_tris, n_q=0):
+        g = Grid.from_bounding_box([0.0, 0.0, 0.0], [1.0, 1.0, 1.0], [n, n, n])
+        assert fn(C.byref(g._g), C.c_size_t(n_tris), C.c_size_t(n_q), out) == 0
+        return out[0], out[1], out[2]
+
+    # grids: triangles per 4^3 brick of the whole grid < 0.6 -> 2, < 3 -> 4, < 40 -> 8, else 16
+    assert ask(512, 100000)[0] == 2          # 0.048 (headline)
+    assert ask(256, 100000)[0] == 2          # 0.38
+    assert ask(192, 100000)[0] == 4          # 0.90
+    assert ask(128, 100000)[0] == 8          # 3.05
+    assert ask(64, 100000)[0] == 8           # 24.4
+    assert ask(32, 100000)[0] == 16          # 195
+    assert ask(512, 1000000)[0] == 2         # 0.48
+    # queries: lane walk (leaves of 2) below 2.5 queries per triangle; packets < 50 per triangle -> 8, < 500 -> 4, else 2
+    assert ask(64, 100000, 100000)[1:] == (2, 1)
+    assert ask(64, 100000, 300000)[1:] == (8, 0)
+    assert ask(64, 100000, 10000000)[1:] == (4, 0)
+    assert ask(64, 11200, 10000000)[1:] == (2, 0)
+
+
 def test_cut_list_words_are_supersets_for_every_tree_size(lib):
     """distance.hip CutList: a list word carries a range's start exactly and its length as a small float rounded UP — the walk may take a
     superset of a subtree range, never less.  Host arithmetic of the library itself (test hook m2s_debug_cut_code), every width of the
