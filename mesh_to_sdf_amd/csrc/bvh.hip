@@ -62,8 +62,14 @@ __global__ __launch_bounds__(256) void k_tri_setup(const float* __restrict__ ver
                                                    uint32_t n_tris, TriRec* __restrict__ raw, Box* __restrict__ boxes,
                                                    float4* __restrict__ cen_raw,
                                                    int* __restrict__ scene /*final values, then 6 per block from part_base on*/, int part_base,
-                                                   int* __restrict__ err) {
+                                                   int* __restrict__ err, uint32_t* __restrict__ aux, uint32_t aux_words, int* __restrict__ parent) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  // the build's counters, and the "no parent" marker of the root (internal node 0, or the only leaf): every other node's entry is
+  // written by k_karras before k_emit reads it
+  if (aux && blockIdx.x == 0) {
+    if (threadIdx.x < aux_words) aux[threadIdx.x] = 0u;
+    if (threadIdx.x == 0) parent[0] = INT32_MIN;
+  }
   int lo[3] = {INT32_MAX, INT32_MAX, INT32_MAX}, hi[3] = {INT32_MIN, INT32_MIN, INT32_MIN};
   if (t < n_tris) {
     const size_t base = topology == 0 ? (size_t)t * 3 : (size_t)t;  // list: tuples(); strip: tuple_windows()
@@ -665,6 +671,8 @@ __global__ __launch_bounds__(64) void k_treelet_lanes(const int2* __restrict__ r
   }
 }
 
+#include "lbvh_sort.hip.h"
+
 // ======== the lean build ==========================================================================================
 // The build is the part of a multi-GPU rank's step that does not shard, so it is a few FULL launches rather than many small ones
 // (round 2: ~45 launch-bound kernels, 0.36 ms for 100 k triangles; tests/golden/build_digests.json pins the tree that sequence and
@@ -689,13 +697,6 @@ __host__ __device__ inline uint32_t key_tiles(size_t n) {
   return tp ? (uint32_t)((n + tp - 1) / tp) : 0u;
 }
 constexpr size_t AUX_WORDS = 16;   // [0]: k_seg_build's finished blocks
-
-// Clears the build's counters and writes the "no parent yet" markers.
-__global__ __launch_bounds__(256) void k_clear_aux(uint32_t* __restrict__ aux, size_t words, int* __restrict__ parent, int n_nodes) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
-  for (size_t k = i; k < words; k += stride) aux[k] = 0u;
-  for (size_t k = i; k < (size_t)n_nodes; k += stride) parent[k] = INT32_MIN;
-}
 
 // 63-bit Morton key of every triangle's box centre (21 bits per axis over the scene's box of centres) and the identity permutation.
 // One block per tile; every block folds the per-block scene partials of k_tri_setup itself, block 0 publishes the final values
@@ -842,7 +843,7 @@ size_t bvh_workspace_bytes(size_t n_tris) {
   size_t b = AUX_WORDS * 4 + 256;
   b += n * 48 + 256 + n * sizeof(TriRec) * 2 + n * 16 + 256 + n * 16 + 256 + n * 4 + 256 + n * sizeof(TriPlanes) + 256 + n * sizeof(Box) * 3 + n * (8 + 4) * 2 + sort_tmp;
   b += n * (sizeof(int2) * 2) + 2 * n * sizeof(int) + 2 * n * sizeof(NodeRec) + 2 * n * (sizeof(NodeExt) + 4);
-  return b + 64 * 256 + 4096 + 24 * ((n + 255) / 256) + 256;
+  return b + 64 * 256 + 4096 + 24 * ((n + 255) / 256) + 256 + sample_sort_bytes(n);
 }
 
 int build_device_mesh(Arena& ws, hipStream_t st, const float* d_verts, size_t n_verts, const void* d_indices,
@@ -894,6 +895,19 @@ int build_device_mesh(Arena& ws, hipStream_t st, const float* d_verts, size_t n_
   size_t sort_tmp = 0;
   (void)rocprim::radix_sort_pairs(nullptr, sort_tmp, keys, keys2, vals, order, n_tris, 0, 64, st);
   void* tmp = ws.take<char>(sort_tmp ? sort_tmp : 1);
+  const uint32_t sort_w = sort_tile_size(n_tris);
+  SortBufs sb;
+  if (sort_w && n_tris > sort_w) {
+    const size_t p = (n_tris + sort_w - 1) / sort_w;
+    sb.tiles = ws.take<uint4>(p * sort_w);
+    sb.samples = ws.take<uint4>(p * (sort_w / SS_G));
+    sb.splitters = ws.take<uint4>(p * SS_PER_TILE);
+    sb.cmat = ws.take<uint8_t>(p * p * SS_PER_TILE);
+    if (!sb.tiles || !sb.samples || !sb.splitters || !sb.cmat) {
+      set_error("internal: BVH workspace too small");
+      return M2S_ERR_HIP_INTERNAL;
+    }
+  }
   if (!raw || !tris || !boxes || !seg || !keys || !keys2 || !vals || !order || !range || !child || !parent || !nodes ||
       !scene || !tmp || !ext || !aux || !cen_raw || !slot_of || !slot_first || !cen || !planes || !corners) {
     set_error("internal: BVH workspace too small");
@@ -908,7 +922,7 @@ int build_device_mesh(Arena& ws, hipStream_t st, const float* d_verts, size_t n_
   leaf_max = std::min(std::max(leaf_max, 1u), 16u);
   out->leaf_max = leaf_max;
   hipLaunchKernelGGL(k_tri_setup, dim3(cdiv(n_tris, B)), dim3(B), 0, st, d_verts, (uint32_t)n_verts, d_indices,
-                     index_bytes, topology, (uint32_t)n_tris, raw, boxes, cen_raw, scene, 8, d_err);
+                     index_bytes, topology, (uint32_t)n_tris, raw, boxes, cen_raw, scene, 8, d_err, records_only ? nullptr : aux, (uint32_t)AUX_WORDS, parent);
   if (records_only) {
     // a tiny problem (grid_is_tiny): all voxels x all triangles needs the triangle records and nothing else — no keys, no sort, no tree
     M2S_HIP_CHECK(hipGetLastError());
@@ -917,15 +931,18 @@ int build_device_mesh(Arena& ws, hipStream_t st, const float* d_verts, size_t n_
     out->n_nodes = 0;
     return 0;
   }
-  hipLaunchKernelGGL(k_clear_aux, dim3(std::min(1024u, cdiv(std::max(AUX_WORDS, 2 * n_tris), B))), dim3(B), 0, st, aux, AUX_WORDS, parent, 2 * n - 1);
   out->cen_raw = cen_raw;
   out->slot_of = slot_of;
   if (after_setup) {   // the caller's seed passes only need the centroids: they run beside the sort and the hierarchy
     const int rc = (*after_setup)(cen_raw, raw, 0);   // phase 0: mark this point of the stream (an event), launch nothing yet
     if (rc) return rc;
   }
-  hipLaunchKernelGGL(k_morton_keys, dim3(key_tiles(n_tris)), dim3(KEY_THREADS), 0, st, boxes, (uint32_t)n_tris, scene, (uint32_t)cdiv(n_tris, B), keys, vals, key_tile_pairs(n_tris));
-  M2S_HIP_CHECK(rocprim::radix_sort_pairs(tmp, sort_tmp, keys, keys2, vals, order, n_tris, 0, 64, st));
+  if (sort_w == 1024u) launch_sample_sort<1024>(st, boxes, (uint32_t)n_tris, scene, (uint32_t)cdiv(n_tris, B), sb, keys2, order, d_err);
+  else if (sort_w == 2048u) launch_sample_sort<2048>(st, boxes, (uint32_t)n_tris, scene, (uint32_t)cdiv(n_tris, B), sb, keys2, order, d_err);
+  else {
+    hipLaunchKernelGGL(k_morton_keys, dim3(key_tiles(n_tris)), dim3(KEY_THREADS), 0, st, boxes, (uint32_t)n_tris, scene, (uint32_t)cdiv(n_tris, B), keys, vals, key_tile_pairs(n_tris));
+    M2S_HIP_CHECK(rocprim::radix_sort_pairs(tmp, sort_tmp, keys, keys2, vals, order, n_tris, 0, 64, st));
+  }
   if (after_setup) {
     // phase 1: `st` now holds ~100 us of work (keys, sort) — the time the host needs to enqueue the side work (the seed
     // passes, behind the phase-0 mark).  Launching it at phase 0 left `st` idle for those ~100 us (a launch costs the host ~8 us,
@@ -1004,7 +1021,9 @@ void warm_bvh(hipStream_t st) {
   // ... and resolves a kernel FUNCTION at its own first launch (~0.3 ms each): ask for the attributes of the ones a first call uses
   const void* fns[] = {
       (const void*)k_tri_setup,
-      (const void*)k_clear_aux,
+      (const void*)k_sort_tiles<1024>,
+      (const void*)k_sort_rank<1024>,
+      (const void*)k_sort_buckets<1024>,
       (const void*)k_morton_keys,
       (const void*)k_roots_from_keys,
       (const void*)k_karras,

@@ -23,6 +23,7 @@ const Entry TABLE[] = {
     M2S_KNOB("M2S_HOST_TIMES", K_INT, host_times),
     M2S_KNOB("M2S_LANE_WALK", K_INT, lane_walk),
     M2S_KNOB("M2S_TREELETS", K_INT, treelets),
+    M2S_KNOB("M2S_SORT_TILE", K_INT, sort_tile),
     M2S_KNOB("M2S_LEAF_MAX", K_U32, leaf_max),
     M2S_KNOB("M2S_LANE_RATIO", K_F64, lane_ratio),
     M2S_KNOB("M2S_LANE_RATIO_SPLIT", K_F64, lane_ratio_split),
