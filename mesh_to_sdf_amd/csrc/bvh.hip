@@ -215,7 +215,7 @@ __global__ __launch_bounds__(256) void k_emit(int n, const int2* __restrict__ ra
                                               NodeRec* __restrict__ nodes, TriRec* __restrict__ tris,
                                               uint32_t* __restrict__ slot_first, float4* __restrict__ cen,
                                               TriPlanes* __restrict__ planes, uint32_t leaf_max, uint32_t* __restrict__ slot_of,
-                                              float4* __restrict__ corners, int* __restrict__ err) {
+                                              float4* __restrict__ corners, float4* __restrict__ nrm, int* __restrict__ err, int dbg) {
   const int id = blockIdx.x * blockDim.x + threadIdx.x;
   if (id >= 2 * n - 1) return;
   const bool leaf = id >= n - 1;
@@ -224,7 +224,7 @@ __global__ __launch_bounds__(256) void k_emit(int n, const int2* __restrict__ ra
   else { int2 r = range[id]; first = r.x; last = r.y; }
   // number of left turns on the root -> node path
   int lefts = 0, cur = id;
-  for (int guard = 0;; ++guard) {
+  for (int guard = 0; !(dbg & 4); ++guard) {
     const int p = parent[cur];
     if (p == INT32_MIN) break;          // root marker
     if (p >= 0) { ++lefts; cur = p; }   // cur is a left child of p
@@ -234,7 +234,7 @@ __global__ __launch_bounds__(256) void k_emit(int n, const int2* __restrict__ ra
   const uint32_t slot = 2u * (uint32_t)first + (uint32_t)lefts;
   if (slot >= 2u * (uint32_t)n - 1u || last < first || last >= n) { atomicOr(err, ERRF_BUILD_TIMEOUT); return; }   // never with sorted keys
   const uint32_t cnt = (uint32_t)(last - first + 1);
-  Box b = leaf ? seg[first] : seg_query(seg, lv, first, last);
+  Box b = (leaf || (dbg & 256)) ? seg[first] : seg_query(seg, lv, first, last);
   NodeRec nr;
   nr.mnx = b.mnx; nr.mny = b.mny; nr.mnz = b.mnz;
   nr.skip = slot + 2u * cnt - 1u;
@@ -244,7 +244,7 @@ __global__ __launch_bounds__(256) void k_emit(int n, const int2* __restrict__ ra
   nr.tri = cnt <= leaf_max ? first : -1;
   nodes[slot] = nr;
   slot_first[slot] = (uint32_t)first;
-  if (leaf) {
+  if (leaf && !(dbg & 512)) {
     const TriRec r = raw[order[first]];
     tris[first] = r;
     // the vertices alone for the ray walks of the generic Raycast sign: 36 of a record's 96 bytes are all they read, and 4.8 MB of
@@ -252,6 +252,7 @@ __global__ __launch_bounds__(256) void k_emit(int n, const int2* __restrict__ ra
     corners[3 * (size_t)first] = make_float4(r.ax, r.ay, r.az, r.bx);
     corners[3 * (size_t)first + 1] = make_float4(r.by, r.bz, r.cx, r.cy);
     corners[3 * (size_t)first + 2] = make_float4(r.cz, 0.0f, 0.0f, 0.0f);
+    nrm[first] = make_float4(r.nrx, r.nry, r.nrz, 0.0f);   // k_node_ext's first pass
     slot_of[order[first]] = (uint32_t)first;   // input triangle -> its slot in the sorted arrays
     cen[first] = make_float4((r.ax + r.bx + r.cx) * (1.0f / 3.0f), (r.ay + r.by + r.cy) * (1.0f / 3.0f),
                              (r.az + r.bz + r.cz) * (1.0f / 3.0f), 0.0f);
@@ -311,24 +312,66 @@ __device__ __forceinline__ float wave_max(float v) {
 constexpr uint32_t EXT_THREAD_BELOW = 16;   // subtrees up to this many triangles: one THREAD per node
 
 // Serial version of the same computation for small subtrees (most nodes: half of them are leaves).
-__device__ __forceinline__ void node_ext_thread(const NodeRec& nr, uint32_t slot, uint32_t cnt, const uint32_t* __restrict__ slot_first,
-                                                const TriRec* __restrict__ tris, NodeExt* __restrict__ ext) {
-  const uint32_t first = slot_first[slot];
-  // Both loops fetch FOUR triangles before they use the first: the records were written by the kernel before (L2 misses), and a
-  // loop that loads, waits and adds per triangle is a chain of up to 2 x 16 memory round trips — most of this kernel's 41 us for
-  // 100 k triangles.  The sums still run in the order i = 0, 1, 2, ... (a triangle past the count is skipped, not added as zero).
-  float sx = 0.0f, sy = 0.0f, sz = 0.0f;
-  for (uint32_t i0 = 0; i0 < cnt; i0 += 4) {
-    f3 nn[4];
-    for (uint32_t u = 0; u < 4; ++u) {
-      const TriRec& t = tris[first + min(i0 + u, cnt - 1u)];
-      nn[u] = cross3(mk3(t.abx, t.aby, t.abz), mk3(t.acx, t.acy, t.acz));
+// Only the VERTICES of a record are read (its first 48 bytes, three 16-byte loads): the edges b - a, c - a are the same f32 subtractions
+// k_tri_setup stored.
+struct TriVerts { float4 a, b, c; };   // (a, cls) (b, index) (c, pad)
+__device__ __forceinline__ TriVerts load_verts(const TriRec* __restrict__ t) {
+  const float4* q = reinterpret_cast<const float4*>(t);
+  return {q[0], q[1], q[2]};
+}
+__device__ __forceinline__ f3 verts_normal(const TriVerts& v) {
+  return cross3(mk3(v.b.x - v.a.x, v.b.y - v.a.y, v.b.z - v.a.z), mk3(v.c.x - v.a.x, v.c.y - v.a.y, v.c.z - v.a.z));
+}
+// Sum of the raw normals ab x ac of the triangles first + lane, first + lane + STRIDE, ... in that order.  The normals come from `nrm`
+// (k_emit: the value k_tri_setup stored in the record, 16 bytes per triangle in sorted order): one coalesced load per triangle where the
+// record's vertices are three loads 96 bytes apart per lane, so BATCH triangles are in flight at a time.
+template <uint32_t STRIDE, uint32_t BATCH>
+__device__ __forceinline__ void sum_normals(const float4* __restrict__ nrm, uint32_t first, uint32_t cnt, uint32_t lane, float& sx, float& sy, float& sz) {
+  for (uint32_t i0 = lane; i0 < cnt; i0 += BATCH * STRIDE) {
+    float4 n[BATCH];
+#pragma unroll
+    for (uint32_t u = 0; u < BATCH; ++u) n[u] = nrm[first + min(i0 + u * STRIDE, cnt - 1u)];
+#pragma unroll
+    for (uint32_t u = 0; u < BATCH; ++u)
+      if (i0 + u * STRIDE < cnt && fabsf(n[u].x) < 3.0e38f && fabsf(n[u].y) < 3.0e38f && fabsf(n[u].z) < 3.0e38f) { sx += n[u].x; sy += n[u].y; sz += n[u].z; }
+  }
+}
+// Extent of the same triangles along n about c, lateral radius, largest |v - c|^2, from the compact vertex array (48 bytes per
+// triangle): BATCH triangles in flight (a repeated last triangle changes no minimum or maximum).
+template <uint32_t STRIDE, uint32_t BATCH>
+__device__ __forceinline__ void extent_along(const float4* __restrict__ corners, uint32_t first, uint32_t cnt, uint32_t lane, float nx, float ny, float nz,
+                                             float cx, float cy, float cz, float& dlo, float& dhi, float& r2, float& w2max) {
+  for (uint32_t i0 = lane; i0 < cnt; i0 += BATCH * STRIDE) {
+    float4 q0[BATCH], q1[BATCH], q2[BATCH];
+#pragma unroll
+    for (uint32_t u = 0; u < BATCH; ++u) {
+      const float4* q = corners + 3 * (size_t)(first + min(i0 + u * STRIDE, cnt - 1u));
+      q0[u] = q[0]; q1[u] = q[1]; q2[u] = q[2];
     }
-    for (uint32_t u = 0; u < 4; ++u) {
-      const f3 n = nn[u];
-      if (i0 + u < cnt && fabsf(n.x) < 3.0e38f && fabsf(n.y) < 3.0e38f && fabsf(n.z) < 3.0e38f) { sx += n.x; sy += n.y; sz += n.z; }
+#pragma unroll
+    for (uint32_t u = 0; u < BATCH; ++u) {
+      const float vx[3] = {q0[u].x, q0[u].w, q1[u].z}, vy[3] = {q0[u].y, q1[u].x, q1[u].w}, vz[3] = {q0[u].z, q1[u].y, q2[u].x};
+      for (int k = 0; k < 3; ++k) {
+        const float wx = vx[k] - cx, wy = vy[k] - cy, wz = vz[k] - cz;
+        const float tt = nx * wx + ny * wy + nz * wz;
+        const float w2 = wx * wx + wy * wy + wz * wz;
+        dlo = fminf(dlo, tt);
+        dhi = fmaxf(dhi, tt);
+        r2 = fmaxf(r2, w2 - tt * tt);
+        w2max = fmaxf(w2max, w2);
+      }
     }
   }
+}
+
+__device__ __forceinline__ void node_ext_thread(const NodeRec& nr, uint32_t slot, uint32_t cnt, const uint32_t* __restrict__ slot_first,
+                                                const float4* __restrict__ nrm, const float4* __restrict__ corners, NodeExt* __restrict__ ext) {
+  const uint32_t first = slot_first[slot];
+  // The sums run in the order i = 0, 1, 2, ... (a triangle past the count is skipped, not added as zero); all the node's normals are
+  // fetched before the first is used: the records were written by the kernel before (L2 misses), and a loop that loads, waits and adds
+  // per triangle is a chain of up to 2 x 16 memory round trips.  The second loop finds the records' lines on their way.
+  float sx = 0.0f, sy = 0.0f, sz = 0.0f;
+  sum_normals<1, 8>(nrm, first, cnt, 0u, sx, sy, sz);
   const float len = sqrtf(sx * sx + sy * sy + sz * sz);
   float nx = 1.0f, ny = 0.0f, nz = 0.0f;
   if (len > 1.0e-30f && len < 3.0e38f) { nx = sx / len; ny = sy / len; nz = sz / len; }
@@ -338,25 +381,7 @@ __device__ __forceinline__ void node_ext_thread(const NodeRec& nr, uint32_t slot
   if (!(fabsf(cz) < 3.0e38f)) cz = 0.0f;
   const float inf = __builtin_inff();
   float dlo = inf, dhi = -inf, r2 = 0.0f, w2max = 0.0f;
-  for (uint32_t i0 = 0; i0 < cnt; i0 += 4) {
-    float vx[4][3], vy[4][3], vz[4][3];
-    for (uint32_t u = 0; u < 4; ++u) {                    // a repeated last triangle changes no minimum or maximum
-      const TriRec& t = tris[first + min(i0 + u, cnt - 1u)];
-      vx[u][0] = t.ax; vx[u][1] = t.bx; vx[u][2] = t.cx;
-      vy[u][0] = t.ay; vy[u][1] = t.by; vy[u][2] = t.cy;
-      vz[u][0] = t.az; vz[u][1] = t.bz; vz[u][2] = t.cz;
-    }
-    for (uint32_t u = 0; u < 4; ++u)
-      for (int k = 0; k < 3; ++k) {
-        const float wx = vx[u][k] - cx, wy = vy[u][k] - cy, wz = vz[u][k] - cz;
-        const float tt = nx * wx + ny * wy + nz * wz;
-        const float w2 = wx * wx + wy * wy + wz * wz;
-        dlo = fminf(dlo, tt);
-        dhi = fmaxf(dhi, tt);
-        r2 = fmaxf(r2, w2 - tt * tt);
-        w2max = fmaxf(w2max, w2);
-      }
-  }
+  extent_along<1, 4>(corners, first, cnt, 0u, nx, ny, nz, cx, cy, cz, dlo, dhi, r2, w2max);
   const float R = sqrtf(fmaxf(r2, 0.0f) + 1.0e-6f * w2max) * 1.00001f + 1.0e-30f;
   const float e = 1.0e-5f * (fabsf(dlo) + fabsf(dhi)) + 2.0e-6f * sqrtf(w2max) + 1.0e-30f;
   NodeExt x;
@@ -366,12 +391,10 @@ __device__ __forceinline__ void node_ext_thread(const NodeRec& nr, uint32_t slot
   ext[slot] = x;
 }
 
-// One wave per node of more than EXT_THREAD_BELOW triangles.
-__device__ __forceinline__ void node_ext_wave(const NodeRec* __restrict__ nodes, uint32_t slot, int lane, const uint32_t* __restrict__ slot_first,
-                                              const TriRec* __restrict__ tris, NodeExt* __restrict__ ext) {
-  const NodeRec nr = nodes[slot];
-  const uint32_t cnt = (nr.skip - slot + 1u) >> 1;
-  const uint32_t first = slot_first[slot];
+// One wave per node of more than EXT_THREAD_BELOW triangles.  A lane takes the triangles lane, lane + 64, ... in that order (the sums are
+// pinned by the golden trees).
+__device__ __forceinline__ void node_ext_wave(const NodeRec& nr, uint32_t slot, uint32_t first, uint32_t cnt, int lane,
+                                              const float4* __restrict__ nrm, const float4* __restrict__ corners, NodeExt* __restrict__ ext) {
   float cx = 0.5f * (nr.mnx + nr.mxx), cy = 0.5f * (nr.mny + nr.mxy), cz = 0.5f * (nr.mnz + nr.mxz);
   if (!(fabsf(cx) < 3.0e38f)) cx = 0.0f;
   if (!(fabsf(cy) < 3.0e38f)) cy = 0.0f;
@@ -389,30 +412,14 @@ __device__ __forceinline__ void node_ext_wave(const NodeRec* __restrict__ nodes,
     return;
   }
   float sx = 0.0f, sy = 0.0f, sz = 0.0f;
-  for (uint32_t i = lane; i < cnt; i += 64) {
-    const TriRec t = tris[first + i];
-    const f3 n = cross3(mk3(t.bx - t.ax, t.by - t.ay, t.bz - t.az), mk3(t.cx - t.ax, t.cy - t.ay, t.cz - t.az));
-    if (fabsf(n.x) < 3.0e38f && fabsf(n.y) < 3.0e38f && fabsf(n.z) < 3.0e38f) { sx += n.x; sy += n.y; sz += n.z; }
-  }
+  sum_normals<64, 8>(nrm, first, cnt, (uint32_t)lane, sx, sy, sz);
   sx = wave_sum(sx); sy = wave_sum(sy); sz = wave_sum(sz);
   float len = sqrtf(sx * sx + sy * sy + sz * sz);
   float nx = 1.0f, ny = 0.0f, nz = 0.0f;
   if (len > 1.0e-30f && len < 3.0e38f) { nx = sx / len; ny = sy / len; nz = sz / len; }
   const float inf = __builtin_inff();
   float dlo = inf, dhi = -inf, r2 = 0.0f, w2max = 0.0f;
-  for (uint32_t i = lane; i < cnt; i += 64) {
-    const TriRec t = tris[first + i];
-    const float vx[3] = {t.ax, t.bx, t.cx}, vy[3] = {t.ay, t.by, t.cy}, vz[3] = {t.az, t.bz, t.cz};
-    for (int k = 0; k < 3; ++k) {
-      const float wx = vx[k] - cx, wy = vy[k] - cy, wz = vz[k] - cz;
-      const float tt = nx * wx + ny * wy + nz * wz;
-      const float w2 = wx * wx + wy * wy + wz * wz;
-      dlo = fminf(dlo, tt);
-      dhi = fmaxf(dhi, tt);
-      r2 = fmaxf(r2, w2 - tt * tt);
-      w2max = fmaxf(w2max, w2);
-    }
-  }
+  extent_along<64, 4>(corners, first, cnt, (uint32_t)lane, nx, ny, nz, cx, cy, cz, dlo, dhi, r2, w2max);
   dlo = wave_min(dlo); dhi = wave_max(dhi); r2 = wave_max(r2); w2max = wave_max(w2max);
   if (lane == 0) {
     // outward rounding: l^2 = w^2 - t^2 cancels, so widen by a few ulps of w^2 before the sqrt
@@ -428,9 +435,13 @@ __device__ __forceinline__ void node_ext_wave(const NodeRec* __restrict__ nodes,
 
 // Both in one launch: a thread per small node; the few larger nodes among a block's 256 slots are queued in LDS and taken by the
 // block's four waves afterwards.  (Two launches before — one thread per node, then one WAVE per node of which 94 % returned at once:
-// 16 + 37 us of the build's critical path for 100 k triangles.)
+// 16 + 37 us of the build's critical path for 100 k triangles.  Measured in round 5 and not kept: the large nodes found by internal
+// node id in extra workgroups, spread evenly instead of a root-to-leaf spine per workgroup — 30.3 against 29.7 us at 100 k triangles,
+// 206 against 189 at 1 M (the locality of a workgroup's own slots is worth more); eight waves per workgroup with the two parts side
+// by side — 35.7 us.)
 __global__ __launch_bounds__(256) void k_node_ext(const NodeRec* __restrict__ nodes, const uint32_t* __restrict__ slot_first,
-                                                  const TriRec* __restrict__ tris, uint32_t n_nodes, NodeExt* __restrict__ ext) {
+                                                  const float4* __restrict__ nrm, const float4* __restrict__ corners, uint32_t n_nodes, NodeExt* __restrict__ ext,
+                                                  int dbg) {
   __shared__ uint32_t big[256];
   __shared__ uint32_t n_big;
   if (threadIdx.x == 0) n_big = 0;
@@ -439,12 +450,15 @@ __global__ __launch_bounds__(256) void k_node_ext(const NodeRec* __restrict__ no
   if (slot < n_nodes) {
     const NodeRec nr = nodes[slot];
     const uint32_t cnt = (nr.skip - slot + 1u) >> 1;
-    if (cnt <= EXT_THREAD_BELOW) node_ext_thread(nr, slot, cnt, slot_first, tris, ext);
-    else big[atomicAdd(&n_big, 1u)] = slot;
+    if (cnt <= EXT_THREAD_BELOW) { if (!(dbg & 2)) node_ext_thread(nr, slot, cnt, slot_first, nrm, corners, ext); }
+    else if (!(dbg & 1)) big[atomicAdd(&n_big, 1u)] = slot;
   }
   __syncthreads();
   const uint32_t nb = n_big;
-  for (uint32_t k = threadIdx.x >> 6; k < nb; k += 4u) node_ext_wave(nodes, big[k], (int)(threadIdx.x & 63u), slot_first, tris, ext);
+  for (uint32_t k = threadIdx.x >> 6; k < nb; k += 4u) {
+    const NodeRec nr = nodes[big[k]];
+    node_ext_wave(nr, big[k], slot_first[big[k]], (nr.skip - big[k] + 1u) >> 1, (int)(threadIdx.x & 63u), nrm, corners, ext);
+  }
 }
 
 // ---- treelet pass ---------------------------------------------------------------------------------------
@@ -470,32 +484,56 @@ __device__ __forceinline__ int adjacent_prefix(const uint64_t* __restrict__ keys
   return a == b ? 64 + __clz((uint32_t)j ^ (uint32_t)(j + 1)) : __clzll((long long)(a ^ b));
 }
 __global__ __launch_bounds__(256) void k_roots_from_keys(const uint64_t* __restrict__ keys, int n, int2* __restrict__ roots,
-                                                         int* __restrict__ n_roots) {
-  constexpr int HALO = TREELET_MAX + 2;
-  __shared__ int s_d[256 + 2 * HALO];
+                                                         int* __restrict__ n_roots, int dbg) {
+  // One thread per SPLIT j (between the positions j and j + 1): the node that splits there reaches from the nearest smaller adjacent
+  // prefix on its left (exclusive) to the nearest smaller one on its right (inclusive).  Both are found by descending a table of
+  // range minima over the block's window of prefixes (seven dependent LDS reads each; a flat loop that let the neighbours join one
+  // by one took up to 64 x 2 and 13 of this kernel's 18 us).  The node is a treelet root iff it holds 3 .. TREELET_MAX triangles and its
+  // parent — the node that splits at the larger of its two boundaries — holds more than TREELET_MAX.
+  constexpr int HALO = 2 * TREELET_MAX + 2, WIN = 256 + 2 * HALO, LEVELS = 7;   // searches go 64 from j, then 65 from the parent's split
+  __shared__ int s_m[LEVELS][WIN];   // s_m[k][i] = min d[i .. i + 2^k - 1]; beyond the window: -2
   __shared__ int s_wcnt[4], s_base;
   const int base = blockIdx.x * 256, lo = base - HALO;
-  for (int t = threadIdx.x; t < 256 + 2 * HALO; t += 256) s_d[t] = adjacent_prefix(keys, n, lo + t);
+  for (int t = threadIdx.x; t < WIN; t += 256) s_m[0][t] = adjacent_prefix(keys, n, lo + t);
   __syncthreads();
-  const int p = base + (int)threadIdx.x;
-  bool is_root = false;
-  int l = p, r = p;
-  if (p < n) {
-    // ONE flat loop, one neighbour per step (nested "extend while the prefix stays >= c" loops cost 74 us: in lockstep a wave pays
-    // the longest extension of any lane at every level).  The neighbours join in the order of their prefix with p — the running minimum
-    // of the adjacent prefixes towards them, non-increasing on either side — so the two sides are merged like two sorted lists; a
-    // node is complete whenever the next candidate's prefix is smaller than the last one taken.
-    int kl = 0, kr = 0;                                           // neighbours taken on the left / right
-    int ml = s_d[p - 1 - lo], mr = s_d[p - lo];                  // prefix at which the next one on either side would join
-    while (kl + kr + 1 < TREELET_MAX + 1) {
-      const int v = max(ml, mr);
-      if (v < 0) break;                                           // nobody left: [l, r] is the whole array
-      if (kl + kr + 1 == TREELET_MAX) break;                     // the next node up would hold more than TREELET_MAX
-      if (ml >= mr) { ++kl; ml = min(ml, s_d[p - kl - 1 - lo]); }
-      else { ++kr; mr = min(mr, s_d[p + kr - lo]); }
-      if (max(ml, mr) < v) { l = p - kl; r = p + kr; }           // that level is complete: a node
+  for (int k = 1; k < LEVELS; ++k) {
+    const int h = 1 << (k - 1);
+    for (int t = threadIdx.x; t < WIN; t += 256) s_m[k][t] = t + h < WIN ? min(s_m[k - 1][t], s_m[k - 1][t + h]) : -2;
+    __syncthreads();
+  }
+  auto right_of = [&](int i, int v) {   // first window index > i whose prefix is < v (WIN: none within reach)
+    int pos = i + 1;
+#pragma unroll
+    for (int k = LEVELS - 1; k >= 0; --k)
+      if (pos < WIN && s_m[k][pos] >= v) pos += 1 << k;
+    return min(pos, WIN);
+  };
+  auto left_of = [&](int i, int v) {    // last window index < i whose prefix is < v (-1: none within reach)
+    int pos = i - 1;
+#pragma unroll
+    for (int k = LEVELS - 1; k >= 0; --k) {
+      const int from = pos - (1 << k) + 1;
+      if (from >= 0 && s_m[k][from] >= v) pos = from - 1;
     }
-    is_root = l == p && r - l + 1 >= 3;
+    return max(pos, -1);
+  };
+  const int j = base + (int)threadIdx.x, w = j - lo;
+  bool is_root = false;
+  int first = 0, size = 0;
+  if (j < n - 1 && !(dbg & 8)) {
+    const int v = s_m[0][w];
+    const int R = right_of(w, v), L = left_of(w, v);
+    size = R - L;
+    if (size >= 3 && size <= TREELET_MAX && L >= 0 && R < WIN) {
+      const int dl = s_m[0][L], dr = s_m[0][R];
+      is_root = true;
+      if (dl >= 0 || dr >= 0) {                                   // not the whole array: the parent splits at the larger boundary
+        const int q = dl > dr ? L : R, vq = max(dl, dr);
+        const int Rq = right_of(q, vq), Lq = left_of(q, vq);
+        is_root = Lq < 0 || Rq >= WIN || Rq - Lq > TREELET_MAX;
+      }
+      first = lo + L + 1;
+    }
   }
   const unsigned long long bal = __ballot(is_root);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -508,8 +546,8 @@ __global__ __launch_bounds__(256) void k_roots_from_keys(const uint64_t* __restr
   __syncthreads();
   if (is_root) {
     int off = s_base + (int)__popcll(bal & ((1ull << lane) - 1ull));
-    for (int w = 0; w < wave; ++w) off += s_wcnt[w];
-    roots[off] = make_int2(l, r - l + 1);
+    for (int w2 = 0; w2 < wave; ++w2) off += s_wcnt[w2];
+    roots[off] = make_int2(first, size);
   }
 }
 
@@ -564,7 +602,7 @@ __device__ __forceinline__ float seg_suffix(float v, int lane, int e) {
 
 __global__ __launch_bounds__(64) void k_treelet_lanes(const int2* __restrict__ roots, const int* __restrict__ n_roots,
                                                       const Box* __restrict__ boxes, uint64_t* __restrict__ keys,
-                                                      uint32_t* __restrict__ order) {
+                                                      uint32_t* __restrict__ order, int dbg) {
   // a few thousand single-wave blocks take the roots in turn (one block per POSSIBLE root — n / 3 of them, nine in ten with
   // nothing to do — spent more time being dispatched than the treelets took)
   const int total = *n_roots, lane = threadIdx.x;
@@ -584,7 +622,7 @@ __global__ __launch_bounds__(64) void k_treelet_lanes(const int2* __restrict__ r
   uint64_t code = 0;
   int depth = 0;
   const float inf = __builtin_inff();
-  for (int level = 0; level < 64; ++level) {
+  for (int level = 0; level < ((dbg & 128) ? 1 : 64); ++level) {
     const bool open = live && e - s > 1 && depth < room;
     if (__ballot(open) == 0ull) break;
     // widest axis of the centres of my segment
@@ -841,7 +879,7 @@ size_t bvh_workspace_bytes(size_t n_tris) {
   (void)rocprim::radix_sort_pairs(nullptr, sort_tmp, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr,
                             (uint32_t*)nullptr, n, 0, 64, (hipStream_t)0);
   size_t b = AUX_WORDS * 4 + 256;
-  b += n * 48 + 256 + n * sizeof(TriRec) * 2 + n * 16 + 256 + n * 16 + 256 + n * 4 + 256 + n * sizeof(TriPlanes) + 256 + n * sizeof(Box) * 3 + n * (8 + 4) * 2 + sort_tmp;
+  b += n * 48 + 256 + n * sizeof(TriRec) * 2 + n * 16 + 256 + n * 16 + 256 + n * 16 + 256 + n * 4 + 256 + n * sizeof(TriPlanes) + 256 + n * sizeof(Box) * 3 + n * (8 + 4) * 2 + sort_tmp;
   b += n * (sizeof(int2) * 2) + 2 * n * sizeof(int) + 2 * n * sizeof(NodeRec) + 2 * n * (sizeof(NodeExt) + 4);
   return b + 64 * 256 + 4096 + 24 * ((n + 255) / 256) + 256 + sample_sort_bytes(n);
 }
@@ -878,6 +916,7 @@ int build_device_mesh(Arena& ws, hipStream_t st, const float* d_verts, size_t n_
   uint32_t* slot_of = ws.take<uint32_t>(n_tris);
   TriPlanes* planes = ws.take<TriPlanes>(n_tris);
   float4* corners = ws.take<float4>(3 * n_tris);
+  float4* nrm = ws.take<float4>(n_tris);
   Box* boxes = ws.take<Box>(n_tris);
   Box* seg = ws.take<Box>(2 * n_tris + 64);
   uint64_t* keys = ws.take<uint64_t>(n_tris);
@@ -909,7 +948,7 @@ int build_device_mesh(Arena& ws, hipStream_t st, const float* d_verts, size_t n_
     }
   }
   if (!raw || !tris || !boxes || !seg || !keys || !keys2 || !vals || !order || !range || !child || !parent || !nodes ||
-      !scene || !tmp || !ext || !aux || !cen_raw || !slot_of || !slot_first || !cen || !planes || !corners) {
+      !scene || !tmp || !ext || !aux || !cen_raw || !slot_of || !slot_first || !cen || !planes || !corners || !nrm) {
     set_error("internal: BVH workspace too small");
     return M2S_ERR_HIP_INTERNAL;
   }
@@ -960,8 +999,8 @@ int build_device_mesh(Arena& ws, hipStream_t st, const float* d_verts, size_t n_
   if (n > 2 && (treelets > 0 || (treelets < 0 && !skip_treelets))) {
     // treelet pass: the nodes of at most TREELET_MAX triangles are rebuilt by sweep splits (their keys rewritten), then the hierarchy is derived
     int2* roots = reinterpret_cast<int2*>(child);   // child[] is not used by the kernels below before k_karras rewrites it
-    hipLaunchKernelGGL(k_roots_from_keys, dim3(cdiv(n_tris, B)), dim3(B), 0, st, (const uint64_t*)keys2, n, roots, scene + 7);
-    hipLaunchKernelGGL(k_treelet_lanes, dim3((unsigned)std::min<size_t>((n_tris + 2) / 3, 8192)), dim3(64), 0, st, roots, scene + 7, boxes, keys2, order);
+    hipLaunchKernelGGL(k_roots_from_keys, dim3(cdiv(n_tris, B)), dim3(B), 0, st, (const uint64_t*)keys2, n, roots, scene + 7, tuning().dbg_skip);
+    hipLaunchKernelGGL(k_treelet_lanes, dim3((unsigned)std::min<size_t>((n_tris + 2) / 3, 8192)), dim3(64), 0, st, roots, scene + 7, boxes, keys2, order, tuning().dbg_skip);
   }
   if (n > 1) hipLaunchKernelGGL(k_karras, dim3(cdiv(n_tris - 1, B)), dim3(B), 0, st, keys2, n, range, child, parent);
 
@@ -980,9 +1019,9 @@ int build_device_mesh(Arena& ws, hipStream_t st, const float* d_verts, size_t n_
   }
   hipLaunchKernelGGL(k_seg_build, dim3(cdiv(n_tris, 512)), dim3(B), 0, st, (const Box*)boxes, (const uint32_t*)order, (uint32_t)n_tris, seg, lv, aux);
   hipLaunchKernelGGL(k_emit, dim3(cdiv(2 * n_tris - 1, B)), dim3(B), 0, st, n, range, parent, seg, lv, order, raw,
-                     nodes, tris, slot_first, cen, planes, leaf_max, slot_of, corners, d_err);
-  hipLaunchKernelGGL(k_node_ext, dim3(cdiv(2 * n_tris - 1, B)), dim3(B), 0, st, nodes, slot_first, tris,
-                     (uint32_t)(2 * n_tris - 1), ext);
+                     nodes, tris, slot_first, cen, planes, leaf_max, slot_of, corners, nrm, d_err, tuning().dbg_skip);
+  hipLaunchKernelGGL(k_node_ext, dim3(cdiv(2 * n_tris - 1, B)), dim3(B), 0, st, nodes, slot_first, (const float4*)nrm, (const float4*)corners,
+                     (uint32_t)(2 * n_tris - 1), ext, tuning().dbg_skip);
   M2S_HIP_CHECK(hipGetLastError());
   out->tris = tris;
   out->slot_first = slot_first;
