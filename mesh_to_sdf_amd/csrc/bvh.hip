@@ -62,14 +62,9 @@ __global__ __launch_bounds__(256) void k_tri_setup(const float* __restrict__ ver
                                                    uint32_t n_tris, TriRec* __restrict__ raw, Box* __restrict__ boxes,
                                                    float4* __restrict__ cen_raw,
                                                    int* __restrict__ scene /*final values, then 6 per block from part_base on*/, int part_base,
-                                                   int* __restrict__ err, uint32_t* __restrict__ aux, uint32_t aux_words, int* __restrict__ parent) {
+                                                   int* __restrict__ err, uint32_t* __restrict__ aux, uint32_t aux_words) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  // the build's counters, and the "no parent" marker of the root (internal node 0, or the only leaf): every other node's entry is
-  // written by k_karras before k_emit reads it
-  if (aux && blockIdx.x == 0) {
-    if (threadIdx.x < aux_words) aux[threadIdx.x] = 0u;
-    if (threadIdx.x == 0) parent[0] = INT32_MIN;
-  }
+  if (aux && blockIdx.x == 0 && threadIdx.x < aux_words) aux[threadIdx.x] = 0u;   // the build's counters
   int lo[3] = {INT32_MAX, INT32_MAX, INT32_MAX}, hi[3] = {INT32_MIN, INT32_MIN, INT32_MIN};
   if (t < n_tris) {
     const size_t base = topology == 0 ? (size_t)t * 3 : (size_t)t;  // list: tuples(); strip: tuple_windows()
@@ -145,11 +140,9 @@ __device__ __forceinline__ int delta(const uint64_t* __restrict__ keys, int n, i
   return __clzll((long long)(a ^ b));
 }
 
-// Node ids: internal i in [0, n-2], leaf k -> (n-1) + k.
-__global__ __launch_bounds__(256) void k_karras(const uint64_t* __restrict__ keys, int n, int2* __restrict__ range,
-                                                int2* __restrict__ child, int* __restrict__ parent) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n - 1) return;
+// Node ids: internal i in [0, n-2], leaf k -> (n-1) + k.  Only the RANGE of a node is derived (its direction and the far end of its
+// keys): k_emit places a node by its range alone (see Recs below), so nobody needs children or parents.
+__device__ __forceinline__ void karras_range(const uint64_t* __restrict__ keys, int n, int i, int2* __restrict__ range) {
   const int d = (delta(keys, n, i, i + 1) - delta(keys, n, i, i - 1)) >= 0 ? 1 : -1;
   const int dmin = delta(keys, n, i, i - d);
   int lmax = 2;
@@ -158,21 +151,35 @@ __global__ __launch_bounds__(256) void k_karras(const uint64_t* __restrict__ key
   for (int t = lmax >> 1; t >= 1; t >>= 1)
     if (delta(keys, n, i, i + (l + t) * d) > dmin) l += t;
   const int j = i + l * d;
-  const int dnode = delta(keys, n, i, j);
-  int s = 0;
-  for (int t = (l + 1) >> 1;; t = (t + 1) >> 1) {
-    if (delta(keys, n, i, i + (s + t) * d) > dnode) s += t;
-    if (t <= 1) break;
-  }
-  const int gamma = i + s * d + min(d, 0);
-  const int first = min(i, j), last = max(i, j);
-  const int left = (first == gamma) ? (n - 1) + gamma : gamma;
-  const int right = (last == gamma + 1) ? (n - 1) + gamma + 1 : gamma + 1;
-  range[i] = make_int2(first, last);
-  child[i] = make_int2(left, right);
-  parent[left] = i;
-  parent[right] = -i - 2;  // negative: "I am a right child of i"  (root keeps its initial marker)
+  range[i] = make_int2(min(i, j), max(i, j));
 }
+
+// ---- where a node sits in pre-order, without walking to the root --------------------------------------------------------------
+// The pre-order slot of a node with the keys [first, last] is 2 * first + (left turns on the way down from the root).  Going UP from
+// the node, its nearest ancestor that has it in the LEFT subtree is the node that splits between `last` and `last + 1`; that
+// ancestor's own last key is the next position to the right whose adjacent prefix d[] is SMALLER than d[last], and so on: the left
+// turns are the prefix-minimum RECORDS of d[last], d[last + 1], ..., d[n - 2] — a function of `last` alone.  d[] takes values in
+// [0, 96), so the records of an interval are a 96-bit set, and two adjacent intervals combine as
+//     records(I J) = records(I)  |  (records(J) & bits below the smallest of I)
+// k_hierarchy scans these sets from the right inside every block of 512 positions and over the blocks; k_emit reads two of them.
+// (Round 4 counted the left turns by chasing parent links: ~25 dependent loads per node.)
+struct Recs { uint64_t lo; uint32_t hi; };
+__device__ __forceinline__ Recs recs_of(int d) {
+  Recs r = {0ull, 0u};
+  if (d >= 64) r.hi = 1u << (d - 64);
+  else if (d >= 0) r.lo = 1ull << d;
+  return r;
+}
+__device__ __forceinline__ Recs recs_join(Recs a, Recs b) {   // a: the left interval
+  uint64_t mlo = ~0ull;
+  uint32_t mhi = ~0u;
+  if (a.lo) { mlo = (a.lo & (0ull - a.lo)) - 1ull; mhi = 0u; }
+  else if (a.hi) { mhi = (a.hi & (0u - a.hi)) - 1u; }
+  return {a.lo | (b.lo & mlo), a.hi | (b.hi & mhi)};
+}
+__device__ __forceinline__ uint4 recs_pack(Recs r) { return make_uint4((uint32_t)r.lo, (uint32_t)(r.lo >> 32), r.hi, 0u); }
+__device__ __forceinline__ Recs recs_unpack(uint4 v) { return {(uint64_t)v.x | ((uint64_t)v.y << 32), v.z}; }
+constexpr uint32_t RECS_BLOCK = 512;   // positions per block of k_hierarchy's segment-tree part
 
 __device__ __forceinline__ Box box_union(Box a, Box b) {
   return {fminf(a.mnx, b.mnx), fminf(a.mny, b.mny), fminf(a.mnz, b.mnz),
@@ -209,7 +216,7 @@ __device__ __forceinline__ void set_slab(NodeExt& x, float lo, float hi) {
 
 // One thread per node (internal 0..n-2, leaves n-1..2n-2): pre-order slot, box, skip link,
 // and for leaves the sorted triangle record.
-__global__ __launch_bounds__(256) void k_emit(int n, const int2* __restrict__ range, const int* __restrict__ parent,
+__global__ __launch_bounds__(256) void k_emit(int n, const int2* __restrict__ range, const uint4* __restrict__ recs_local, const uint4* __restrict__ recs_carry,
                                               const Box* __restrict__ seg, SegLevels lv,
                                               const uint32_t* __restrict__ order, const TriRec* __restrict__ raw,
                                               NodeRec* __restrict__ nodes, TriRec* __restrict__ tris,
@@ -222,14 +229,11 @@ __global__ __launch_bounds__(256) void k_emit(int n, const int2* __restrict__ ra
   int first, last;
   if (leaf) { first = last = id - (n - 1); }
   else { int2 r = range[id]; first = r.x; last = r.y; }
-  // number of left turns on the root -> node path
-  int lefts = 0, cur = id;
-  for (int guard = 0; !(dbg & 4); ++guard) {
-    const int p = parent[cur];
-    if (p == INT32_MIN) break;          // root marker
-    if (p >= 0) { ++lefts; cur = p; }   // cur is a left child of p
-    else cur = -p - 2;                  // right child
-    if (guard > 256) { atomicOr(err, ERRF_BUILD_TIMEOUT); return; }   // a radix tree over 64 + 32 key bits is at most 96 deep: only garbage keys get here
+  // number of left turns on the root -> node path: the prefix-minimum records of d[last ..] (Recs above)
+  int lefts = 0;
+  if (!(dbg & 4) && last >= 0 && last < n) {
+    const Recs r = recs_join(recs_unpack(recs_local[last]), recs_unpack(recs_carry[(uint32_t)last / RECS_BLOCK]));
+    lefts = __popcll(r.lo) + __popc(r.hi);
   }
   const uint32_t slot = 2u * (uint32_t)first + (uint32_t)lefts;
   if (slot >= 2u * (uint32_t)n - 1u || last < first || last >= n) { atomicOr(err, ERRF_BUILD_TIMEOUT); return; }   // never with sorted keys
@@ -793,20 +797,55 @@ __global__ __launch_bounds__(KEY_THREADS) void k_morton_keys(const Box* __restri
   }
 }
 
-// Segment tree of the leaf boxes in two steps inside ONE launch: every block builds the levels 0..SEG_LOCAL of its 512 leaves in
-// LDS, and the block that finishes last (a ticket behind a device-scope fence) adds the levels above from the blocks' tops.
-// Unions are min / max: any order gives the same boxes.
+// One launch, two independent jobs over the final keys and order (after the treelet pass):
+//  * workgroups [0, seg_blocks): the segment tree of the leaf boxes in two steps — every block builds the levels 0..SEG_LOCAL of its
+//    512 leaves in LDS, and the block that finishes last (a ticket behind a device-scope fence) adds the levels above from the blocks'
+//    tops (unions are min / max: any order gives the same boxes) — and the prefix-minimum record sets of the adjacent prefixes (Recs
+//    above): scanned from the right inside the block's 512 positions (recs_local), the block's total handed to the last block, which
+//    scans the totals from the right over the blocks (recs_carry[b] = the records of everything right of block b);
+//  * the others: the Karras ranges of the internal nodes, one thread each.
+// (Round 4: k_karras, then k_seg_build — 15.5 + 11.3 us at 100 k triangles, neither filling the chip.)
 constexpr int SEG_LOCAL = 9;
-__global__ __launch_bounds__(256) void k_seg_build(const Box* __restrict__ boxes, const uint32_t* __restrict__ order, uint32_t n,
-                                                   Box* __restrict__ seg, SegLevels lv, uint32_t* __restrict__ done) {
+__global__ __launch_bounds__(256) void k_hierarchy(const Box* __restrict__ boxes, const uint32_t* __restrict__ order, uint32_t n,
+                                                   Box* __restrict__ seg, SegLevels lv, uint32_t* __restrict__ done, uint32_t seg_blocks,
+                                                   const uint64_t* __restrict__ keys, int2* __restrict__ range,
+                                                   uint4* __restrict__ recs_local, uint4* __restrict__ recs_total, uint4* __restrict__ recs_carry) {
+  if (blockIdx.x >= seg_blocks) {
+    const int i = (int)((blockIdx.x - seg_blocks) * 256u + threadIdx.x);
+    if (i < (int)n - 1) karras_range(keys, (int)n, i, range);
+    return;
+  }
   __shared__ Box s[1024], s2[512];
+  __shared__ uint4 s_r[2][RECS_BLOCK];
   __shared__ bool s_last;
   const uint32_t t = threadIdx.x, leaf0 = blockIdx.x * 512u;
   for (uint32_t k = t; k < 512u; k += 256u) {
     const uint32_t i = leaf0 + k;
     if (i < n) { const Box b = boxes[order[i]]; s[k] = b; seg[i] = b; }
+    s_r[0][k] = recs_pack(recs_of(adjacent_prefix(keys, (int)n, (int)i)));   // -1 (no bit) from the last position on
   }
   __syncthreads();
+  // records of [k, 512) inside the block: log-step scan from the right, ping-pong
+  int cur = 0;
+  for (uint32_t h = 1; h < RECS_BLOCK; h <<= 1) {
+    for (uint32_t k = t; k < RECS_BLOCK; k += 256u) {
+      const Recs a = recs_unpack(s_r[cur][k]);
+      s_r[cur ^ 1][k] = k + h < RECS_BLOCK ? recs_pack(recs_join(a, recs_unpack(s_r[cur][k + h]))) : s_r[cur][k];
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+  for (uint32_t k = t; k < RECS_BLOCK; k += 256u)
+    if (leaf0 + k < n) recs_local[leaf0 + k] = s_r[cur][k];
+  const bool single = lv.levels <= SEG_LOCAL + 1;           // one block: it is its own "last block"
+  if (t == 0 && !single) {
+    uint32_t* dst = reinterpret_cast<uint32_t*>(recs_total + blockIdx.x);
+    const uint4 v = s_r[cur][0];
+    __hip_atomic_store(dst + 0, v.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(dst + 1, v.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(dst + 2, v.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (single && t == 0) recs_carry[0] = make_uint4(0u, 0u, 0u, 0u);
   for (int l = 1; l <= SEG_LOCAL && l < lv.levels; ++l) {
     const uint32_t m = 512u >> l, gj = (leaf0 >> l) + t;
     Box u{};
@@ -829,13 +868,49 @@ __global__ __launch_bounds__(256) void k_seg_build(const Box* __restrict__ boxes
     }
     __syncthreads();
   }
-  if (lv.levels <= SEG_LOCAL + 1) return;
+  if (single) return;
   if (t == 0) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    s_last = __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u;
+    s_last = __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == seg_blocks - 1u;
   }
   __syncthreads();
   if (!s_last) return;
+  // ---- the last block: the record sets right of every block, chunks of RECS_BLOCK blocks from the right
+  {
+    Recs right = {0ull, 0u};                                 // records of everything right of the current chunk
+    for (int c0 = (int)((seg_blocks - 1u) / RECS_BLOCK * RECS_BLOCK); c0 >= 0; c0 -= (int)RECS_BLOCK) {
+      for (uint32_t k = t; k < RECS_BLOCK; k += 256u) {
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if ((uint32_t)c0 + k < seg_blocks) {
+          const uint32_t* src = reinterpret_cast<const uint32_t*>(recs_total + c0 + k);
+          v.x = __hip_atomic_load(src + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          v.y = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          v.z = __hip_atomic_load(src + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        s_r[0][k] = v;
+      }
+      __syncthreads();
+      int cu = 0;
+      for (uint32_t h = 1; h < RECS_BLOCK; h <<= 1) {
+        for (uint32_t k = t; k < RECS_BLOCK; k += 256u) {
+          const Recs a = recs_unpack(s_r[cu][k]);
+          s_r[cu ^ 1][k] = k + h < RECS_BLOCK ? recs_pack(recs_join(a, recs_unpack(s_r[cu][k + h]))) : s_r[cu][k];
+        }
+        __syncthreads();
+        cu ^= 1;
+      }
+      // s_r[cu][k] = records of the blocks [c0 + k, end of chunk); block c0 + k wants the blocks right of it
+      for (uint32_t k = t; k < RECS_BLOCK; k += 256u)
+        if ((uint32_t)c0 + k < seg_blocks) {
+          Recs in_chunk = {0ull, 0u};
+          if (k + 1u < RECS_BLOCK) in_chunk = recs_unpack(s_r[cu][k + 1u]);
+          recs_carry[c0 + k] = recs_pack(recs_join(in_chunk, right));
+        }
+      const Recs whole = recs_join(recs_unpack(s_r[cu][0]), right);
+      __syncthreads();
+      right = whole;
+    }
+  }
   auto load_top = [&](uint32_t j) {          // level SEG_LOCAL, written by other blocks: read past this XCD's L2
     const uint32_t* src = reinterpret_cast<const uint32_t*>(seg + lv.off[SEG_LOCAL] + j);
     float f[6];
@@ -880,7 +955,7 @@ size_t bvh_workspace_bytes(size_t n_tris) {
                             (uint32_t*)nullptr, n, 0, 64, (hipStream_t)0);
   size_t b = AUX_WORDS * 4 + 256;
   b += n * 48 + 256 + n * sizeof(TriRec) * 2 + n * 16 + 256 + n * 16 + 256 + n * 16 + 256 + n * 4 + 256 + n * sizeof(TriPlanes) + 256 + n * sizeof(Box) * 3 + n * (8 + 4) * 2 + sort_tmp;
-  b += n * (sizeof(int2) * 2) + 2 * n * sizeof(int) + 2 * n * sizeof(NodeRec) + 2 * n * (sizeof(NodeExt) + 4);
+  b += n * (sizeof(int2) * 2) + n * 16 + 2 * (n / 512 + 2) * 16 + 768 + 2 * n * sizeof(NodeRec) + 2 * n * (sizeof(NodeExt) + 4);
   return b + 64 * 256 + 4096 + 24 * ((n + 255) / 256) + 256 + sample_sort_bytes(n);
 }
 
@@ -925,7 +1000,9 @@ int build_device_mesh(Arena& ws, hipStream_t st, const float* d_verts, size_t n_
   uint32_t* order = ws.take<uint32_t>(n_tris);
   int2* range = ws.take<int2>(n_tris);
   int2* child = ws.take<int2>(n_tris);
-  int* parent = ws.take<int>(2 * n_tris);
+  uint4* recs_local = ws.take<uint4>(n_tris);
+  uint4* recs_total = ws.take<uint4>((n_tris + RECS_BLOCK - 1) / RECS_BLOCK);
+  uint4* recs_carry = ws.take<uint4>((n_tris + RECS_BLOCK - 1) / RECS_BLOCK);
   NodeRec* nodes = ws.take<NodeRec>(2 * n_tris);
   NodeExt* ext = ws.take<NodeExt>(2 * n_tris);
   uint32_t* slot_first = ws.take<uint32_t>(2 * n_tris);
@@ -947,7 +1024,7 @@ int build_device_mesh(Arena& ws, hipStream_t st, const float* d_verts, size_t n_
       return M2S_ERR_HIP_INTERNAL;
     }
   }
-  if (!raw || !tris || !boxes || !seg || !keys || !keys2 || !vals || !order || !range || !child || !parent || !nodes ||
+  if (!raw || !tris || !boxes || !seg || !keys || !keys2 || !vals || !order || !range || !child || !recs_local || !recs_total || !recs_carry || !nodes ||
       !scene || !tmp || !ext || !aux || !cen_raw || !slot_of || !slot_first || !cen || !planes || !corners || !nrm) {
     set_error("internal: BVH workspace too small");
     return M2S_ERR_HIP_INTERNAL;
@@ -961,7 +1038,7 @@ int build_device_mesh(Arena& ws, hipStream_t st, const float* d_verts, size_t n_
   leaf_max = std::min(std::max(leaf_max, 1u), 16u);
   out->leaf_max = leaf_max;
   hipLaunchKernelGGL(k_tri_setup, dim3(cdiv(n_tris, B)), dim3(B), 0, st, d_verts, (uint32_t)n_verts, d_indices,
-                     index_bytes, topology, (uint32_t)n_tris, raw, boxes, cen_raw, scene, 8, d_err, records_only ? nullptr : aux, (uint32_t)AUX_WORDS, parent);
+                     index_bytes, topology, (uint32_t)n_tris, raw, boxes, cen_raw, scene, 8, d_err, records_only ? nullptr : aux, (uint32_t)AUX_WORDS);
   if (records_only) {
     // a tiny problem (grid_is_tiny): all voxels x all triangles needs the triangle records and nothing else — no keys, no sort, no tree
     M2S_HIP_CHECK(hipGetLastError());
@@ -1002,7 +1079,6 @@ int build_device_mesh(Arena& ws, hipStream_t st, const float* d_verts, size_t n_
     hipLaunchKernelGGL(k_roots_from_keys, dim3(cdiv(n_tris, B)), dim3(B), 0, st, (const uint64_t*)keys2, n, roots, scene + 7, tuning().dbg_skip);
     hipLaunchKernelGGL(k_treelet_lanes, dim3((unsigned)std::min<size_t>((n_tris + 2) / 3, 8192)), dim3(64), 0, st, roots, scene + 7, boxes, keys2, order, tuning().dbg_skip);
   }
-  if (n > 1) hipLaunchKernelGGL(k_karras, dim3(cdiv(n_tris - 1, B)), dim3(B), 0, st, keys2, n, range, child, parent);
 
   SegLevels lv;
   lv.levels = 0;
@@ -1017,8 +1093,9 @@ int build_device_mesh(Arena& ws, hipStream_t st, const float* d_verts, size_t n_
       cnt = (cnt + 1) / 2;
     }
   }
-  hipLaunchKernelGGL(k_seg_build, dim3(cdiv(n_tris, 512)), dim3(B), 0, st, (const Box*)boxes, (const uint32_t*)order, (uint32_t)n_tris, seg, lv, aux);
-  hipLaunchKernelGGL(k_emit, dim3(cdiv(2 * n_tris - 1, B)), dim3(B), 0, st, n, range, parent, seg, lv, order, raw,
+  hipLaunchKernelGGL(k_hierarchy, dim3(cdiv(n_tris, 512) + cdiv(n_tris - 1, B)), dim3(B), 0, st, (const Box*)boxes, (const uint32_t*)order, (uint32_t)n_tris, seg, lv, aux,
+                     cdiv(n_tris, 512), (const uint64_t*)keys2, range, recs_local, recs_total, recs_carry);
+  hipLaunchKernelGGL(k_emit, dim3(cdiv(2 * n_tris - 1, B)), dim3(B), 0, st, n, (const int2*)range, (const uint4*)recs_local, (const uint4*)recs_carry, (const Box*)seg, lv, order, raw,
                      nodes, tris, slot_first, cen, planes, leaf_max, slot_of, corners, nrm, d_err, tuning().dbg_skip);
   hipLaunchKernelGGL(k_node_ext, dim3(cdiv(2 * n_tris - 1, B)), dim3(B), 0, st, nodes, slot_first, (const float4*)nrm, (const float4*)corners,
                      (uint32_t)(2 * n_tris - 1), ext, tuning().dbg_skip);
@@ -1065,9 +1142,8 @@ void warm_bvh(hipStream_t st) {
       (const void*)k_sort_buckets<1024>,
       (const void*)k_morton_keys,
       (const void*)k_roots_from_keys,
-      (const void*)k_karras,
       (const void*)k_treelet_lanes,
-      (const void*)k_seg_build,
+      (const void*)k_hierarchy,
       (const void*)k_emit,
       (const void*)k_node_ext};
   hipFuncAttributes attr;
