@@ -568,40 +568,93 @@ template <int CTRL, int ROWS>
 __device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, ROWS, 0xf, false); }   // lanes without a source keep v
 template <int CTRL, int ROWS>
 __device__ __forceinline__ float dpp_f(float v) { return __int_as_float(dpp_i<CTRL, ROWS>(__float_as_int(v))); }
-constexpr int DPP_SHR = 0x110, DPP_SHL = 0x100, DPP_BCAST15 = 0x142, DPP_BCAST31 = 0x143, DPP_WAVE_SHL1 = 0x130;
+constexpr int DPP_SHR = 0x110, DPP_BCAST15 = 0x142, DPP_BCAST31 = 0x143, DPP_WAVE_SHL1 = 0x130;
 
-// inclusive scan towards higher lanes over [s, lane]; MIN: fminf, else fmaxf
-template <bool MIN>
-__device__ __forceinline__ float seg_prefix(float v, int lane, int s) {
-#define M2S_STEP(CTRL, ROWS, SRC) { const float t = dpp_f<CTRL, ROWS>(v); const float u = MIN ? fminf(v, t) : fmaxf(v, t); v = (SRC) >= s ? u : v; }
-  M2S_STEP(DPP_SHR + 1, 0xf, lane - 1)
-  M2S_STEP(DPP_SHR + 2, 0xf, lane - 2)
-  M2S_STEP(DPP_SHR + 4, 0xf, lane - 4)
-  M2S_STEP(DPP_SHR + 8, 0xf, lane - 8)
-  M2S_STEP(DPP_BCAST15, 0xa, (lane & ~15) - 1)
-  M2S_STEP(DPP_BCAST31, 0xc, 31)
-#undef M2S_STEP
-  return v;
+// The segmented scans of a level all run over the same segments, so the lanes that take part in a step are the same for every scan:
+// twelve lane masks per level (SGPR pairs), and a step is ONE fused DPP min / max into a scratch register plus ONE v_cndmask under
+// the step's mask.  (The compiler's form of `v = src_in_segment ? min(v, dpp(v)) : v` recomputed the comparison for every scan and
+// moved before it took the minimum: five instructions per step, 600 of a level's ~1 000.)  Three scans are interleaved, so that the
+// DPP read of a register comes two instructions after its last write inside a block (the VALU-write -> DPP-read hazard wants two wait
+// states); the compiler does not pad inline assembly, so every block starts with an s_nop 1 against whatever it put in front.
+struct ScanMasks {
+  unsigned long long up[6];     // prefix steps: row_shr 1, 2, 4, 8, row_bcast 15, row_bcast 31
+  unsigned long long down[4];   // suffix steps: row_shl 1, 2, 4, 8 (the two row crossings go through lane reads)
+};
+__device__ __forceinline__ ScanMasks scan_masks(int lane, int s, int e) {
+  ScanMasks m;
+  const int r = lane & 15;
+  m.up[0] = __ballot(r >= 1 && lane - 1 >= s);
+  m.up[1] = __ballot(r >= 2 && lane - 2 >= s);
+  m.up[2] = __ballot(r >= 4 && lane - 4 >= s);
+  m.up[3] = __ballot(r >= 8 && lane - 8 >= s);
+  m.up[4] = __ballot((lane & 16) != 0 && (lane & ~15) - 1 >= s);
+  m.up[5] = __ballot(lane >= 32 && 31 >= s);
+  m.down[0] = __ballot(r + 1 <= 15 && lane + 1 < e);
+  m.down[1] = __ballot(r + 2 <= 15 && lane + 2 < e);
+  m.down[2] = __ballot(r + 4 <= 15 && lane + 4 < e);
+  m.down[3] = __ballot(r + 8 <= 15 && lane + 8 < e);
+  return m;
 }
-// inclusive scan towards lower lanes over [lane, e)
+#define M2S_SCAN3(OP, CTRL, MASK)                                                                     \
+  asm volatile("s_nop 1\n\t"                                                                          \
+               "v_" OP "_f32_dpp %3, %0, %0 " CTRL "\n\t"                                              \
+               "v_" OP "_f32_dpp %4, %1, %1 " CTRL "\n\t"                                              \
+               "v_" OP "_f32_dpp %5, %2, %2 " CTRL "\n\t"                                              \
+               "v_cndmask_b32 %0, %0, %3, %6\n\t"                                                      \
+               "v_cndmask_b32 %1, %1, %4, %6\n\t"                                                      \
+               "v_cndmask_b32 %2, %2, %5, %6"                                                          \
+               : "+v"(a), "+v"(b), "+v"(c), "=&v"(t0), "=&v"(t1), "=&v"(t2)                            \
+               : "s"(MASK))
+// inclusive scans towards higher lanes over [s, lane] of three values at once; MIN: minima, else maxima
 template <bool MIN>
-__device__ __forceinline__ float seg_suffix(float v, int lane, int e) {
-#define M2S_STEP(CTRL, SRC) { const float t = dpp_f<CTRL, 0xf>(v); const float u = MIN ? fminf(v, t) : fmaxf(v, t); v = (SRC) < e ? u : v; }
-  M2S_STEP(DPP_SHL + 1, lane + 1)
-  M2S_STEP(DPP_SHL + 2, lane + 2)
-  M2S_STEP(DPP_SHL + 4, lane + 4)
-  M2S_STEP(DPP_SHL + 8, lane + 8)
-#undef M2S_STEP
+__device__ __forceinline__ void seg_prefix3(float& a, float& b, float& c, const ScanMasks& m) {
+  float t0, t1, t2;
+  if (MIN) {
+    M2S_SCAN3("min", "row_shr:1 row_mask:0xf bank_mask:0xf", m.up[0]);
+    M2S_SCAN3("min", "row_shr:2 row_mask:0xf bank_mask:0xf", m.up[1]);
+    M2S_SCAN3("min", "row_shr:4 row_mask:0xf bank_mask:0xf", m.up[2]);
+    M2S_SCAN3("min", "row_shr:8 row_mask:0xf bank_mask:0xf", m.up[3]);
+    M2S_SCAN3("min", "row_bcast:15 row_mask:0xa bank_mask:0xf", m.up[4]);
+    M2S_SCAN3("min", "row_bcast:31 row_mask:0xc bank_mask:0xf", m.up[5]);
+  } else {
+    M2S_SCAN3("max", "row_shr:1 row_mask:0xf bank_mask:0xf", m.up[0]);
+    M2S_SCAN3("max", "row_shr:2 row_mask:0xf bank_mask:0xf", m.up[1]);
+    M2S_SCAN3("max", "row_shr:4 row_mask:0xf bank_mask:0xf", m.up[2]);
+    M2S_SCAN3("max", "row_shr:8 row_mask:0xf bank_mask:0xf", m.up[3]);
+    M2S_SCAN3("max", "row_bcast:15 row_mask:0xa bank_mask:0xf", m.up[4]);
+    M2S_SCAN3("max", "row_bcast:31 row_mask:0xc bank_mask:0xf", m.up[5]);
+  }
+}
+// inclusive scans towards lower lanes over [lane, e)
+template <bool MIN>
+__device__ __forceinline__ void seg_suffix3(float& a, float& b, float& c, const ScanMasks& m, int lane, int e) {
+  float t0, t1, t2;
+  if (MIN) {
+    M2S_SCAN3("min", "row_shl:1 row_mask:0xf bank_mask:0xf", m.down[0]);
+    M2S_SCAN3("min", "row_shl:2 row_mask:0xf bank_mask:0xf", m.down[1]);
+    M2S_SCAN3("min", "row_shl:4 row_mask:0xf bank_mask:0xf", m.down[2]);
+    M2S_SCAN3("min", "row_shl:8 row_mask:0xf bank_mask:0xf", m.down[3]);
+  } else {
+    M2S_SCAN3("max", "row_shl:1 row_mask:0xf bank_mask:0xf", m.down[0]);
+    M2S_SCAN3("max", "row_shl:2 row_mask:0xf bank_mask:0xf", m.down[1]);
+    M2S_SCAN3("max", "row_shl:4 row_mask:0xf bank_mask:0xf", m.down[2]);
+    M2S_SCAN3("max", "row_shl:8 row_mask:0xf bank_mask:0xf", m.down[3]);
+  }
   {
     const int src = (lane | 15) + 1;                              // first lane of the next row (rows 0 and 2 take it)
-    const float t = __shfl(v, src & 63), u = MIN ? fminf(v, t) : fmaxf(v, t);
-    v = (!(lane & 16) && src < e) ? u : v;
+    const bool take = !(lane & 16) && src < e;
+    const float ta = __shfl(a, src & 63), tb = __shfl(b, src & 63), tc = __shfl(c, src & 63);
+    a = take ? (MIN ? fminf(a, ta) : fmaxf(a, ta)) : a;
+    b = take ? (MIN ? fminf(b, tb) : fmaxf(b, tb)) : b;
+    c = take ? (MIN ? fminf(c, tc) : fmaxf(c, tc)) : c;
   }
   {
-    const float t = __shfl(v, 32), u = MIN ? fminf(v, t) : fmaxf(v, t);
-    v = (lane < 32 && 32 < e) ? u : v;
+    const bool take = lane < 32 && 32 < e;
+    const float ta = __shfl(a, 32), tb = __shfl(b, 32), tc = __shfl(c, 32);
+    a = take ? (MIN ? fminf(a, ta) : fmaxf(a, ta)) : a;
+    b = take ? (MIN ? fminf(b, tb) : fmaxf(b, tb)) : b;
+    c = take ? (MIN ? fminf(c, tc) : fmaxf(c, tc)) : c;
   }
-  return v;
 }
 
 __global__ __launch_bounds__(64) void k_treelet_lanes(const int2* __restrict__ roots, const int* __restrict__ n_roots,
@@ -632,8 +685,16 @@ __global__ __launch_bounds__(64) void k_treelet_lanes(const int2* __restrict__ r
     // widest axis of the centres of my segment
     const float cen[3] = {0.5f * (b.mnx + b.mxx), 0.5f * (b.mny + b.mxy), 0.5f * (b.mnz + b.mxz)};
     const int tail = e - 1;
+    const ScanMasks sm = scan_masks(lane, s, e);
     float ext[3];
-    for (int k = 0; k < 3; ++k) ext[k] = __shfl(seg_prefix<false>(cen[k], lane, s), tail) - __shfl(seg_prefix<true>(cen[k], lane, s), tail);
+    {
+      float hi0 = cen[0], hi1 = cen[1], hi2 = cen[2], lo0 = cen[0], lo1 = cen[1], lo2 = cen[2];
+      seg_prefix3<false>(hi0, hi1, hi2, sm);
+      seg_prefix3<true>(lo0, lo1, lo2, sm);
+      ext[0] = __shfl(hi0, tail) - __shfl(lo0, tail);
+      ext[1] = __shfl(hi1, tail) - __shfl(lo1, tail);
+      ext[2] = __shfl(hi2, tail) - __shfl(lo2, tail);
+    }
     int axis = 2;
     if (open) axis = (ext[0] >= ext[1] && ext[0] >= ext[2]) ? 0 : (ext[1] >= ext[2] ? 1 : 2);   // NaN extents: comparisons false -> axis 2
     const int key = ord(axis == 0 ? cen[0] : (axis == 1 ? cen[1] : cen[2]));                    // total order, NaN included
@@ -665,10 +726,11 @@ __global__ __launch_bounds__(64) void k_treelet_lanes(const int2* __restrict__ r
       tri = (uint32_t)__builtin_amdgcn_ds_permute(dst, (int)tri);
     }
     // the split after me: boxes of the items up to my position and of the rest
-    const float L[6] = {seg_prefix<true>(b.mnx, lane, s), seg_prefix<true>(b.mny, lane, s), seg_prefix<true>(b.mnz, lane, s),
-                        seg_prefix<false>(b.mxx, lane, s), seg_prefix<false>(b.mxy, lane, s), seg_prefix<false>(b.mxz, lane, s)};
-    const float S[6] = {seg_suffix<true>(b.mnx, lane, e), seg_suffix<true>(b.mny, lane, e), seg_suffix<true>(b.mnz, lane, e),
-                        seg_suffix<false>(b.mxx, lane, e), seg_suffix<false>(b.mxy, lane, e), seg_suffix<false>(b.mxz, lane, e)};
+    float L[6] = {b.mnx, b.mny, b.mnz, b.mxx, b.mxy, b.mxz}, S[6] = {b.mnx, b.mny, b.mnz, b.mxx, b.mxy, b.mxz};
+    seg_prefix3<true>(L[0], L[1], L[2], sm);
+    seg_prefix3<false>(L[3], L[4], L[5], sm);
+    seg_suffix3<true>(S[0], S[1], S[2], sm, lane, e);
+    seg_suffix3<false>(S[3], S[4], S[5], sm, lane, e);
     float Rr[6];
     for (int k = 0; k < 6; ++k) Rr[k] = dpp_f<DPP_WAVE_SHL1, 0xf>(S[k]);   // S of lane + 1
     int cost_key = INT32_MAX;
