@@ -92,6 +92,7 @@ int ensure_capacity(DeviceState& s, size_t bytes) {
     s.base = nullptr;
     s.cap = 0;
   }
+  s.warmed_cap = 0;   // a fresh block: m2s_warmup has its pages to touch again
   const size_t want = bytes + bytes / 8 + (1u << 20);
   M2S_HIP_CHECK(hipMalloc((void**)&s.base, want));
   s.cap = want;
@@ -131,6 +132,7 @@ void release_scratch(DeviceState& s) {
   s.active = -1;
   s.base = nullptr;
   s.cap = 0;
+  s.warmed_cap = 0;
 }
 
 int resolve_ctx(const m2s_opts* opts, CallCtx* c, DeviceState** st) {
@@ -818,11 +820,38 @@ struct m2s_mesh {
   uint32_t acc_launches = 0;
   int* d_err_async = nullptr;     // device error word of asynchronous calls (inside `mem`), read by m2s_mesh_drain_timings
   bool async_readers = false;     // asynchronous walks may still be reading the sign planes
-  // walks of the tree that a later call cannot see as finished: asynchronous ones (until m2s_mesh_drain_timings) and ones on another stream
-  bool tree_async = false;
+  // walks of the tree that a later call on ANOTHER stream cannot see as finished (calls on one stream are ordered by it): the last call was
+  // asynchronous (tree_last_async), or an asynchronous call was followed by a call on a different stream (tree_async_other); both end with
+  // m2s_mesh_drain_timings or a device synchronisation
+  bool tree_last_async = false, tree_async_other = false;
   hipStream_t tree_stream = nullptr;
   bool tree_used = false;
 };
+
+// The leaf size a call wants its tree to have (grid_leaf_max / query_leaf_max): the resident tree is re-marked when it differs — one
+// 5 us launch on the call's stream.  Walks that this stream does not order before the launch must have finished first.
+// INVARIANT the multi-stream cases rest on: k_releaf only moves the `tri` marks between two valid cuts of the same tree (a subtree of at
+// most leaf_max triangles is walked as one leaf, and every mixture of old and new marks is still a cut: each root-to-leaf path meets a
+// mark), and the walks take the exact minimum over whatever leaves they meet.  So a call on another stream that finds the host-side size
+// already equal to its wish, while the re-marking launch is still in flight, computes the same bits at a slightly different cost.
+static int remark_leaves(m2s_mesh* m, const m2s::CallCtx& c, uint32_t want) {
+  using namespace m2s;
+  const bool other_stream = m->tree_used && m->tree_stream != c.stream;
+  if (want != m->dm.leaf_max) {
+    if (m->tree_async_other || (other_stream && m->tree_last_async)) {
+      M2S_HIP_CHECK(hipDeviceSynchronize());
+      m->tree_async_other = false;
+      m->tree_last_async = false;
+    }
+    const int rc = set_leaf_size(c.stream, &m->dm, want);
+    if (rc) return rc;
+  }
+  if (other_stream && m->tree_last_async) m->tree_async_other = true;
+  m->tree_stream = c.stream;
+  m->tree_used = true;
+  m->tree_last_async = !c.sync;
+  return 0;
+}
 
 // Folds the finished entries of m->pending into the accumulators and recycles their events.
 static void reap_pending(m2s_mesh* m, bool wait) {
@@ -959,7 +988,7 @@ int m2s_generate_grid_sdf(const float* vertices, size_t n_vertices, const void* 
 
   size_t need = bvh_workspace_bytes(n_tris) + 4096;
   if (sign_method == M2S_SIGN_RAYCAST) need += sign_workspace_bytes(g, n_tris);
-  need += grid_distance_workspace_bytes(g);
+  need += grid_distance_workspace_bytes(g, n_tris);
   if (c.mem_kind == M2S_MEM_HOST)
     need += align_up(n_vertices * 12) + align_up(n_indices * (size_t)(indices ? index_bytes : 0)) + align_up(slab_cells * 4) + 1024;
   rc = ensure_capacity(*st, need);
@@ -1379,7 +1408,7 @@ int m2s_mesh_generate_grid_sdf(m2s_mesh* m, const m2s_grid* grid, int sign_metho
   if (g.chunk_log < 31u && c.mem_kind != M2S_MEM_DEVICE) return fail(M2S_ERR_BAD_ARG, "m2s_opts.x_period needs mem_kind == M2S_MEM_DEVICE");
   const uint64_t ny = grid->cell_count[1], nz = grid->cell_count[2], xb = g.xb;
 
-  size_t need = grid_distance_workspace_bytes(g) + 8192;
+  size_t need = grid_distance_workspace_bytes(g, m->n_tris) + 8192;
   if (c.mem_kind == M2S_MEM_HOST) need += align_up(slab_cells * 4) + 1024;
   rc = ensure_capacity(*st, need);
   if (rc) return rc;
@@ -1400,19 +1429,8 @@ int m2s_mesh_generate_grid_sdf(m2s_mesh* m, const m2s_grid* grid, int sign_metho
   M2S_HIP_CHECK(hipEventRecord(st->ev[1], c.stream));
   st->planes_done = nullptr;
   st->have_raw_seeds = false;
-  {
-    // The leaf size this grid's walks want (grid_leaf_max: leaves of 4 - 16 triangles where a brick meets several): the resident tree is
-    // re-marked when it differs — one 5 us launch; walks that are not ordered before this stream must have finished first.
-    const uint32_t want = grid_leaf_max(g, m->n_tris);
-    if (want != m->dm.leaf_max) {
-      if (m->tree_async || (m->tree_used && m->tree_stream != c.stream)) { M2S_HIP_CHECK(hipDeviceSynchronize()); m->tree_async = false; }
-      rc = set_leaf_size(c.stream, &m->dm, want);
-      if (rc) return rc;
-    }
-    m->tree_stream = c.stream;
-    m->tree_used = true;
-    if (!c.sync) m->tree_async = true;
-  }
+  rc = remark_leaves(m, c, grid_leaf_max(g, m->n_tris));   // leaves of 4 - 16 triangles where a brick meets several
+  if (rc) return rc;
   bool built_planes = false;
   const uint32_t* plane = nullptr;
   if (sign_method == M2S_SIGN_RAYCAST) {
@@ -1511,6 +1529,8 @@ int m2s_mesh_drain_timings(m2s_mesh* m, m2s_timings* t) {
   m->acc_units = 0;
   m->acc_launches = 0;
   m->async_readers = false;   // every asynchronous walk has finished
+  m->tree_last_async = false;
+  m->tree_async_other = false;
   // deferred error report of the asynchronous calls since the last drain (the reference panics: lib.rs:257)
   int e = 0;
   M2S_HIP_CHECK(hipMemcpy(&e, m->d_err_async, sizeof(int), hipMemcpyDeviceToHost));
@@ -1565,18 +1585,8 @@ int m2s_mesh_generate_sdf(m2s_mesh* m, const float* queries, size_t n_queries, i
   M2S_HIP_CHECK(hipEventRecord(st->ev[0], c.stream));
   M2S_HIP_CHECK(hipEventRecord(st->ev[1], c.stream));
   M2S_HIP_CHECK(hipEventRecord(st->ev[2], c.stream));
-  {
-    // the leaf size this query set wants (query_leaf_max); as in m2s_mesh_generate_grid_sdf
-    const uint32_t want = query_is_tiny(n_queries, m->n_tris, algorithm, sign_src) ? m->dm.leaf_max : query_leaf_max(n_queries, m->n_tris, sign_src);
-    if (want != m->dm.leaf_max) {
-      if (m->tree_async || (m->tree_used && m->tree_stream != c.stream)) { M2S_HIP_CHECK(hipDeviceSynchronize()); m->tree_async = false; }
-      rc = set_leaf_size(c.stream, &m->dm, want);
-      if (rc) return rc;
-    }
-    m->tree_stream = c.stream;
-    m->tree_used = true;
-    if (!c.sync) m->tree_async = true;
-  }
+  rc = remark_leaves(m, c, query_is_tiny(n_queries, m->n_tris, algorithm, sign_src) ? m->dm.leaf_max : query_leaf_max(n_queries, m->n_tris, sign_src));
+  if (rc) return rc;
   rc = launch_query_distance(ws, c.stream, m->dm, d_q, n_queries, mode, sign_src, algorithm, d_out, d_err);
   if (rc) return rc;
   M2S_HIP_CHECK(hipEventRecord(st->ev[3], c.stream));

@@ -244,7 +244,7 @@ int build_grid_sign_plane(Arena& ws, hipStream_t st, const DeviceMesh& mesh, con
                           const uint32_t** d_inside_plane, bool slab_only);
 
 // distance.hip
-size_t grid_distance_workspace_bytes(const GridParams& g);
+size_t grid_distance_workspace_bytes(const GridParams& g, size_t n_tris);
 // Split walk (distance.hip): a packet still walking when the launch runs dry hands the rest of its pre-order ranges to other waves.
 // `cnt`: [0] suspended packets (= accumulator slots taken), [1 + r] items in the list of follow-up round r (r = 1 ..),
 // [16 + x] the time (10 ns ticks, made odd) at which XCD x was handed its last packet, [24 + x] the time it was handed its first,

@@ -162,7 +162,10 @@ __device__ __forceinline__ GridBrick grid_lane_voxel_plain(const GridParams& g, 
 // packets (its private L2 keeps seeing the same part of the BVH), and the runs are dealt out round-robin — XCD x takes the runs
 // x, x+8, x+16, ...: every XCD still works through whole super-bricks, and no XCD is handed the expensive eighth of the grid, as
 // one contiguous eighth per XCD did (matters most for the thin multi-GPU pieces, which have few runs).
-constexpr uint32_t XCD_RUN_LOG = 8;   // 7 is as fast, 8 re-fetches less (L2 misses 363 -> 263 MB on the headline)
+#ifndef M2S_XCD_RUN_LOG
+#define M2S_XCD_RUN_LOG 8
+#endif
+constexpr uint32_t XCD_RUN_LOG = M2S_XCD_RUN_LOG;   // 7 is as fast, 8 re-fetches less (L2 misses 363 -> 263 MB on the headline)
 __device__ __forceinline__ uint32_t xcd_remap(uint32_t b) {
   const uint32_t i = b >> 3, x = b & 7u;
   return ((((i >> XCD_RUN_LOG) << 3) + x) << XCD_RUN_LOG) | (i & ((1u << XCD_RUN_LOG) - 1u));
@@ -2328,10 +2331,23 @@ static size_t cut_blocks(const GridParams& g, uint32_t log) {
 // percent or two of it.  Below that every packet has a slot (a suspended packet can always hand over: no path back into the walk).
 constexpr uint32_t SPLIT_MAX_PACKETS = 1u << 19, SPLIT_ITEMS_PER_SLOT = 8;
 static uint32_t split_cap_slots(size_t packets) { return (uint32_t)std::min<size_t>(std::max<size_t>(packets, 64), SPLIT_MAX_PACKETS); }
-static size_t split_workspace_bytes(size_t packets) {
+// The same conditions prepare_grid_walk applies (those it adds — lane walk, tree-less path, counters — only switch the split walk off).
+static bool split_may_run(const GridParams& g, size_t n_tris, size_t packets) {
+  const Tuning& tn = tuning();
+  if (tn.split == 0 || packets > SPLIT_MAX_PACKETS) return false;
+  if (tn.split > 0) return true;
+  const double real_bricks = (double)bricks_along(g.xe - g.xb, g.bl[0]) * bricks_along(g.n[1], g.bl[1]) * bricks_along(g.n[2], g.bl[2]);
+  const double grid_bricks = (double)bricks_along(g.n[0], g.bl[0]) * bricks_along(g.n[1], g.bl[1]) * bricks_along(g.n[2], g.bl[2]);
+  return real_bricks >= 10240.0 && n_tris >= 300000u && (double)n_tris >= 5.0 * grid_bricks;
+}
+// Nothing where the split walk cannot run (it was ~235 MB of every 256^3 call's block, ~370 MB from 2^19 packets on), the item lists by the
+// rounds in use.
+static size_t split_workspace_bytes(const GridParams& g, size_t n_tris, size_t packets) {
+  if (!split_may_run(g, n_tris, packets)) return 0;
   const size_t cap = split_cap_slots(packets);
   const size_t items = std::max<size_t>(cap, std::min<size_t>(cap * SPLIT_ITEMS_PER_SLOT, 1u << 20));
-  return 256 + SPLIT_CNT_WORDS * 4 + cap * 4 + 256 + cap * 128 * 4 + 256 + (size_t)SPLIT_MAX_ROUNDS * items * 16 + 256;
+  const size_t rounds = std::min(tuning().split_rounds, SPLIT_MAX_ROUNDS);
+  return 256 + SPLIT_CNT_WORDS * 4 + cap * 4 + 256 + cap * 128 * 4 + 256 + rounds * items * 16 + 256;
 }
 bool grid_is_tiny(const GridParams& g, size_t n_tris, int algorithm) {
   if (algorithm != 0 || n_tris == 0 || g.xe <= g.xb || g.n[1] == 0 || g.n[2] == 0 || g.chunk_log < 31u) return false;
@@ -2339,12 +2355,12 @@ bool grid_is_tiny(const GridParams& g, size_t n_tris, int algorithm) {
   const double cells = (double)(g.xe - g.xb) * g.n[1] * g.n[2];
   return cells <= 4194304.0 && cells * (double)n_tris <= limit;
 }
-size_t grid_distance_workspace_bytes(const GridParams& g) {
+size_t grid_distance_workspace_bytes(const GridParams& g, size_t n_tris) {
   const size_t bricks = (size_t)host_brick_count(g);
   if ((double)(g.xe - g.xb) * g.n[1] * g.n[2] <= 4194304.0)   // room for k_brute_split's per-voxel words
-    return bricks * 44 + bricks + 16384 + cut_blocks(g, 0) * CUT_WORDS * 4 + bricks * 64 * 8 + 4096 + split_workspace_bytes(bricks);
+    return bricks * 44 + bricks + 16384 + cut_blocks(g, 0) * CUT_WORDS * 4 + bricks * 64 * 8 + 4096 + split_workspace_bytes(g, n_tris, bricks);
   const size_t trail_counters = (size_t)bricks_along(g.xe - g.xb, g.bl[0]) * (bricks_along(g.n[1], g.bl[1]) + 1) * 4;   // M2S_PEER_TRAIL progress
-  return bricks * 44 + bricks + 16384 + cut_blocks(g, 0) * CUT_WORDS * 4 + trail_counters + 1024 + split_workspace_bytes(bricks);   // seeds + cut lists (one per brick) + split walk
+  return bricks * 44 + bricks + 16384 + cut_blocks(g, 0) * CUT_WORDS * 4 + trail_counters + 1024 + split_workspace_bytes(g, n_tris, bricks);   // seeds + cut lists (one per brick) + split walk
 }
 
 __global__ __launch_bounds__(256) void k_seed_remap(uint32_t* __restrict__ ids, size_t n, const uint32_t* __restrict__ slot_of, uint32_t n_tris) {
@@ -2495,7 +2511,7 @@ int prepare_grid_walk(Arena& ws, hipStream_t st, const DeviceMesh& mesh, const G
   // whose voxels see many triangles at (nearly) the same distance, and they weigh the more the finer the mesh is against the grid —
   // blob-100k in 96^3 ... 192^3 1.79 -> 1.07, 1.57 -> 1.28, 1.81 -> 1.63 ms, in 256^3 2.25 -> 2.34 (a wash), the 64-layer slabs of
   // 512^3 1.21 -> 1.26 (a loss: no tail to speak of, three more launches); blob-1M in 256^3 12.8 -> 9.5 ms, its slowest 8-GPU slab of
-  // 512^3 5.05 -> 4.05, its fastest 3.14 -> 3.16.  Automatic: from 0.45 triangles per packet brick of the WHOLE grid on (split_auto, above).
+  // 512^3 5.05 -> 4.05, its fastest 3.14 -> 3.16.  Automatic: split_auto above (>= 300 000 triangles, >= 5 per packet brick of the WHOLE grid, >= 10 240 bricks).
   if (!lane_walk && split_possible && (tn.split > 0 || split_auto)) {
     SplitCtl sc;
     sc.cap_slots = split_cap_slots(packets);

@@ -2,6 +2,7 @@
 #include "tuning.h"
 
 #include <cstddef>
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -58,10 +59,11 @@ bool assign(Tuning& t, const Entry& e, const char* text) {
   char* end = nullptr;
   char* field = reinterpret_cast<char*>(&t) + e.offset;
   switch (e.kind) {
-    case K_INT: { const long v = strtol(text, &end, 10); if (end == text) return false; *reinterpret_cast<int*>(field) = (int)v; break; }
-    case K_U32: { const long long v = strtoll(text, &end, 10); if (end == text || v < 0) return false; *reinterpret_cast<uint32_t*>(field) = (uint32_t)v; break; }
-    case K_F32: { const double v = strtod(text, &end); if (end == text) return false; *reinterpret_cast<float*>(field) = (float)v; break; }
-    case K_F64: { const double v = strtod(text, &end); if (end == text) return false; *reinterpret_cast<double*>(field) = v; break; }
+    // the whole text must be one number in the field's range ("12abc", 2^32 for a 32-bit field: refused, not wrapped)
+    case K_INT: { const long v = strtol(text, &end, 10); if (end == text || *end || v < INT32_MIN || v > INT32_MAX) return false; *reinterpret_cast<int*>(field) = (int)v; break; }
+    case K_U32: { const long long v = strtoll(text, &end, 10); if (end == text || *end || v < 0 || v > (long long)UINT32_MAX) return false; *reinterpret_cast<uint32_t*>(field) = (uint32_t)v; break; }
+    case K_F32: { const double v = strtod(text, &end); if (end == text || *end) return false; *reinterpret_cast<float*>(field) = (float)v; break; }
+    case K_F64: { const double v = strtod(text, &end); if (end == text || *end) return false; *reinterpret_cast<double*>(field) = v; break; }
   }
   return true;
 }
@@ -76,6 +78,7 @@ void sanitise(Tuning& t) {
   if (t.split_rounds > 6) t.split_rounds = 6;
   if (t.push_pieces < 1) t.push_pieces = 1;
   if (t.host_piece_mb < 1) t.host_piece_mb = 1;
+  if (t.leaf_max > 16) t.leaf_max = 16;   // the tree's limit (bvh.hip): a larger wish would differ from every resident tree's size for ever
 }
 
 void load_from_environment() {
@@ -113,7 +116,7 @@ int tuning_set(const char* name, const char* value) {
 
 int tuning_describe(char* buf, int cap) {
   const Tuning& t = tuning();
-  int need = 0;
+  int need = 0, copied = 0;
   for (const Entry& e : TABLE) {
     char line[96];
     const char* field = reinterpret_cast<const char*>(&t) + e.offset;
@@ -124,10 +127,10 @@ int tuning_describe(char* buf, int cap) {
       case K_F32: n = snprintf(line, sizeof(line), "%s=%.9g\n", e.name, (double)*reinterpret_cast<const float*>(field)); break;
       case K_F64: n = snprintf(line, sizeof(line), "%s=%.17g\n", e.name, *reinterpret_cast<const double*>(field)); break;
     }
-    if (buf && need + n < cap) memcpy(buf + need, line, (size_t)n);
+    if (buf && copied == need && need + n < cap) { memcpy(buf + need, line, (size_t)n); copied += n; }   // whole lines, and none after the first that did not fit
     need += n;
   }
-  if (buf && cap > 0) buf[need < cap ? need : cap - 1] = 0;
+  if (buf && cap > 0) buf[copied] = 0;
   return need;
 }
 
