@@ -319,6 +319,12 @@ static std::vector<std::pair<uint32_t, uint32_t>> slab_chunks(const GridParams& 
 static int stats_begin(Arena& ws, hipStream_t stream, DeviceMesh* mesh, unsigned long long** d_stats) {
   *d_stats = nullptr;
   if (!tuning().stats) return 0;
+#ifndef M2S_STATS_BUILD
+  static bool told = false;
+  if (!told) fprintf(stderr, "[m2s] M2S_STATS: this build carries no counting kernels; load mesh_to_sdf_amd/libm2s_stats.so (make -C mesh_to_sdf_amd/csrc stats) through M2S_LIB\n");
+  told = true;
+  return 0;
+#endif
   *d_stats = ws.take<unsigned long long>(128);
   if (!*d_stats) return fail(M2S_ERR_HIP, "internal: workspace");
   unsigned long long init[128] = {0};

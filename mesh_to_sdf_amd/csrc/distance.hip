@@ -248,11 +248,22 @@ __device__ __forceinline__ float finish(const Best<MODE>& best, bool negate_unsi
   return best.pos ? d : -d;                              // rtree.rs:118-123
 }
 
-// Pruning threshold in d2 space for the current best.  margin: relative 2e-5 on the distance
-// plus `slack` absolute (~32 ulp of the coordinate scale, + the approx_eq window in Normal mode).
+// Pruning threshold in d2 space for the current best: a node or a triangle is looked at while its lower bound is <= (d (1 + PRUNE_REL) +
+// slack)^2, with `slack` absolute (~67 ulp of the coordinate scale, + the approx_eq window of 1e-6 in Normal mode).
+// What the relative part has to cover ("The pruning margin"; u = 2^-24): a triangle T may only be skipped if its
+// COMPUTED distance could neither beat nor tie (Normal: approx_eq, 2 ulp) the final minimum.  With delta the true distance of T and B a
+// computed lower bound of something that contains T:  B <= delta (1 + e_B) + a_B  and  computed d_T >= delta (1 - e_T) - a_T, where the
+// absolute parts a_B, a_T (coordinate cancellation: <= ~16 u x scale together) are what `slack` is for, and the relative parts are
+//   e_T <= 4 u     dot3 of the difference vector and the square root of the final comparison
+//   e_B <= 7 u     ext_dist2 beyond 6.4 node radii (closer in, the 2e-6 x radius widening of the stored slab and the 1e-6 |v|^2 taken off the
+//                  lateral term are larger than its rounding), planes_dist2 / box_dist2 likewise, + 1 u for the approximate square root here
+//   2 u            the approx_eq tie window of the Normal fold (float-cmp ulps = 2)
+// together < 14 u = 8.3e-7.  PRUNE_REL = 4e-6 is 4.8 times that.  (Rounds 1-4 used 2e-5: config 5's walk 78.6 -> 75.7 ms at 2e-6; far from
+// a flat sheet the candidates within the margin are a disc of radius sqrt(2 m) D.)
+constexpr float PRUNE_REL = 4.0e-6f;
 __device__ __forceinline__ float prune_bound(float best_d2, float slack) {
   const float d = __builtin_amdgcn_sqrtf(best_d2);
-  const float r = __builtin_fmaf(d, 1.00002f, slack);
+  const float r = __builtin_fmaf(d, 1.0f + PRUNE_REL, slack);
   return r * r;
 }
 
@@ -1702,6 +1713,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(M2S_LANE_WA
 // GRID = false (generic queries): "brick" = packet of sorted queries, lane = packet, 64 consecutive packets (neighbours in
 // the Morton order) per wave; centre and radius from `centres` (k_qpacket_bounds), the seed from the lattice cell of the
 // centre (as k_packet<false> does), `nbx` = the number of wave slots the packet walk was launched with.
+#ifndef M2S_CUT_PREFETCH
+#define M2S_CUT_PREFETCH 0
+#endif
 constexpr uint32_t NB_CUT = (uint32_t)sizeof(NodeExt);
 template <bool GRID>
 __global__ __launch_bounds__(64) void k_cut(DeviceMesh mesh, GridParams g, const uint32_t* __restrict__ seeds, uint32_t seed_shift,
@@ -1750,7 +1764,7 @@ __global__ __launch_bounds__(64) void k_cut(DeviceMesh mesh, GridParams g, const
     const f3 av = sub3(q, s);
     const float d2 = dot3(av, av);
     D = (d2 == d2) ? sqrtf(d2) : __builtin_inff();
-    // sphere: the packet walk keeps a node while bound <= d * 1.00002 + slack: stay well above that
+    // sphere: the packet walk keeps a node while bound <= d * (1 + PRUNE_REL) + slack: stay well above that
     R = (D * 1.0001f + 2.0f * r) * 1.0003f + abs_margin;
     R2 = R * R;                                              // inf: nothing is dropped
     if (D > r && D < 3.0e37f) {                              // (valid for any D > 0; useless when r^2 / 2D is large)
@@ -1772,10 +1786,25 @@ __global__ __launch_bounds__(64) void k_cut(DeviceMesh mesh, GridParams g, const
   };
   uint32_t n = 0, last_start = 0, last_end = 0, resume = 0, opened = 0;   // per lane
   uint32_t off = 0, steps = 0;                                // wave-uniform
+#if M2S_CUT_PREFETCH
+  // The walk is a chain of dependent record loads (~0.6 us a step, whatever the occupancy): BOTH possible successors of a node — its
+  // first child, the next record, and its skip target — are requested as soon as their addresses are known, so that the next step's
+  // record is on its way while this step's tests run.
+  NodeExt nxt = record_at_bytes<NodeExt>(mesh.ext, 0u);
+#endif
   while (off < end) {
     off = __builtin_amdgcn_readfirstlane(off);
     ++steps;
+#if M2S_CUT_PREFETCH
+    const NodeExt nr = nxt;
+    const uint32_t last_rec = end - NB;
+    const NodeExt pre_child = record_at_bytes<NodeExt>(mesh.ext, min(off + NB, last_rec));
+    const NodeExt pre_skip = record_at_bytes<NodeExt>(mesh.ext, min(__builtin_amdgcn_readfirstlane(nr.skip), last_rec));
+    const uint32_t off_in = off;
+    bool done = false;
+#else
     const NodeExt nr = *reinterpret_cast<const NodeExt*>(reinterpret_cast<const char*>(mesh.ext) + off);
+#endif
     const bool active = off >= resume;                        // this brick has not dropped / emitted an ancestor
     // closest point of the disc-slab to q:  q - c = ax * n_s + lat * l / |l|   (common.h NodeExt, ext_dist2)
     const float vx = q.x - nr.cx, vy = q.y - nr.cy, vz = q.z - nr.cz;
@@ -1789,8 +1818,13 @@ __global__ __launch_bounds__(64) void k_cut(DeviceMesh mesh, GridParams g, const
     const float ax = copysignf(fmaxf(fabsf(dt) - nr.half, 0.0f), dt);
     const float L2 = __builtin_fmaf(ax, ax, lat * lat);
     bool keep = active & !(L2 > R2);                          // sphere test; NaN keeps the node
+#if M2S_CUT_PREFETCH
+    if (__ballot(keep) == 0ull) { off = nr.skip; done = true; }
+    if (!done) {
+#else
     if (__ballot(keep) == 0ull) { off = nr.skip; continue; }
     {
+#endif
       // gradient test (lanes without it carry grad_c0 = inf: never dropped).  rcp / rsq instead of IEEE divisions: their
       // 1-ulp error is nothing beside the 2e-5 added under the root
       const float ne_s = __builtin_fmaf(nr.nz, e.z, __builtin_fmaf(nr.ny, e.y, nr.nx * e.x));            // n_s . e
@@ -1805,8 +1839,13 @@ __global__ __launch_bounds__(64) void k_cut(DeviceMesh mesh, GridParams g, const
       const bool drop = (A > 0.0f) & (A * A > grad_c1sq * nme2);                                         // A > c1 |n - e| without the root; false on NaN
       keep = keep & !drop;
     }
+#if M2S_CUT_PREFETCH
+    if (!done && __ballot(keep) == 0ull) { off = nr.skip; done = true; }
+    if (!done) {
+#else
     const unsigned long long bal = __ballot(keep);
     if (bal == 0ull) { off = nr.skip; continue; }
+#endif
     // Where many triangles are (nearly) equidistant — towards the medial axis, e.g. deep inside a round body — the brick-level
     // test keeps a large part of the tree however far it descends: a brick that has already opened `budget` nodes emits what
     // it meets next as it is and leaves the rest to the packet's per-voxel tests (which are 200 times sharper there).
@@ -1823,6 +1862,10 @@ __global__ __launch_bounds__(64) void k_cut(DeviceMesh mesh, GridParams g, const
     opened += (keep & !emit) ? 1u : 0u;
     if (active & (emit | !keep)) resume = nr.skip;            // done with this subtree either way
     off = (__ballot(keep & !emit) != 0ull) ? off + NB : nr.skip;   // some brick still has to look inside
+#if M2S_CUT_PREFETCH
+    }
+    nxt = (off == off_in + NB) ? pre_child : pre_skip;
+#endif
   }
   if (!in_grid) return;
   if (n == 0) { n = 1; last_start = 0; last_end = end; }    // cannot happen with finite input; never walk nothing
@@ -2239,10 +2282,16 @@ void launch_packet(hipStream_t st, const DeviceMesh& mesh, const GridParams& g, 
   if (split_in) split = *split_in;
   const uint32_t per = 8u << XCD_RUN_LOG;                              // one run on each of the eight XCDs
   const uint32_t grid_blocks = ((n_packets + per - 1) / per) * per;    // a whole number of runs per XCD (xcd_remap)
-  if (mesh.stats != nullptr)   // M2S_STATS: the counting variant (a few SALU ops more per node); never suspended, so that a packet's counters are whole
+#ifdef M2S_STATS_BUILD
+  // M2S_STATS: the counting variant (a few SALU ops more per node); never suspended, so that a packet's counters are whole.  Only the
+  // side library libm2s_stats.so (make stats; tools/exp_stats.py loads it through M2S_LIB) carries these instantiations: the product
+  // library's code object is seven k_packet variants smaller.
+  if (mesh.stats != nullptr)
     hipLaunchKernelGGL((k_packet<GRID, MODE, SIGN, true, false>), dim3(grid_blocks), dim3(64), 0, st, mesh, g,
                        qs, perm, n_q, plane, out, err, n_packets, seed_in, seed_shift, seed_ny, seed_nz, seed_lattice, cut, peers, split);
-  else if (defer == 3 && GRID && MODE != MODE_NEAREST_NORMAL && split.cnt != nullptr)
+  else
+#endif
+  if (defer == 3 && GRID && MODE != MODE_NEAREST_NORMAL && split.cnt != nullptr)
     hipLaunchKernelGGL((k_packet<GRID, MODE == MODE_NEAREST_NORMAL ? MODE_UNSIGNED : MODE, SIGN, false, GRID, GRID ? 3 : 1>), dim3(grid_blocks), dim3(64), 0, st, mesh, g,
                        qs, perm, n_q, plane, out, err, n_packets, seed_in, seed_shift, seed_ny, seed_nz, seed_lattice, cut, peers, split);
   else if (defer == 3)
@@ -2615,7 +2664,11 @@ int launch_grid_walk(hipStream_t st, const DeviceMesh& mesh, const GridParams& g
     M2S_HIP_CHECK(hipGetLastError());
     return 0;
   }
-  const SplitCtl* split = (!brute && plan.split.cnt != nullptr && mesh.stats == nullptr) ? &plan.split : nullptr;
+  // (the Normal fold's split variants — k_packet<GRID, NORMAL_FOLD, ..., SPLIT, {1, 3}>, k_split_round<NORMAL_FOLD> — need 9 - 11 registers
+  // more than eight waves per SIMD leave and spill them to scratch, the very thing that costs this kernel 10 - 40 %: the automatic choice
+  // leaves the Normal sign to the plain walk; M2S_SPLIT=1 / 2 still runs them — the tests do)
+  const bool split_ok = mode != MODE_NORMAL_FOLD || tuning().split > 0;
+  const SplitCtl* split = (!brute && plan.split.cnt != nullptr && mesh.stats == nullptr && split_ok) ? &plan.split : nullptr;
   if (split) hipLaunchKernelGGL(k_split_init, dim3(1), dim3(64), 0, st, split->cnt, plan.split_forced ? 1u : 0u);
   if (mode == MODE_UNSIGNED && d_inside_plane) {
     if (brute) launch_brute<true, MODE_UNSIGNED, SIGN_GRID_PLANE>(st, mesh, g, nullptr, 0, d_inside_plane, d_out, d_err, packets, peers);

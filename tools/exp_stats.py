@@ -7,6 +7,7 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ["M2S_STATS"] = os.environ.get("M2S_STATS", "1")
+os.environ.setdefault("M2S_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mesh_to_sdf_amd", "libm2s_stats.so"))   # the counting build (make -C mesh_to_sdf_amd/csrc stats)
 import torch  # noqa: E402
 
 from mesh_to_sdf_amd import Grid, SignMethod, Topology, generate_grid_sdf, meshes  # noqa: E402

@@ -19,7 +19,7 @@ for C in $CFGS; do
     ( cd /tmp && timeout 600 rocprofv3 --pmc $P --kernel-trace --output-format csv -d $OUT/pmc_$i -o p -- $BENCH > $OUT/pmc_$i.log 2>&1 )
   done
   python tools/pmc_summary.py $OUT k_packet > $OUT/pmc_k_packet.txt 2>&1
-  M2S_STATS=1 python bench.py --config $C --steps 1 --warmup 0 --no-cpu-baseline --no-live-pmc 2>&1 | grep "m2s stats" | head -12 > $OUT/stats.txt
+  M2S_LIB=$PWD/mesh_to_sdf_amd/libm2s_stats.so M2S_STATS=1 python bench.py --config $C --steps 1 --warmup 0 --no-cpu-baseline --no-live-pmc 2>&1 | grep "m2s stats" | head -12 > $OUT/stats.txt
   find $OUT -name "*.db" -delete
   rm -rf $OUT/pmc_? $OUT/trace
 done
