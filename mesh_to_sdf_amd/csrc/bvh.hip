@@ -222,7 +222,7 @@ __global__ __launch_bounds__(256) void k_emit(int n, const int2* __restrict__ ra
                                               NodeRec* __restrict__ nodes, TriRec* __restrict__ tris,
                                               uint32_t* __restrict__ slot_first, float4* __restrict__ cen,
                                               TriPlanes* __restrict__ planes, uint32_t leaf_max, uint32_t* __restrict__ slot_of,
-                                              float4* __restrict__ corners, float4* __restrict__ nrm, int* __restrict__ err, int dbg) {
+                                              float4* __restrict__ corners, float4* __restrict__ nrm, int* __restrict__ err) {
   const int id = blockIdx.x * blockDim.x + threadIdx.x;
   if (id >= 2 * n - 1) return;
   const bool leaf = id >= n - 1;
@@ -231,14 +231,14 @@ __global__ __launch_bounds__(256) void k_emit(int n, const int2* __restrict__ ra
   else { int2 r = range[id]; first = r.x; last = r.y; }
   // number of left turns on the root -> node path: the prefix-minimum records of d[last ..] (Recs above)
   int lefts = 0;
-  if (!(dbg & 4) && last >= 0 && last < n) {
+  if (last >= 0 && last < n) {
     const Recs r = recs_join(recs_unpack(recs_local[last]), recs_unpack(recs_carry[(uint32_t)last / RECS_BLOCK]));
     lefts = __popcll(r.lo) + __popc(r.hi);
   }
   const uint32_t slot = 2u * (uint32_t)first + (uint32_t)lefts;
   if (slot >= 2u * (uint32_t)n - 1u || last < first || last >= n) { atomicOr(err, ERRF_BUILD_TIMEOUT); return; }   // never with sorted keys
   const uint32_t cnt = (uint32_t)(last - first + 1);
-  Box b = (leaf || (dbg & 256)) ? seg[first] : seg_query(seg, lv, first, last);
+  Box b = leaf ? seg[first] : seg_query(seg, lv, first, last);
   NodeRec nr;
   nr.mnx = b.mnx; nr.mny = b.mny; nr.mnz = b.mnz;
   nr.skip = slot + 2u * cnt - 1u;
@@ -248,7 +248,7 @@ __global__ __launch_bounds__(256) void k_emit(int n, const int2* __restrict__ ra
   nr.tri = cnt <= leaf_max ? first : -1;
   nodes[slot] = nr;
   slot_first[slot] = (uint32_t)first;
-  if (leaf && !(dbg & 512)) {
+  if (leaf) {
     const TriRec r = raw[order[first]];
     tris[first] = r;
     // the vertices alone for the ray walks of the generic Raycast sign: 36 of a record's 96 bytes are all they read, and 4.8 MB of
@@ -444,8 +444,7 @@ __device__ __forceinline__ void node_ext_wave(const NodeRec& nr, uint32_t slot, 
 // 206 against 189 at 1 M (the locality of a workgroup's own slots is worth more); eight waves per workgroup with the two parts side
 // by side — 35.7 us.)
 __global__ __launch_bounds__(256) void k_node_ext(const NodeRec* __restrict__ nodes, const uint32_t* __restrict__ slot_first,
-                                                  const float4* __restrict__ nrm, const float4* __restrict__ corners, uint32_t n_nodes, NodeExt* __restrict__ ext,
-                                                  int dbg) {
+                                                  const float4* __restrict__ nrm, const float4* __restrict__ corners, uint32_t n_nodes, NodeExt* __restrict__ ext) {
   __shared__ uint32_t big[256];
   __shared__ uint32_t n_big;
   if (threadIdx.x == 0) n_big = 0;
@@ -454,8 +453,8 @@ __global__ __launch_bounds__(256) void k_node_ext(const NodeRec* __restrict__ no
   if (slot < n_nodes) {
     const NodeRec nr = nodes[slot];
     const uint32_t cnt = (nr.skip - slot + 1u) >> 1;
-    if (cnt <= EXT_THREAD_BELOW) { if (!(dbg & 2)) node_ext_thread(nr, slot, cnt, slot_first, nrm, corners, ext); }
-    else if (!(dbg & 1)) big[atomicAdd(&n_big, 1u)] = slot;
+    if (cnt <= EXT_THREAD_BELOW) node_ext_thread(nr, slot, cnt, slot_first, nrm, corners, ext);
+    else big[atomicAdd(&n_big, 1u)] = slot;
   }
   __syncthreads();
   const uint32_t nb = n_big;
@@ -488,7 +487,7 @@ __device__ __forceinline__ int adjacent_prefix(const uint64_t* __restrict__ keys
   return a == b ? 64 + __clz((uint32_t)j ^ (uint32_t)(j + 1)) : __clzll((long long)(a ^ b));
 }
 __global__ __launch_bounds__(256) void k_roots_from_keys(const uint64_t* __restrict__ keys, int n, int2* __restrict__ roots,
-                                                         int* __restrict__ n_roots, int dbg) {
+                                                         int* __restrict__ n_roots) {
   // One thread per SPLIT j (between the positions j and j + 1): the node that splits there reaches from the nearest smaller adjacent
   // prefix on its left (exclusive) to the nearest smaller one on its right (inclusive).  Both are found by descending a table of
   // range minima over the block's window of prefixes (seven dependent LDS reads each; a flat loop that let the neighbours join one
@@ -524,7 +523,7 @@ __global__ __launch_bounds__(256) void k_roots_from_keys(const uint64_t* __restr
   const int j = base + (int)threadIdx.x, w = j - lo;
   bool is_root = false;
   int first = 0, size = 0;
-  if (j < n - 1 && !(dbg & 8)) {
+  if (j < n - 1) {
     const int v = s_m[0][w];
     const int R = right_of(w, v), L = left_of(w, v);
     size = R - L;
@@ -659,7 +658,7 @@ __device__ __forceinline__ void seg_suffix3(float& a, float& b, float& c, const 
 
 __global__ __launch_bounds__(64) void k_treelet_lanes(const int2* __restrict__ roots, const int* __restrict__ n_roots,
                                                       const Box* __restrict__ boxes, uint64_t* __restrict__ keys,
-                                                      uint32_t* __restrict__ order, int dbg) {
+                                                      uint32_t* __restrict__ order) {
   // a few thousand single-wave blocks take the roots in turn (one block per POSSIBLE root — n / 3 of them, nine in ten with
   // nothing to do — spent more time being dispatched than the treelets took)
   const int total = *n_roots, lane = threadIdx.x;
@@ -679,7 +678,7 @@ __global__ __launch_bounds__(64) void k_treelet_lanes(const int2* __restrict__ r
   uint64_t code = 0;
   int depth = 0;
   const float inf = __builtin_inff();
-  for (int level = 0; level < ((dbg & 128) ? 1 : 64); ++level) {
+  for (int level = 0; level < 64; ++level) {
     const bool open = live && e - s > 1 && depth < room;
     if (__ballot(open) == 0ull) break;
     // widest axis of the centres of my segment
@@ -1138,8 +1137,8 @@ int build_device_mesh(Arena& ws, hipStream_t st, const float* d_verts, size_t n_
   if (n > 2 && (treelets > 0 || (treelets < 0 && !skip_treelets))) {
     // treelet pass: the nodes of at most TREELET_MAX triangles are rebuilt by sweep splits (their keys rewritten), then the hierarchy is derived
     int2* roots = reinterpret_cast<int2*>(child);   // child[] is not used by the kernels below before k_karras rewrites it
-    hipLaunchKernelGGL(k_roots_from_keys, dim3(cdiv(n_tris, B)), dim3(B), 0, st, (const uint64_t*)keys2, n, roots, scene + 7, tuning().dbg_skip);
-    hipLaunchKernelGGL(k_treelet_lanes, dim3((unsigned)std::min<size_t>((n_tris + 2) / 3, 8192)), dim3(64), 0, st, roots, scene + 7, boxes, keys2, order, tuning().dbg_skip);
+    hipLaunchKernelGGL(k_roots_from_keys, dim3(cdiv(n_tris, B)), dim3(B), 0, st, (const uint64_t*)keys2, n, roots, scene + 7);
+    hipLaunchKernelGGL(k_treelet_lanes, dim3((unsigned)std::min<size_t>((n_tris + 2) / 3, 8192)), dim3(64), 0, st, roots, scene + 7, boxes, keys2, order);
   }
 
   SegLevels lv;
@@ -1158,9 +1157,9 @@ int build_device_mesh(Arena& ws, hipStream_t st, const float* d_verts, size_t n_
   hipLaunchKernelGGL(k_hierarchy, dim3(cdiv(n_tris, 512) + cdiv(n_tris - 1, B)), dim3(B), 0, st, (const Box*)boxes, (const uint32_t*)order, (uint32_t)n_tris, seg, lv, aux,
                      cdiv(n_tris, 512), (const uint64_t*)keys2, range, recs_local, recs_total, recs_carry);
   hipLaunchKernelGGL(k_emit, dim3(cdiv(2 * n_tris - 1, B)), dim3(B), 0, st, n, (const int2*)range, (const uint4*)recs_local, (const uint4*)recs_carry, (const Box*)seg, lv, order, raw,
-                     nodes, tris, slot_first, cen, planes, leaf_max, slot_of, corners, nrm, d_err, tuning().dbg_skip);
+                     nodes, tris, slot_first, cen, planes, leaf_max, slot_of, corners, nrm, d_err);
   hipLaunchKernelGGL(k_node_ext, dim3(cdiv(2 * n_tris - 1, B)), dim3(B), 0, st, nodes, slot_first, (const float4*)nrm, (const float4*)corners,
-                     (uint32_t)(2 * n_tris - 1), ext, tuning().dbg_skip);
+                     (uint32_t)(2 * n_tris - 1), ext);
   M2S_HIP_CHECK(hipGetLastError());
   out->tris = tris;
   out->slot_first = slot_first;

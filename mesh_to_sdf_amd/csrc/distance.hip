@@ -1713,9 +1713,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(M2S_LANE_WA
 // GRID = false (generic queries): "brick" = packet of sorted queries, lane = packet, 64 consecutive packets (neighbours in
 // the Morton order) per wave; centre and radius from `centres` (k_qpacket_bounds), the seed from the lattice cell of the
 // centre (as k_packet<false> does), `nbx` = the number of wave slots the packet walk was launched with.
-#ifndef M2S_CUT_PREFETCH
-#define M2S_CUT_PREFETCH 0
-#endif
 constexpr uint32_t NB_CUT = (uint32_t)sizeof(NodeExt);
 template <bool GRID>
 __global__ __launch_bounds__(64) void k_cut(DeviceMesh mesh, GridParams g, const uint32_t* __restrict__ seeds, uint32_t seed_shift,
@@ -1786,25 +1783,10 @@ __global__ __launch_bounds__(64) void k_cut(DeviceMesh mesh, GridParams g, const
   };
   uint32_t n = 0, last_start = 0, last_end = 0, resume = 0, opened = 0;   // per lane
   uint32_t off = 0, steps = 0;                                // wave-uniform
-#if M2S_CUT_PREFETCH
-  // The walk is a chain of dependent record loads (~0.6 us a step, whatever the occupancy): BOTH possible successors of a node — its
-  // first child, the next record, and its skip target — are requested as soon as their addresses are known, so that the next step's
-  // record is on its way while this step's tests run.
-  NodeExt nxt = record_at_bytes<NodeExt>(mesh.ext, 0u);
-#endif
   while (off < end) {
     off = __builtin_amdgcn_readfirstlane(off);
     ++steps;
-#if M2S_CUT_PREFETCH
-    const NodeExt nr = nxt;
-    const uint32_t last_rec = end - NB;
-    const NodeExt pre_child = record_at_bytes<NodeExt>(mesh.ext, min(off + NB, last_rec));
-    const NodeExt pre_skip = record_at_bytes<NodeExt>(mesh.ext, min(__builtin_amdgcn_readfirstlane(nr.skip), last_rec));
-    const uint32_t off_in = off;
-    bool done = false;
-#else
     const NodeExt nr = *reinterpret_cast<const NodeExt*>(reinterpret_cast<const char*>(mesh.ext) + off);
-#endif
     const bool active = off >= resume;                        // this brick has not dropped / emitted an ancestor
     // closest point of the disc-slab to q:  q - c = ax * n_s + lat * l / |l|   (common.h NodeExt, ext_dist2)
     const float vx = q.x - nr.cx, vy = q.y - nr.cy, vz = q.z - nr.cz;
@@ -1818,13 +1800,8 @@ __global__ __launch_bounds__(64) void k_cut(DeviceMesh mesh, GridParams g, const
     const float ax = copysignf(fmaxf(fabsf(dt) - nr.half, 0.0f), dt);
     const float L2 = __builtin_fmaf(ax, ax, lat * lat);
     bool keep = active & !(L2 > R2);                          // sphere test; NaN keeps the node
-#if M2S_CUT_PREFETCH
-    if (__ballot(keep) == 0ull) { off = nr.skip; done = true; }
-    if (!done) {
-#else
     if (__ballot(keep) == 0ull) { off = nr.skip; continue; }
     {
-#endif
       // gradient test (lanes without it carry grad_c0 = inf: never dropped).  rcp / rsq instead of IEEE divisions: their
       // 1-ulp error is nothing beside the 2e-5 added under the root
       const float ne_s = __builtin_fmaf(nr.nz, e.z, __builtin_fmaf(nr.ny, e.y, nr.nx * e.x));            // n_s . e
@@ -1839,13 +1816,8 @@ __global__ __launch_bounds__(64) void k_cut(DeviceMesh mesh, GridParams g, const
       const bool drop = (A > 0.0f) & (A * A > grad_c1sq * nme2);                                         // A > c1 |n - e| without the root; false on NaN
       keep = keep & !drop;
     }
-#if M2S_CUT_PREFETCH
-    if (!done && __ballot(keep) == 0ull) { off = nr.skip; done = true; }
-    if (!done) {
-#else
     const unsigned long long bal = __ballot(keep);
     if (bal == 0ull) { off = nr.skip; continue; }
-#endif
     // Where many triangles are (nearly) equidistant — towards the medial axis, e.g. deep inside a round body — the brick-level
     // test keeps a large part of the tree however far it descends: a brick that has already opened `budget` nodes emits what
     // it meets next as it is and leaves the rest to the packet's per-voxel tests (which are 200 times sharper there).
@@ -1862,10 +1834,6 @@ __global__ __launch_bounds__(64) void k_cut(DeviceMesh mesh, GridParams g, const
     opened += (keep & !emit) ? 1u : 0u;
     if (active & (emit | !keep)) resume = nr.skip;            // done with this subtree either way
     off = (__ballot(keep & !emit) != 0ull) ? off + NB : nr.skip;   // some brick still has to look inside
-#if M2S_CUT_PREFETCH
-    }
-    nxt = (off == off_in + NB) ? pre_child : pre_skip;
-#endif
   }
   if (!in_grid) return;
   if (n == 0) { n = 1; last_start = 0; last_end = end; }    // cannot happen with finite input; never walk nothing

@@ -159,7 +159,7 @@ __device__ __forceinline__ void fold_scene(int* __restrict__ scene, uint32_t n_p
 template <uint32_t W>
 __global__ __launch_bounds__(W / 4) void k_sort_tiles(const Box* __restrict__ boxes, uint32_t n, int* __restrict__ scene, uint32_t n_partials,
                                                       uint4* __restrict__ tiles, uint4* __restrict__ samples,
-                                                      uint64_t* __restrict__ keys_out, uint32_t* __restrict__ order_out, int dbg) {
+                                                      uint64_t* __restrict__ keys_out, uint32_t* __restrict__ order_out) {
   constexpr uint32_t T = W / 4;
   __shared__ uint64_t sk[W];
   __shared__ uint32_t si[W];
@@ -188,7 +188,7 @@ __global__ __launch_bounds__(W / 4) void k_sort_tiles(const Box* __restrict__ bo
   }
   for (uint32_t u = 0; u < 4; ++u) { sk[e0 + u] = k[u]; si[e0 + u] = v[u]; }
   __syncthreads();
-  if (!(dbg & 16)) bitonic_rounds<T>(sk, si, W, 8u, tid);
+  bitonic_rounds<T>(sk, si, W, 8u, tid);
   if (keys_out) {                                   // the whole mesh in one tile: these are the sorted arrays
     for (uint32_t e = tid; e < W && e < n; e += T) { keys_out[e] = sk[e]; order_out[e] = si[e]; }
     return;
@@ -261,7 +261,7 @@ __global__ __launch_bounds__(SS_RANK_THREADS) void k_sort_rank(const uint4* __re
 template <uint32_t W>
 __global__ __launch_bounds__(SS_BUCKET_THREADS) void k_sort_buckets(const uint4* __restrict__ tiles, uint32_t n, uint32_t p,
                                                                     const uint4* __restrict__ splitters, const uint8_t* __restrict__ cmat,
-                                                                    uint64_t* __restrict__ keys_out, uint32_t* __restrict__ order_out, int* __restrict__ err, int dbg) {
+                                                                    uint64_t* __restrict__ keys_out, uint32_t* __restrict__ order_out, int* __restrict__ err) {
   constexpr uint32_t SP = W / SS_G, T = SS_BUCKET_THREADS, MAXP = ss_max_tiles(W);
   __shared__ uint64_t sk[SS_CAP];
   __shared__ uint32_t si[SS_CAP];
@@ -355,7 +355,7 @@ __global__ __launch_bounds__(SS_BUCKET_THREADS) void k_sort_buckets(const uint4*
     si[i] = vv;
   }
   __syncthreads();
-  if (N > 1u && !(dbg & 32)) bitonic_rounds<T>(sk, si, N, 2u, tid);
+  if (N > 1u) bitonic_rounds<T>(sk, si, N, 2u, tid);
   for (uint32_t i = tid; i < m; i += T) { keys_out[goff + i] = sk[i]; order_out[goff + i] = si[i]; }
 }
 
@@ -382,11 +382,11 @@ void launch_sample_sort(hipStream_t st, const Box* boxes, uint32_t n, int* scene
                         uint64_t* keys_out, uint32_t* order_out, int* d_err) {
   const uint32_t p = (n + W - 1u) / W;
   if (p == 1u) {
-    hipLaunchKernelGGL(k_sort_tiles<W>, dim3(1), dim3(W / 4), 0, st, boxes, n, scene, n_partials, (uint4*)nullptr, (uint4*)nullptr, keys_out, order_out, tuning().dbg_skip);
+    hipLaunchKernelGGL(k_sort_tiles<W>, dim3(1), dim3(W / 4), 0, st, boxes, n, scene, n_partials, (uint4*)nullptr, (uint4*)nullptr, keys_out, order_out);
     return;
   }
-  hipLaunchKernelGGL(k_sort_tiles<W>, dim3(p), dim3(W / 4), 0, st, boxes, n, scene, n_partials, sb.tiles, sb.samples, (uint64_t*)nullptr, (uint32_t*)nullptr, tuning().dbg_skip);
+  hipLaunchKernelGGL(k_sort_tiles<W>, dim3(p), dim3(W / 4), 0, st, boxes, n, scene, n_partials, sb.tiles, sb.samples, (uint64_t*)nullptr, (uint32_t*)nullptr);
   hipLaunchKernelGGL(k_sort_rank<W>, dim3(p), dim3(SS_RANK_THREADS), 0, st, (const uint4*)sb.samples, p, sb.splitters, sb.cmat);
   hipLaunchKernelGGL(k_sort_buckets<W>, dim3(p * SS_PER_TILE), dim3(SS_BUCKET_THREADS), 0, st, (const uint4*)sb.tiles, n, p, (const uint4*)sb.splitters,
-                     (const uint8_t*)sb.cmat, keys_out, order_out, d_err, tuning().dbg_skip);
+                     (const uint8_t*)sb.cmat, keys_out, order_out, d_err);
 }

@@ -22,7 +22,6 @@ struct Entry {
 const Entry TABLE[] = {
     M2S_KNOB("M2S_STATS", K_INT, stats),
     M2S_KNOB("M2S_HOST_TIMES", K_INT, host_times),
-    M2S_KNOB("M2S_DBG_SKIP", K_INT, dbg_skip),
     M2S_KNOB("M2S_LANE_WALK", K_INT, lane_walk),
     M2S_KNOB("M2S_TREELETS", K_INT, treelets),
     M2S_KNOB("M2S_SORT_TILE", K_INT, sort_tile),

@@ -13,7 +13,6 @@ namespace m2s {
 struct Tuning {
   // ---- diagnostics
   int stats = 0;                    // M2S_STATS        1: traversal counters of the packet walk on stderr, 2: + a counting pass from the final bound
-  int dbg_skip = 0;                 // M2S_DBG_SKIP     timing experiments only (results are wrong): parts of the build's kernels left out, by bit
   int host_times = 0;               // M2S_HOST_TIMES   1: where the host time of a call goes, on stderr
   // ---- which walk (tests force each flavour; the defaults are measured crossovers, distance.hip)
   int lane_walk = -1;               // M2S_LANE_WALK    -1 automatic, 0 never, 1 always: one voxel / query per lane instead of one packet per wave
