@@ -410,7 +410,7 @@ void m2s_gltf_close(m2s_gltf* gltf);
 /* Library / device introspection. */
 /* The one-off costs of a process's first call, paid now instead: the HIP runtime and this library's code objects on `device`
  * (-1 = the current one), the streams and events of the device's context, `workspace_bytes` of device workspace (0 = none: it
- * grows on demand; a 512^3 grid call needs ~0.6 GB, 10 M queries ~1.5 GB) and, for callers of the host-pointer entry points, the
+ * grows on demand; a 512^3 grid call needs ~0.4 GB, 10 M queries ~1.5 GB) and, for callers of the host-pointer entry points, the
  * pinned staging ring (`host_ring_bytes` > 0: three slots of min(host_ring_bytes, 64 MB)).  Optional, idempotent (a repeated call
  * touches only what has grown since), blocking.  The workspace it grows is the one of the library's OWN stream: a caller that passes
  * m2s_opts.stream (or stream_mode 1) works out of a block per stream, which still grows, and is first touched, in that caller's first call.
