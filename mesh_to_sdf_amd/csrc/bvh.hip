@@ -437,15 +437,18 @@ __device__ __forceinline__ void node_ext_wave(const NodeRec& nr, uint32_t slot, 
   }
 }
 
-// Both in one launch: a thread per small node; the few larger nodes among a block's 256 slots are queued in LDS and taken by the
-// block's four waves afterwards.  (Two launches before — one thread per node, then one WAVE per node of which 94 % returned at once:
-// 16 + 37 us of the build's critical path for 100 k triangles.  Measured in round 5 and not kept: the large nodes found by internal
-// node id in extra workgroups, spread evenly instead of a root-to-leaf spine per workgroup — 30.3 against 29.7 us at 100 k triangles,
-// 206 against 189 at 1 M (the locality of a workgroup's own slots is worth more); eight waves per workgroup with the two parts side
-// by side — 35.7 us.)
+// Both in one launch: a thread per small node; the few larger nodes among a block's 256 slots are queued in LDS (with their records:
+// the queuing thread holds them) and taken by the block's four waves afterwards, FOUR nodes at a time per wave — the nodes of up to
+// 64 triangles among them (one triangle per lane: 12 of a typical workgroup's 15) fetch all their normals, then all their vertices,
+// in two round trips where node after node took two each.  (Two launches before — one thread per node, then one WAVE per node of which
+// 94 % returned at once: 16 + 37 us of the build's critical path for 100 k triangles.  Measured in round 5 and not kept: the large
+// nodes found by internal node id in extra workgroups, spread evenly instead of a root-to-leaf spine per workgroup — 30.3 against
+// 29.7 us at 100 k triangles, 206 against 189 at 1 M (the locality of a workgroup's own slots is worth more); eight waves per workgroup
+// with the two parts side by side — 35.7 us.)
 __global__ __launch_bounds__(256) void k_node_ext(const NodeRec* __restrict__ nodes, const uint32_t* __restrict__ slot_first,
                                                   const float4* __restrict__ nrm, const float4* __restrict__ corners, uint32_t n_nodes, NodeExt* __restrict__ ext) {
-  __shared__ uint32_t big[256];
+  __shared__ NodeRec big_nr[256];
+  __shared__ uint32_t big_slot[256], big_first[256];
   __shared__ uint32_t n_big;
   if (threadIdx.x == 0) n_big = 0;
   __syncthreads();
@@ -454,13 +457,80 @@ __global__ __launch_bounds__(256) void k_node_ext(const NodeRec* __restrict__ no
     const NodeRec nr = nodes[slot];
     const uint32_t cnt = (nr.skip - slot + 1u) >> 1;
     if (cnt <= EXT_THREAD_BELOW) node_ext_thread(nr, slot, cnt, slot_first, nrm, corners, ext);
-    else big[atomicAdd(&n_big, 1u)] = slot;
+    else {
+      const uint32_t at = atomicAdd(&n_big, 1u);
+      big_nr[at] = nr;
+      big_slot[at] = slot;
+      big_first[at] = slot_first[slot];
+    }
   }
   __syncthreads();
-  const uint32_t nb = n_big;
-  for (uint32_t k = threadIdx.x >> 6; k < nb; k += 4u) {
-    const NodeRec nr = nodes[big[k]];
-    node_ext_wave(nr, big[k], slot_first[big[k]], (nr.skip - big[k] + 1u) >> 1, (int)(threadIdx.x & 63u), nrm, corners, ext);
+  const uint32_t nb = n_big, wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+  const float inf = __builtin_inff();
+  for (uint32_t k0 = wave; k0 < nb; k0 += 16u) {
+    NodeRec nr[4];
+    uint32_t sl[4], first[4], cnt[4];
+    bool have[4], one[4];                                      // a node of this group; one triangle per lane
+#pragma unroll
+    for (uint32_t u = 0; u < 4; ++u) {
+      const uint32_t k = k0 + 4u * u;
+      have[u] = k < nb;
+      nr[u] = big_nr[have[u] ? k : k0];
+      sl[u] = big_slot[have[u] ? k : k0];
+      first[u] = big_first[have[u] ? k : k0];
+      cnt[u] = (nr[u].skip - sl[u] + 1u) >> 1;
+      one[u] = have[u] && cnt[u] <= 64u;
+    }
+    float4 nv[4];
+#pragma unroll
+    for (uint32_t u = 0; u < 4; ++u) nv[u] = (one[u] && lane < cnt[u]) ? nrm[first[u] + lane] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    float4 q0[4], q1[4], q2[4];
+#pragma unroll
+    for (uint32_t u = 0; u < 4; ++u) {
+      const float4* q = corners + 3 * (size_t)(first[u] + min(lane, cnt[u] - 1u));
+      if (one[u]) { q0[u] = q[0]; q1[u] = q[1]; q2[u] = q[2]; }
+    }
+#pragma unroll
+    for (uint32_t u = 0; u < 4; ++u) {
+      if (!one[u]) continue;
+      // the same sums, in the same order, as node_ext_wave takes for a node of at most 64 triangles
+      float sx = 0.0f, sy = 0.0f, sz = 0.0f;
+      if (lane < cnt[u] && fabsf(nv[u].x) < 3.0e38f && fabsf(nv[u].y) < 3.0e38f && fabsf(nv[u].z) < 3.0e38f) { sx += nv[u].x; sy += nv[u].y; sz += nv[u].z; }
+      sx = wave_sum(sx); sy = wave_sum(sy); sz = wave_sum(sz);
+      const float len = sqrtf(sx * sx + sy * sy + sz * sz);
+      float nx = 1.0f, ny = 0.0f, nz = 0.0f;
+      if (len > 1.0e-30f && len < 3.0e38f) { nx = sx / len; ny = sy / len; nz = sz / len; }
+      float cx = 0.5f * (nr[u].mnx + nr[u].mxx), cy = 0.5f * (nr[u].mny + nr[u].mxy), cz = 0.5f * (nr[u].mnz + nr[u].mxz);
+      if (!(fabsf(cx) < 3.0e38f)) cx = 0.0f;
+      if (!(fabsf(cy) < 3.0e38f)) cy = 0.0f;
+      if (!(fabsf(cz) < 3.0e38f)) cz = 0.0f;
+      float dlo = inf, dhi = -inf, r2 = 0.0f, w2max = 0.0f;
+      if (lane < cnt[u]) {
+        const float vx[3] = {q0[u].x, q0[u].w, q1[u].z}, vy[3] = {q0[u].y, q1[u].x, q1[u].w}, vz[3] = {q0[u].z, q1[u].y, q2[u].x};
+        for (int k = 0; k < 3; ++k) {
+          const float wx = vx[k] - cx, wy = vy[k] - cy, wz = vz[k] - cz;
+          const float tt = nx * wx + ny * wy + nz * wz;
+          const float w2 = wx * wx + wy * wy + wz * wz;
+          dlo = fminf(dlo, tt);
+          dhi = fmaxf(dhi, tt);
+          r2 = fmaxf(r2, w2 - tt * tt);
+          w2max = fmaxf(w2max, w2);
+        }
+      }
+      dlo = wave_min(dlo); dhi = wave_max(dhi); r2 = wave_max(r2); w2max = wave_max(w2max);
+      if (lane == 0u) {
+        const float R = sqrtf(fmaxf(r2, 0.0f) + 1.0e-6f * w2max) * 1.00001f + 1.0e-30f;
+        const float e = 1.0e-5f * (fabsf(dlo) + fabsf(dhi)) + 2.0e-6f * sqrtf(w2max) + 1.0e-30f;
+        NodeExt x;
+        x.cx = cx; x.cy = cy; x.cz = cz; x.R = R;
+        x.nx = nx; x.ny = ny; x.nz = nz; set_slab(x, dlo - e, dhi + e);
+        x.skip = nr[u].skip * (uint32_t)sizeof(NodeExt); x.tri = nr[u].tri; x.pad = 0;   // BYTE offset of the skip target
+        ext[sl[u]] = x;
+      }
+    }
+#pragma unroll
+    for (uint32_t u = 0; u < 4; ++u)
+      if (have[u] && !one[u]) node_ext_wave(nr[u], sl[u], first[u], cnt[u], (int)lane, nrm, corners, ext);
   }
 }
 
