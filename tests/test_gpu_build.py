@@ -50,3 +50,22 @@ def test_build_same_tree_blob_1m():
     from mesh_to_sdf_amd import meshes
 
     _same_tree("blob-1M", *meshes.named("blob-1M"))
+
+
+@pytest.mark.parametrize("n", [1024, 1025, 2048, 2049, 122880, 122881, 229376, 229377])
+def test_sort_forms_build_the_same_tree(n):
+    """The build's sort (lbvh_sort.hip.h): one tile, the three-launch sample sort with tiles of 1 024 and of 2 048 pairs, rocPRIM — sizes on
+    both sides of every switch, triangles in RANDOM order (every tile then has the same key distribution: the case the staggered samples
+    are for) with a fifth of the keys repeated.  Every form must leave the same tree as rocPRIM's stable sort."""
+    from mesh_to_sdf_amd import _lib
+
+    rng = np.random.default_rng(n)
+    c = rng.uniform(-1, 1, (n, 1, 3)).astype(np.float32)
+    c[rng.integers(0, n, n // 5)] = c[rng.integers(0, n, n // 5)]          # repeated centres = repeated keys
+    v = (c + rng.uniform(-0.01, 0.01, (n, 3, 3)).astype(np.float32)).reshape(-1, 3)
+    idx = np.arange(3 * n, dtype=np.uint32)
+    with _lib.knobs(M2S_SORT_TILE=0):
+        want = _digest(v, idx)
+    for tile in (-1, 1024, 2048):
+        with _lib.knobs(M2S_SORT_TILE=tile):
+            assert _digest(v, idx) == want, f"M2S_SORT_TILE={tile} builds another tree for {n} triangles"
