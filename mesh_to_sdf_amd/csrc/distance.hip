@@ -2636,7 +2636,13 @@ int launch_grid_walk(hipStream_t st, const DeviceMesh& mesh, const GridParams& g
   // more than eight waves per SIMD leave and spill them to scratch, the very thing that costs this kernel 10 - 40 %: the automatic choice
   // leaves the Normal sign to the plain walk; M2S_SPLIT=1 / 2 still runs them — the tests do)
   const bool split_ok = mode != MODE_NORMAL_FOLD || tuning().split > 0;
-  const SplitCtl* split = (!brute && plan.split.cnt != nullptr && mesh.stats == nullptr && split_ok) ? &plan.split : nullptr;
+  SplitCtl piece_split = plan.split;
+  if (piece_split.cnt != nullptr && !plan.split_forced) {
+    // the patience is measured in hand-out rounds of THIS launch (an x-piece of the slab is shallower than the slab the plan was made for)
+    const double rounds_before = std::max(1.0, (double)packets / 8192.0 - 1.0);
+    piece_split.patience_q8 = (uint32_t)std::min(65535.0 * 256.0, 256.0 * tuning().split_patience / rounds_before);
+  }
+  const SplitCtl* split = (!brute && plan.split.cnt != nullptr && mesh.stats == nullptr && split_ok) ? &piece_split : nullptr;
   if (split) hipLaunchKernelGGL(k_split_init, dim3(1), dim3(64), 0, st, split->cnt, plan.split_forced ? 1u : 0u);
   if (mode == MODE_UNSIGNED && d_inside_plane) {
     if (brute) launch_brute<true, MODE_UNSIGNED, SIGN_GRID_PLANE>(st, mesh, g, nullptr, 0, d_inside_plane, d_out, d_err, packets, peers);
