@@ -1092,7 +1092,7 @@ size_t bvh_workspace_bytes(size_t n_tris) {
 
 int build_device_mesh(Arena& ws, hipStream_t st, const float* d_verts, size_t n_verts, const void* d_indices,
                       size_t n_indices, int index_bytes, int topology, size_t n_tris, int* d_err, DeviceMesh* out,
-                      const std::function<int(const float4*, const TriRec*, int)>* after_setup, bool records_only, uint32_t leaf_max) {
+                      const std::function<int(const float4*, const TriRec*, int)>* after_setup, bool records_only, uint32_t leaf_max, uint64_t job_cells) {
   (void)n_indices;
   out->cen_raw = nullptr;
   out->slot_of = nullptr;
@@ -1203,7 +1203,11 @@ int build_device_mesh(Arena& ws, hipStream_t st, const float* d_verts, size_t n_
   // blob-100k 64^3 0.88 / 0.85 ms, 128^3 0.82 / 0.78; blob-1M 128^3 3.41 / 3.17, 256^3 6.26 / 6.17; blob-11k 48^3 0.43 / 0.40).  With leaves of 4 it is a wash at
   // 100 k triangles (160^3 1.13 / 1.14), a loss at 1 M (384^3 11.3 / 11.6) and still a gain for small meshes (blob-11k 64^3 - 96^3 0.39 / 0.37): M2S_TREELETS -1.
   const int treelets = tuning().treelets;
-  const bool skip_treelets = leaf_max >= 8u || (leaf_max >= 4u && n_tris < 32768u);
+  // ... and a one-shot call over few cells walks too little for its 5 % to be worth the pass's 35 - 45 us (round 5, whole call with / without:
+  // suzanne, 968 triangles, Normal sign, 48^3 0.214 / 0.187 ms, 192^3 0.467 / 0.432, 256^3 0.685 / 0.661; blob-11k 128^3 0.419 / 0.401, 160^3 0.529 / 0.525,
+  // 256^3 0.931 / 0.937)
+  const bool few_cells = job_cells < (4u << 20) || (n_tris < 4096u && job_cells < (32u << 20));
+  const bool skip_treelets = leaf_max >= 8u || (leaf_max >= 4u && n_tris < 32768u) || few_cells;
   if (n > 2 && (treelets > 0 || (treelets < 0 && !skip_treelets))) {
     // treelet pass: the nodes of at most TREELET_MAX triangles are rebuilt by sweep splits (their keys rewritten), then the hierarchy is derived
     int2* roots = reinterpret_cast<int2*>(child);   // child[] is not used by the kernels below before k_karras rewrites it

@@ -1074,7 +1074,7 @@ int m2s_generate_grid_sdf(const float* vertices, size_t n_vertices, const void* 
     return 0;
   };
   rc = build_device_mesh(ws, c.stream, sm.d_verts, n_vertices, sm.d_indices, n_indices, index_bytes, topology, n_tris, d_err, &mesh,
-                         &seeds_beside_build, tiny, grid_leaf_max(g, n_tris));
+                         &seeds_beside_build, tiny, grid_leaf_max(g, n_tris), (uint64_t)slab_cells);
   if (rc) return rc;
   hc.lap("build enqueued (code objects on a first call)");
   M2S_HIP_CHECK(hipEventRecord(st->ev[1], c.stream));

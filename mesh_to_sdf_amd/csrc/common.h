@@ -229,7 +229,7 @@ size_t bvh_workspace_bytes(size_t n_tris);
 int build_device_mesh(Arena& ws, hipStream_t st, const float* d_verts, size_t n_verts, const void* d_indices,
                       size_t n_indices, int index_bytes, int topology, size_t n_tris, int* d_err, DeviceMesh* out,
                       const std::function<int(const float4*, const TriRec*, int)>* after_setup = nullptr, bool records_only = false,
-                      uint32_t leaf_max = 2);
+                      uint32_t leaf_max = 2, uint64_t job_cells = ~0ull);   // job_cells: the cells a one-shot grid call is about to walk (unknown: all ones)
 bool query_walk_is_lane(size_t n_q, size_t n_tris, int sign_src);       // distance.hip: sparse query sets take the lane walk
 uint32_t query_leaf_max(size_t n_q, size_t n_tris, int sign_src);       // ... and the leaf size a query call wants its tree to have
 uint32_t grid_leaf_max(const GridParams& g, size_t n_tris);   // distance.hip: the leaf size a grid call wants its tree to have

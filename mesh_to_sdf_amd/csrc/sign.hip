@@ -21,7 +21,8 @@ namespace m2s {
 
 namespace {
 
-constexpr int SMALL_WINDOW = 64;  // lines a lane handles alone; larger windows are spread over the wave
+constexpr uint32_t SMALL_WINDOW = 64;  // lines a lane handles alone; larger windows are spread over the wave
+constexpr uint32_t RAY_MARK_SHARED_BELOW = 16384;   // meshes of up to this many triangles: sixteen lanes per triangle (k_ray_mark<16>)
 
 struct Window {
   uint32_t ulo, uhi, wlo, whi;  // inclusive index ranges on the two free axes; empty if ulo > uhi
@@ -109,17 +110,24 @@ struct BigList {
   uint2* items;                  // x = triangle | axis << 30, y = first chunk;  nullptr: no list (small grids)
 };
 
-template <int AXIS>
-__device__ __forceinline__ void mark_axis(bool valid, uint32_t tri, f3 a, f3 b, f3 c, f3 mn, f3 mx, const GridParams& g, const SlabX& sx,
+// G lanes share a triangle (sub = this lane's place among them): the lines of a window of up to SMALL_WINDOW x G lines are dealt out to them
+template <int AXIS, uint32_t G>
+__device__ __forceinline__ void mark_axis(bool valid, uint32_t tri, uint32_t sub, f3 a, f3 b, f3 c, f3 mn, f3 mx, const GridParams& g, const SlabX& sx,
                                           uint32_t* __restrict__ plane, const BigList& list) {
   Window w = {1, 0, 1, 0};
   if (valid) w = make_window<AXIS>(mn, mx, g, sx);
   const uint32_t cnt = window_count(w);
-  const bool small = cnt <= SMALL_WINDOW;
+  bool small = cnt <= SMALL_WINDOW * G;
   if (small) {
-    for (uint32_t iu = w.ulo; iu <= w.uhi && cnt; ++iu)
-      for (uint32_t iw = w.wlo; iw <= w.whi; ++iw) mark_line<AXIS>(a, b, c, mn, mx, g, sx, iu, iw, plane);
+    if (G == 1u) {
+      for (uint32_t iu = w.ulo; iu <= w.uhi && cnt; ++iu)
+        for (uint32_t iw = w.wlo; iw <= w.whi; ++iw) mark_line<AXIS>(a, b, c, mn, mx, g, sx, iu, iw, plane);
+    } else {
+      const uint32_t nw = w.whi - w.wlo + 1u;
+      for (uint32_t i = sub; i < cnt; i += G) mark_line<AXIS>(a, b, c, mn, mx, g, sx, w.ulo + i / nw, w.wlo + i % nw, plane);
+    }
   }
+  if (sub != 0u) small = true;                       // a large window is its first lane's business
   if (list.items != nullptr) {
     // Windows too large for one lane go onto a work list; k_ray_mark_big spreads their lines over the whole
     // chip.  (A low-poly mesh in a fine grid has FEW triangles with HUGE windows: walking them with the owner's
@@ -154,9 +162,13 @@ __device__ __forceinline__ void mark_axis(bool valid, uint32_t tri, f3 a, f3 b, 
   }
 }
 
+// G = 1: a lane per triangle (meshes that fill the chip by themselves).  G = 16: sixteen lanes per triangle — a low-poly mesh has few
+// triangles with wide windows, and a lane that walks 3 x 64 lines alone is the whole sign phase (suzanne, 968 triangles, in 64^3:
+// 100 us of marking on 16 waves where everything else of the call's sign planes takes 20).
+template <uint32_t G>
 __global__ __launch_bounds__(256) void k_ray_mark(DeviceMesh mesh, GridParams g, SlabX sx, uint32_t* __restrict__ px,
                                                   uint32_t* __restrict__ py, uint32_t* __restrict__ pz, BigList list) {
-  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x, t = gid / G, sub = gid % G;
   const bool valid = t < mesh.n_tris;
   f3 a = {0, 0, 0}, b = {0, 0, 0}, c = {0, 0, 0}, mn = {0, 0, 0}, mx = {0, 0, 0};
   if (valid) {
@@ -166,9 +178,9 @@ __global__ __launch_bounds__(256) void k_ray_mark(DeviceMesh mesh, GridParams g,
     c = mk3(r.cx, r.cy, r.cz);
     triangle_bounding_box(a, b, c, &mn, &mx);
   }
-  mark_axis<0>(valid, t, a, b, c, mn, mx, g, sx, px, list);
-  mark_axis<1>(valid, t, a, b, c, mn, mx, g, sx, py, list);
-  mark_axis<2>(valid, t, a, b, c, mn, mx, g, sx, pz, list);
+  mark_axis<0, G>(valid, t, sub, a, b, c, mn, mx, g, sx, px, list);
+  mark_axis<1, G>(valid, t, sub, a, b, c, mn, mx, g, sx, py, list);
+  mark_axis<2, G>(valid, t, sub, a, b, c, mn, mx, g, sx, pz, list);
 }
 
 template <int AXIS>
@@ -336,7 +348,8 @@ int build_grid_sign_plane(Arena& ws, hipStream_t st, const DeviceMesh& mesh, con
       sx.period = g.period ? g.period : 1u;
     }
     const uint32_t layers = whole ? g.n[0] : vlayers;
-    hipLaunchKernelGGL(k_ray_mark, dim3((mesh.n_tris + B - 1) / B), dim3(B), 0, st, mesh, g, sx, px, py, pz, list);
+    if (mesh.n_tris <= RAY_MARK_SHARED_BELOW) hipLaunchKernelGGL(k_ray_mark<16>, dim3((mesh.n_tris * 16u + B - 1) / B), dim3(B), 0, st, mesh, g, sx, px, py, pz, list);
+    else hipLaunchKernelGGL(k_ray_mark<1>, dim3((mesh.n_tris + B - 1) / B), dim3(B), 0, st, mesh, g, sx, px, py, pz, list);
     if (list.items) hipLaunchKernelGGL(k_ray_mark_big, dim3(2048), dim3(B), 0, st, mesh, g, sx, px, py, pz, list);
     const size_t row_words = (size_t)g.n[1] * g.nzw;
     hipLaunchKernelGGL(k_scan_x, dim3((unsigned)((row_words + B - 1) / B)), dim3(B), 0, st, px, g.n[0], row_words, whole ? 0u : sx.lo);
@@ -358,7 +371,8 @@ void warm_sign(hipStream_t st) {
   hipLaunchKernelGGL(k_warm_sign, dim3(1), dim3(64), 0, st);
   // ... and resolves a kernel FUNCTION at its own first launch (~0.3 ms each): ask for the attributes of the ones a first call uses
   const void* fns[] = {
-      (const void*)k_ray_mark,
+      (const void*)k_ray_mark<1>,
+      (const void*)k_ray_mark<16>,
       (const void*)k_ray_mark_big,
       (const void*)k_scan_x,
       (const void*)k_scan_y};
