@@ -22,7 +22,10 @@ namespace m2s {
 namespace {
 
 constexpr uint32_t SMALL_WINDOW = 64;  // lines a lane handles alone; larger windows are spread over the wave
-constexpr uint32_t RAY_MARK_SHARED_BELOW = 16384;   // meshes of up to this many triangles: sixteen lanes per triangle (k_ray_mark<16>)
+#ifndef M2S_RAY_SHARED_BELOW
+#define M2S_RAY_SHARED_BELOW 16384
+#endif
+constexpr uint32_t RAY_MARK_SHARED_BELOW = M2S_RAY_SHARED_BELOW;   // meshes of up to this many triangles: sixteen lanes per triangle (k_ray_mark<16>)
 
 struct Window {
   uint32_t ulo, uhi, wlo, whi;  // inclusive index ranges on the two free axes; empty if ulo > uhi
