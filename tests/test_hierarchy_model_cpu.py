@@ -148,3 +148,32 @@ def test_treelet_roots_by_split(kind, n):
         if root:
             got.append((L + 1, s))
     assert sorted(got) == want
+
+
+def test_treelet_rank_by_sorting_composites_equals_counting_predecessors():
+    """k_treelet_lanes moves every item of an open segment to the lane of its rank by (key, position): for long segments by sorting the
+    composites (segment start, key, lane) over the whole wave and pulling, for short ones by counting predecessors and pushing.  Both
+    must give the same arrangement; items of closed segments stay."""
+    rng = np.random.default_rng(5)
+    for _ in range(200):
+        cuts = sorted(set(rng.integers(1, 64, rng.integers(0, 12)).tolist()))
+        starts = [0] + cuts
+        ends = cuts + [64]
+        s = np.zeros(64, dtype=np.int64); e = np.zeros(64, dtype=np.int64); is_open = np.zeros(64, dtype=bool)
+        for a, b in zip(starts, ends):
+            s[a:b], e[a:b] = a, b
+            is_open[a:b] = (b - a > 1) and rng.random() < 0.8
+        key = rng.integers(-5, 5, 64)                                  # many ties: the position decides
+        item = np.arange(64)
+        # counting form (push)
+        pushed = item.copy()
+        for lane in range(64):
+            rank = lane
+            if is_open[lane]:
+                rank = s[lane] + sum(1 for j in range(s[lane], e[lane]) if key[j] < key[lane] or (key[j] == key[lane] and j < lane))
+            pushed[rank] = item[lane]
+        # sorting form (pull)
+        ukey = np.where(is_open, key + 2 ** 31, 0)
+        comp = (s << 38) | (ukey << 6) | np.arange(64)
+        pulled = item[np.sort(comp) & 63]
+        assert (pushed == pulled).all()
