@@ -1227,7 +1227,8 @@ int build_device_mesh(Arena& ws, hipStream_t st, const float* d_verts, size_t n_
   // ... and a one-shot call over few cells walks too little for its 5 % to be worth the pass's 35 - 45 us (round 5, whole call with / without:
   // suzanne, 968 triangles, Normal sign, 48^3 0.214 / 0.187 ms, 192^3 0.467 / 0.432, 256^3 0.685 / 0.661; blob-11k 128^3 0.419 / 0.401, 160^3 0.529 / 0.525,
   // 256^3 0.931 / 0.937)
-  const bool few_cells = job_cells < (4u << 20) || (n_tris < 4096u && job_cells < (32u << 20));
+  // (blob-100k 160^3, 4.1 M cells: 1.022 with / 1.048 without — the limit is 3 M)
+  const bool few_cells = job_cells < (3u << 20) || (n_tris < 4096u && job_cells < (32u << 20));
   const bool skip_treelets = leaf_max >= 8u || (leaf_max >= 4u && n_tris < 32768u) || few_cells;
   if (n > 2 && (treelets > 0 || (treelets < 0 && !skip_treelets))) {
     // treelet pass: the nodes of at most TREELET_MAX triangles are rebuilt by sweep splits (their keys rewritten), then the hierarchy is derived

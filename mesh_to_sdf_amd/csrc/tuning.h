@@ -19,7 +19,7 @@ struct Tuning {
   double lane_ratio = 60.0;         // M2S_LANE_RATIO   grid: lane walk above this many triangles per packet brick
   double lane_ratio_split = 100.0;  // M2S_LANE_RATIO_SPLIT   ... and above this many where the packet walk's stragglers can be split (below)
   double query_lane_coeff = 2.5;    // M2S_QUERY_LANE_COEFF   queries: lane walk below this many queries per triangle
-  int treelets = -1;                // M2S_TREELETS     the build's treelet pass (groups of <= 64 triangles re-partitioned by sweep splits): 1 always, 0 never, -1 unless the leaves hold 8 or more triangles (4 or more below 32 768 triangles) or a one-shot grid call walks fewer than 4 M cells (32 M below 4 096 triangles)
+  int treelets = -1;                // M2S_TREELETS     the build's treelet pass (groups of <= 64 triangles re-partitioned by sweep splits): 1 always, 0 never, -1 unless the leaves hold 8 or more triangles (4 or more below 32 768 triangles) or a one-shot grid call walks fewer than 3 M cells (32 M below 4 096 triangles)
   int sort_tile = -1;               // M2S_SORT_TILE    the build's sort of the (key, triangle) pairs: -1 automatic (sample sort with tiles of 1024 / 2048 pairs up to 122 880 / 229 376 triangles, rocPRIM above), 0 rocPRIM always, 1024 / 2048 that tile size where it can hold the mesh
   uint32_t leaf_max = 0;            // M2S_LEAF_MAX     triangles per collapsed leaf of the tree a grid call walks (1 .. 16; a resident tree is re-marked); 0: by triangles per brick (2 / 4 / 8 / 16)
   double brute_max = -1.0;          // M2S_BRUTE_MAX    tree-less path for cells x triangles (queries x triangles) up to this; < 0: automatic, 0: never
