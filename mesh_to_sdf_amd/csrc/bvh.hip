@@ -7,11 +7,11 @@
 //
 // Pipeline (all on the call's stream, no host round trip):
 //   k_tri_setup     : indices -> (a,b,c), degeneracy class, padded box (geo.rs:4-22), scene bounds
-//   k_morton_keys   : 63-bit Morton key of the box centre
-//   rocprim radix sort (key,value)            — library sort, not on the parity path
+//   k_sort_tiles / k_sort_rank / k_sort_buckets (lbvh_sort.hip.h) : 63-bit Morton keys of the box centres and their sample sort;
+//                     above 229 376 triangles k_morton_keys + rocPRIM's radix sort — neither is on the parity path
 //   k_roots_from_keys, k_treelet_lanes : sweep-split treelets of <= 64 triangles (their keys rewritten as path codes)
-//   k_karras        : Karras 2012 hierarchy over the sorted keys (ranges, children, parents)
-//   k_seg_build     : segment tree of leaf boxes (fence-free refit)
+//   k_hierarchy     : Karras 2012 ranges over the sorted keys, the segment tree of leaf boxes (fence-free refit) and the record sets
+//                     that place a node in pre-order, side by side in one launch
 //   k_emit          : node boxes by range query, pre-order index = 2*first + #left-turns, skip links
 //   k_node_ext      : oriented bound (disc-shaped slab) of every node
 #include <algorithm>
@@ -540,18 +540,18 @@ __global__ __launch_bounds__(256) void k_node_ext(const NodeRec* __restrict__ no
 // LBVH nodes of at most TREELET_MAX triangles; k_treelet_lanes rebuilds each with one wave: top-down, every segment split along the
 // widest axis of its triangle-box centres at the position that minimises (sum of box extents) x (triangle count) over both sides.
 // The triangles of the node are reordered inside its range of the sorted arrays and their keys keep the node's Morton prefix
-// followed by the path in the new treelet (prefix-free codes), so the radix tree over the keys (k_karras) is the LBVH above the
+// followed by the path in the new treelet (prefix-free codes), so the radix tree over the keys (k_hierarchy's Karras ranges) is the LBVH above the
 // node and the new treelet inside.
 constexpr int TREELET_MAX = 64;   // one wave holds a treelet's items in its lanes
 
-// The treelet roots straight from the sorted keys, without the hierarchy.  The radix tree over the keys (ties broken by position, as k_karras does: the common prefix of two EQUAL keys j < j' is
+// The treelet roots straight from the sorted keys, without the hierarchy.  The radix tree over the keys (ties broken by position, as karras_range does: the common prefix of two EQUAL keys j < j' is
 // 64 + clz(j ^ j')) has the property that the common prefix of any two positions is the minimum of the ADJACENT prefixes between
 // them, so the nodes that contain position p are found by growing [l, r] from [p, p]: the next node up shares c = max(d[l - 1], d[r])
 // bits and reaches as far as the adjacent prefixes stay >= c.  The largest such node of at most TREELET_MAX triangles is p's
 // treelet; it is a root of the old list iff it has at least 3 triangles, and its first position reports it.  A block keeps the
 // adjacent prefixes of its 256 positions plus 66 either side in LDS (a node of <= 64 reaches no further, and one step beyond shows
 // that its parent is too large).
-__device__ __forceinline__ int adjacent_prefix(const uint64_t* __restrict__ keys, int n, int j) {   // delta(j, j + 1) of k_karras; -1 outside
+__device__ __forceinline__ int adjacent_prefix(const uint64_t* __restrict__ keys, int n, int j) {   // delta(j, j + 1) of karras_range; -1 outside
   if (j < 0 || j + 1 >= n) return -1;
   const uint64_t a = keys[j], b = keys[j + 1];
   return a == b ? 64 + __clz((uint32_t)j ^ (uint32_t)(j + 1)) : __clzll((long long)(a ^ b));
@@ -871,13 +871,13 @@ __global__ __launch_bounds__(64) void k_treelet_lanes(const int2* __restrict__ r
 // The build is the part of a multi-GPU rank's step that does not shard, so it is a few FULL launches rather than many small ones
 // (round 2: ~45 launch-bound kernels, 0.36 ms for 100 k triangles; tests/golden/build_digests.json pins the tree that sequence and
 // this one both produced, byte for byte):
-//   k_tri_setup + k_clear_aux   records, boxes, centroids, per-block scene partials; counters and parent markers
-//   k_morton_keys               every block folds the scene partials itself and writes its tile's keys
-//   rocPRIM radix_sort_pairs    (a block sort + merges at these sizes; three own LSD sorts lost to it)
+//   k_tri_setup                 records, boxes, centroids, per-block scene partials; clears the build's counters
+//   k_sort_tiles / _rank / _buckets   keys + sample sort (lbvh_sort.hip.h); above 229 376 triangles: k_morton_keys (every block folds the scene
+//                               partials itself and writes its tile's keys) + rocPRIM radix_sort_pairs (a block sort + merges)
 //   k_roots_from_keys           treelet roots straight from the sorted keys
 //   k_treelet_lanes             sweep-split treelets, one wave each, items in lanes
-//   k_karras                    the hierarchy, once, over the rewritten keys
-//   k_seg_build                 ten segment-tree levels per block in LDS, the last block to finish adds the top levels
+//   k_hierarchy                 the Karras ranges, once, over the rewritten keys; beside them ten segment-tree levels per block in LDS and
+//                               the record-set scans, the last block to finish adding the top levels
 //   k_emit, k_node_ext          pre-order records, oriented bounds
 constexpr int KEY_THREADS = 512, KEY_CHUNK = KEY_THREADS * 8;
 constexpr uint32_t KEY_MAX_TILES = 128;
@@ -890,7 +890,7 @@ __host__ __device__ inline uint32_t key_tiles(size_t n) {
   const uint32_t tp = key_tile_pairs(n);
   return tp ? (uint32_t)((n + tp - 1) / tp) : 0u;
 }
-constexpr size_t AUX_WORDS = 16;   // [0]: k_seg_build's finished blocks
+constexpr size_t AUX_WORDS = 16;   // [0]: k_hierarchy's finished segment-tree blocks
 
 // 63-bit Morton key of every triangle's box centre (21 bits per axis over the scene's box of centres) and the identity permutation.
 // One block per tile; every block folds the per-block scene partials of k_tri_setup itself, block 0 publishes the final values
@@ -1159,7 +1159,7 @@ int build_device_mesh(Arena& ws, hipStream_t st, const float* d_verts, size_t n_
   NodeExt* ext = ws.take<NodeExt>(2 * n_tris);
   uint32_t* slot_first = ws.take<uint32_t>(2 * n_tris);
   int* scene = ws.take<int>(8 + 6 * ((n_tris + 255) / 256));
-  uint32_t* aux = ws.take<uint32_t>(AUX_WORDS);   // [0]: k_seg_build's finished blocks
+  uint32_t* aux = ws.take<uint32_t>(AUX_WORDS);   // [0]: k_hierarchy's finished segment-tree blocks
   size_t sort_tmp = 0;
   (void)rocprim::radix_sort_pairs(nullptr, sort_tmp, keys, keys2, vals, order, n_tris, 0, 64, st);
   void* tmp = ws.take<char>(sort_tmp ? sort_tmp : 1);
@@ -1232,7 +1232,7 @@ int build_device_mesh(Arena& ws, hipStream_t st, const float* d_verts, size_t n_
   const bool skip_treelets = leaf_max >= 8u || (leaf_max >= 4u && n_tris < 32768u) || few_cells;
   if (n > 2 && (treelets > 0 || (treelets < 0 && !skip_treelets))) {
     // treelet pass: the nodes of at most TREELET_MAX triangles are rebuilt by sweep splits (their keys rewritten), then the hierarchy is derived
-    int2* roots = reinterpret_cast<int2*>(child);   // child[] is not used by the kernels below before k_karras rewrites it
+    int2* roots = reinterpret_cast<int2*>(child);   // child[]: a scratch array nothing else uses
     hipLaunchKernelGGL(k_roots_from_keys, dim3(cdiv(n_tris, B)), dim3(B), 0, st, (const uint64_t*)keys2, n, roots, scene + 7);
     hipLaunchKernelGGL(k_treelet_lanes, dim3((unsigned)std::min<size_t>((n_tris + 2) / 3, 8192)), dim3(64), 0, st, roots, scene + 7, boxes, keys2, order);
   }

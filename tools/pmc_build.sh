@@ -13,7 +13,7 @@ for C in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM" "SQ_WAVE_CYCLES SQ
   i=$((i+1))
   ( cd /tmp && timeout 200 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_$i -o p -- $CMD > $OUT/pmc_$i.log 2>&1 )
 done
-for K in k_tri_setup k_morton_hist k_karras k_treelet_roots_block k_treelet_lanes k_seg_build k_emit k_node_ext; do
+for K in k_tri_setup k_sort_tiles k_sort_rank k_sort_buckets k_roots_from_keys k_treelet_lanes k_hierarchy k_emit k_node_ext; do
   echo "== $K"; python tools/pmc_summary.py $OUT $K
 done > $OUT/summary.txt 2>&1
 find $OUT -name "*.db" -delete
