@@ -542,6 +542,9 @@ __global__ __launch_bounds__(256) void k_node_ext(const NodeRec* __restrict__ no
 // The triangles of the node are reordered inside its range of the sorted arrays and their keys keep the node's Morton prefix
 // followed by the path in the new treelet (prefix-free codes), so the radix tree over the keys (k_hierarchy's Karras ranges) is the LBVH above the
 // node and the new treelet inside.
+#ifndef M2S_TREELET_SORT_ABOVE
+#define M2S_TREELET_SORT_ABOVE 12
+#endif
 constexpr int TREELET_MAX = 64;   // one wave holds a treelet's items in its lanes
 
 // The treelet roots straight from the sorted keys, without the hierarchy.  The radix tree over the keys (ties broken by position, as karras_range does: the common prefix of two EQUAL keys j < j' is
@@ -774,7 +777,7 @@ __global__ __launch_bounds__(64) void k_treelet_lanes(const int2* __restrict__ r
     // that rank.  (The count alone was 76 instructions per four items: 1 200 of the first level's 1 900.)
     int longest = open ? e - s : 0;
     for (int o = 32; o > 0; o >>= 1) longest = max(longest, __shfl_xor(longest, o));
-    if (longest > 12) {
+    if (longest > M2S_TREELET_SORT_ABOVE) {
       const uint32_t ukey = open ? (uint32_t)key ^ 0x80000000u : 0u;
       unsigned long long comp = ((unsigned long long)(uint32_t)s << 38) | ((unsigned long long)ukey << 6) | (unsigned long long)(uint32_t)lane;
 #pragma unroll
