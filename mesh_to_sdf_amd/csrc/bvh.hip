@@ -667,8 +667,14 @@ __device__ __forceinline__ ScanMasks scan_masks(int lane, int s, int e) {
   m.down[3] = __ballot(r + 8 <= 15 && lane + 8 < e);
   return m;
 }
-#define M2S_SCAN3(OP, CTRL, MASK)                                                                     \
-  asm volatile("s_nop 1\n\t"                                                                          \
+// The compiler pads no hazard around or inside inline assembly.  A block's own hazard is the VALU write of a, b, c by the block in front of it ->
+// DPP read: two wait states (s_nop 1).  The FIRST block of a scan follows compiler-scheduled code, which may end in a VALU write of EXEC (v_cmpx,
+// five wait states before a DPP instruction) or of a, b, c: it pads five (NOP = "4").  v_min / v_max_f32 return the other operand for a quiet NaN
+// as fminf / fmaxf do; box extents never carry a signalling NaN (they come out of arithmetic), and the golden digests include NaN / inf boxes.
+#define M2S_SCAN3(OP, CTRL, MASK) M2S_SCAN3_N("1", OP, CTRL, MASK)
+#define M2S_SCAN3_FIRST(OP, CTRL, MASK) M2S_SCAN3_N("4", OP, CTRL, MASK)
+#define M2S_SCAN3_N(NOP, OP, CTRL, MASK)                                                               \
+  asm volatile("s_nop " NOP "\n\t"                                                                     \
                "v_" OP "_f32_dpp %3, %0, %0 " CTRL "\n\t"                                              \
                "v_" OP "_f32_dpp %4, %1, %1 " CTRL "\n\t"                                              \
                "v_" OP "_f32_dpp %5, %2, %2 " CTRL "\n\t"                                              \
@@ -682,14 +688,14 @@ template <bool MIN>
 __device__ __forceinline__ void seg_prefix3(float& a, float& b, float& c, const ScanMasks& m) {
   float t0, t1, t2;
   if (MIN) {
-    M2S_SCAN3("min", "row_shr:1 row_mask:0xf bank_mask:0xf", m.up[0]);
+    M2S_SCAN3_FIRST("min", "row_shr:1 row_mask:0xf bank_mask:0xf", m.up[0]);
     M2S_SCAN3("min", "row_shr:2 row_mask:0xf bank_mask:0xf", m.up[1]);
     M2S_SCAN3("min", "row_shr:4 row_mask:0xf bank_mask:0xf", m.up[2]);
     M2S_SCAN3("min", "row_shr:8 row_mask:0xf bank_mask:0xf", m.up[3]);
     M2S_SCAN3("min", "row_bcast:15 row_mask:0xa bank_mask:0xf", m.up[4]);
     M2S_SCAN3("min", "row_bcast:31 row_mask:0xc bank_mask:0xf", m.up[5]);
   } else {
-    M2S_SCAN3("max", "row_shr:1 row_mask:0xf bank_mask:0xf", m.up[0]);
+    M2S_SCAN3_FIRST("max", "row_shr:1 row_mask:0xf bank_mask:0xf", m.up[0]);
     M2S_SCAN3("max", "row_shr:2 row_mask:0xf bank_mask:0xf", m.up[1]);
     M2S_SCAN3("max", "row_shr:4 row_mask:0xf bank_mask:0xf", m.up[2]);
     M2S_SCAN3("max", "row_shr:8 row_mask:0xf bank_mask:0xf", m.up[3]);
@@ -702,12 +708,12 @@ template <bool MIN>
 __device__ __forceinline__ void seg_suffix3(float& a, float& b, float& c, const ScanMasks& m, int lane, int e) {
   float t0, t1, t2;
   if (MIN) {
-    M2S_SCAN3("min", "row_shl:1 row_mask:0xf bank_mask:0xf", m.down[0]);
+    M2S_SCAN3_FIRST("min", "row_shl:1 row_mask:0xf bank_mask:0xf", m.down[0]);
     M2S_SCAN3("min", "row_shl:2 row_mask:0xf bank_mask:0xf", m.down[1]);
     M2S_SCAN3("min", "row_shl:4 row_mask:0xf bank_mask:0xf", m.down[2]);
     M2S_SCAN3("min", "row_shl:8 row_mask:0xf bank_mask:0xf", m.down[3]);
   } else {
-    M2S_SCAN3("max", "row_shl:1 row_mask:0xf bank_mask:0xf", m.down[0]);
+    M2S_SCAN3_FIRST("max", "row_shl:1 row_mask:0xf bank_mask:0xf", m.down[0]);
     M2S_SCAN3("max", "row_shl:2 row_mask:0xf bank_mask:0xf", m.down[1]);
     M2S_SCAN3("max", "row_shl:4 row_mask:0xf bank_mask:0xf", m.down[2]);
     M2S_SCAN3("max", "row_shl:8 row_mask:0xf bank_mask:0xf", m.down[3]);
@@ -1300,6 +1306,9 @@ void warm_bvh(hipStream_t st) {
       (const void*)k_sort_tiles<1024>,
       (const void*)k_sort_rank<1024>,
       (const void*)k_sort_buckets<1024>,
+      (const void*)k_sort_tiles<2048>,
+      (const void*)k_sort_rank<2048>,
+      (const void*)k_sort_buckets<2048>,
       (const void*)k_morton_keys,
       (const void*)k_roots_from_keys,
       (const void*)k_treelet_lanes,

@@ -206,6 +206,9 @@ template <uint32_t W>
 __global__ __launch_bounds__(SS_RANK_THREADS) void k_sort_rank(const uint4* __restrict__ samples, uint32_t p, uint4* __restrict__ splitters,
                                                                uint8_t* __restrict__ cmat) {
   constexpr uint32_t SP = W / SS_G, Q = SP / SS_PER_TILE, PARTS = SS_RANK_THREADS / SP, MAXS = ss_max_tiles(W) * SP;
+  // all samples of all tiles in LDS: 12 bytes each, 86 KB for W = 2048 — gfx950's 160 KB of LDS per CU (one workgroup per CU there); this
+  // library is gfx950-only (Makefile: ARCH), a 64 KB-LDS target would have to stream the other tiles' runs through a window instead
+  static_assert(MAXS * 12u + SP * 4u <= 160u * 1024u, "k_sort_rank keeps every sample in LDS: needs gfx950's 160 KB");
   __shared__ uint64_t sk[MAXS];
   __shared__ uint32_t si[MAXS];
   __shared__ uint32_t s_rank[SP];
@@ -372,7 +375,8 @@ struct SortBufs {
   uint4* splitters = nullptr;
   uint8_t* cmat = nullptr;
 };
-inline size_t sample_sort_bytes(size_t n) {                       // an upper estimate for any tile size
+inline size_t sample_sort_bytes(size_t n) {                       // nothing where rocPRIM sorts (the tile x bucket matrix is quadratic in n:
+  if (sort_tile_size(n) == 0u) return 0;                          // 380 MB at 10 M triangles, 9.5 GB at 50 M); else an upper estimate for either tile size
   const size_t p = (n + 1023) / 1024;
   return (n + 2048) * 16 + p * 64 * 16 + p * SS_PER_TILE * 16 + p * p * SS_PER_TILE + 4 * 256;
 }
