@@ -96,11 +96,17 @@ __host__ __device__ __forceinline__ uint32_t bricks_along(uint32_t cells, uint32
   return (cells + (1u << log2_extent) - 1u) >> log2_extent;
 }
 __host__ __device__ __forceinline__ uint32_t super_brick_xlog(uint32_t nbx, uint32_t xl_cap = 0) {
-  for (uint32_t xl = xl_cap ? xl_cap - 1u : 3u; xl > 0; --xl) {
+  // the largest xl in 1 .. min(3, xl_cap - 1) whose padding is at most nbx / 8, else 0.  Straight-line: every packet computes it in its
+  // prologue, and the compiler turned the loop over xl (trip count from xl_cap) into an eight-wide "vectorised" scalar monster of ~100
+  // SALU + 26 VALU instructions per packet (round 6, found in the -S listing).
+  const uint32_t top = xl_cap ? xl_cap - 1u : 3u;
+  uint32_t r = 0;
+#pragma unroll
+  for (uint32_t xl = 1; xl <= 3u; ++xl) {
     const uint32_t padded = ((nbx + (1u << xl) - 1u) >> xl) << xl;
-    if ((padded - nbx) * 8u <= nbx) return xl;
+    if (xl <= top && (padded - nbx) * 8u <= nbx) r = xl;
   }
-  return 0;
+  return r;
 }
 __device__ __forceinline__ uint32_t div_magic(uint32_t n, uint32_t d, uint32_t magic) {
   return magic ? __umulhi(n, magic) : n / d;   // common.h set_super_brick_magic
@@ -1616,46 +1622,6 @@ static void launch_jfa_pass(hipStream_t st, const GridParams& g, const float4* i
     hipLaunchKernelGGL(k_jfa_pass, dim3(nb), dim3(256), 0, st, g, (const GridParams*)nullptr, in, out, step, ids);
 }
 
-// Coarse-to-fine flooding (round 6).  The long steps of the flood only carry candidates across the EMPTY part of the lattice, where
-// a point's nearest centroid is the same as its neighbours': they run on a lattice of half the resolution (an eighth of the points)
-// whose points sit at the centres of 2 x 2 x 2 packet bricks; k_jfa_refine then gives every fine point the best of (the triangle
-// splatted into its own cell, the flooded candidates of the 2 x 2 x 2 coarse points around it), and two unit passes over the fine
-// lattice — the second one leaves the ids — let the fine splats travel two cells.  Passes over a lattice of P points: before
-// (log2 P^(1/3) + 1) P, now 2 P + P / 8 x log2: 1024^3 over 100 k triangles (256^3 brick centres) 5.97 -> ~1 ms on the critical path
-// of the call, the 512^3 call's side stream 0.40 -> 0.17 ms beside the build.  Seeds are a starting bound, never a result:
-// any triangle is a valid seed, so the walks' output cannot change (and does not: parity suite + soaks).
-__global__ __launch_bounds__(256) void k_jfa_refine(DeviceMesh mesh, GridParams gf, GridParams gc, const unsigned long long* __restrict__ keys_f,
-                                                    const float4* __restrict__ lat_c, float4* __restrict__ out) {
-  const uint32_t n0 = gf.n[0], n1 = gf.n[1], n2 = gf.n[2];
-  const size_t i = (size_t)blockIdx.x * 256u + threadIdx.x;
-  if (i >= (size_t)n0 * n1 * n2) return;
-  const uint32_t z = (uint32_t)(i % n2), y = (uint32_t)((i / n2) % n1), x = (uint32_t)(i / ((size_t)n2 * n1));
-  const f3 p = lattice_point(gf, x, y, z);
-  // the two coarse points per axis that enclose the fine one (clamped: at the border both are the same point)
-  const uint32_t cx[2] = {min(x >> 1, gc.n[0] - 1u), min((x & 1u) ? (x >> 1) + 1u : max(x >> 1, 1u) - 1u, gc.n[0] - 1u)};
-  const uint32_t cy[2] = {min(y >> 1, gc.n[1] - 1u), min((y & 1u) ? (y >> 1) + 1u : max(y >> 1, 1u) - 1u, gc.n[1] - 1u)};
-  const uint32_t cz[2] = {min(z >> 1, gc.n[2] - 1u), min((z & 1u) ? (z >> 1) + 1u : max(z >> 1, 1u) - 1u, gc.n[2] - 1u)};
-  float4 c[9];
-#pragma unroll
-  for (int k = 0; k < 8; ++k) c[k] = lat_c[((size_t)cx[k >> 2] * gc.n[1] + cy[(k >> 1) & 1]) * gc.n[2] + cz[k & 1]];
-  const uint32_t own = (uint32_t)(keys_f[i] & 0xffffffffull);        // untouched cells hold ~0
-  c[8] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0xffffffffu));
-  if (own != 0xffffffffu) { c[8] = mesh.cen[own]; c[8].w = __uint_as_float(own); }
-  unsigned long long key = 0x7f800000ffffffffull;                    // (+inf, no triangle)
-  float4 bc = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0xffffffffu));
-#pragma unroll
-  for (int k = 0; k < 9; ++k) {
-    const uint32_t cand = __float_as_uint(c[k].w);
-    const float ex = p.x - c[k].x, ey = p.y - c[k].y, ez = p.z - c[k].z;
-    const float d = __builtin_fmaf(ex, ex, __builtin_fmaf(ey, ey, ez * ez));
-    const unsigned long long kk = ((unsigned long long)__float_as_uint(d) << 32) | cand;   // nearer, or as near with the smaller id (as k_jfa_pass32)
-    const bool take = cand != 0xffffffffu && kk < key;
-    key = take ? kk : key;
-    bc = take ? c[k] : bc;
-  }
-  out[i] = bc;
-}
-
 // ---- k_lane_q: the lane walk for generic queries ---------------------------------------------
 // One sorted query per lane, every lane on its own through the tree (as k_lane) and, for the best-of-three-rays sign, through the
 // box tree along each axis.  For SPARSE query sets: a packet of 64 of 100 000 queries in the benchmark box is 44 cells of the 512^3
@@ -1823,10 +1789,24 @@ __global__ __launch_bounds__(64) void k_cut(DeviceMesh mesh, GridParams g, const
   };
   uint32_t n = 0, last_start = 0, last_end = 0, resume = 0, opened = 0;   // per lane
   uint32_t off = 0, steps = 0;                                // wave-uniform
+#ifdef M2S_STATS_BUILD
+  // M2S_STATS: where a wave's node visits go — on nodes larger than the wave's own block of 4 x 4 x 4 bricks (what a coarser level
+  // of lists could decide once for several waves) or below
+  uint32_t st_visits = 0, st_above1 = 0, st_above4 = 0, st_pruned_above1 = 0;
+  const float st_block = 4.0f * __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, r)));
+#endif
   while (off < end) {
     off = __builtin_amdgcn_readfirstlane(off);
     ++steps;
     const NodeExt nr = *reinterpret_cast<const NodeExt*>(reinterpret_cast<const char*>(mesh.ext) + off);
+#ifdef M2S_STATS_BUILD
+    {
+      const float ext = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, fmaxf(nr.R, nr.half))));
+      ++st_visits;
+      st_above1 += ext > st_block ? 1u : 0u;
+      st_above4 += ext > 4.0f * st_block ? 1u : 0u;
+    }
+#endif
     const bool active = off >= resume;                        // this brick has not dropped / emitted an ancestor
     // closest point of the disc-slab to q:  q - c = ax * n_s + lat * l / |l|   (common.h NodeExt, ext_dist2)
     const float vx = q.x - nr.cx, vy = q.y - nr.cy, vz = q.z - nr.cz;
@@ -1875,6 +1855,16 @@ __global__ __launch_bounds__(64) void k_cut(DeviceMesh mesh, GridParams g, const
     if (active & (emit | !keep)) resume = nr.skip;            // done with this subtree either way
     off = (__ballot(keep & !emit) != 0ull) ? off + NB : nr.skip;   // some brick still has to look inside
   }
+#ifdef M2S_STATS_BUILD
+  if (mesh.stats != nullptr && lane == 0u) {
+    atomicAdd(&mesh.stats[104], 1ull);
+    atomicAdd(&mesh.stats[105], (unsigned long long)st_visits);
+    atomicAdd(&mesh.stats[106], (unsigned long long)st_above1);
+    atomicAdd(&mesh.stats[107], (unsigned long long)st_above4);
+    atomicMax(&mesh.stats[108], (unsigned long long)st_visits);
+  }
+  (void)st_pruned_above1;
+#endif
   if (!in_grid) return;
   if (n == 0) { n = 1; last_start = 0; last_end = end; }    // cannot happen with finite input; never walk nothing
   out[n] = cut_word(last_start, last_end);
@@ -2412,17 +2402,12 @@ bool grid_is_tiny(const GridParams& g, size_t n_tris, int algorithm) {
   const double cells = (double)(g.xe - g.xb) * g.n[1] * g.n[2];
   return cells <= 4194304.0 && cells * (double)n_tris <= limit;
 }
-// the half-resolution seed lattice (launch_grid_seeds): two records and a key per point
-static size_t seed_coarse_bytes(const GridParams& g) {
-  const size_t c0 = bricks_along(bricks_along(g.xe - g.xb, g.bl[0]), 1), c1 = bricks_along(bricks_along(g.n[1], g.bl[1]), 1), c2 = bricks_along(bricks_along(g.n[2], g.bl[2]), 1);
-  return c0 * c1 * c2 * 40 + 1024;
-}
 size_t grid_distance_workspace_bytes(const GridParams& g, size_t n_tris) {
   const size_t bricks = (size_t)host_brick_count(g);
   if ((double)(g.xe - g.xb) * g.n[1] * g.n[2] <= 4194304.0)   // room for k_brute_split's per-voxel words
-    return bricks * 44 + bricks + 16384 + seed_coarse_bytes(g) + cut_blocks(g, 0) * CUT_WORDS * 4 + bricks * 64 * 8 + 4096 + split_workspace_bytes(g, n_tris, bricks);
+    return bricks * 44 + bricks + 16384 + cut_blocks(g, 0) * CUT_WORDS * 4 + bricks * 64 * 8 + 4096 + split_workspace_bytes(g, n_tris, bricks);
   const size_t trail_counters = (size_t)bricks_along(g.xe - g.xb, g.bl[0]) * (bricks_along(g.n[1], g.bl[1]) + 1) * 4;   // M2S_PEER_TRAIL progress
-  return bricks * 44 + bricks + 16384 + seed_coarse_bytes(g) + cut_blocks(g, 0) * CUT_WORDS * 4 + trail_counters + 1024 + split_workspace_bytes(g, n_tris, bricks);   // seeds + cut lists (one per brick) + split walk
+  return bricks * 44 + bricks + 16384 + cut_blocks(g, 0) * CUT_WORDS * 4 + trail_counters + 1024 + split_workspace_bytes(g, n_tris, bricks);   // seeds + cut lists (one per brick) + split walk
 }
 
 __global__ __launch_bounds__(256) void k_seed_remap(uint32_t* __restrict__ ids, size_t n, const uint32_t* __restrict__ slot_of, uint32_t n_tris) {
@@ -2459,37 +2444,14 @@ int launch_grid_seeds(Arena& ws, hipStream_t st, const float4* cen, uint32_t n_t
   const unsigned nb1 = (unsigned)((points1 + 255) / 256);
   M2S_HIP_CHECK(hipMemsetAsync(keys, 0xff, points1 * 8, st));
   hipLaunchKernelGGL(k_jfa_splat, dim3((mesh.n_tris + 255) / 256), dim3(256), 0, st, mesh, g1, nullptr, keys);
-  // M2S_SEED_COARSE: -1 automatic (lattices of 2^19 points or more: below that every pass is a launch floor and the two forms cost the
-  // same), 0 never, 1 always (tests).  An interleaved slab needs whole coarse points per chunk.
-  const int coarse_knob = tuning().seed_coarse;
-  const bool chunks_ok = g.chunk_log >= 31u || g.chunk_log >= stride_log[0] + 1u;
-  const bool coarse = chunks_ok && g1.n[0] >= 2u && g1.n[1] >= 2u && g1.n[2] >= 2u && (coarse_knob > 0 || (coarse_knob < 0 && points1 >= (1u << 19)));
-  if (coarse) {
-    const uint32_t stride2[3] = {stride_log[0] + 1u, stride_log[1] + 1u, stride_log[2] + 1u};
-    const GridParams g2 = coarse_level(g, stride2, g.xb);
-    const size_t points2 = (size_t)g2.n[0] * g2.n[1] * g2.n[2];
-    float4* ca = ws.take<float4>(points2);
-    float4* cb = ws.take<float4>(points2);
-    unsigned long long* keys2 = ws.take<unsigned long long>(points2);
-    if (!ca || !cb || !keys2) { set_error("internal: seed workspace too small"); return M2S_ERR_HIP_INTERNAL; }
-    const unsigned nb2 = (unsigned)((points2 + 255) / 256);
-    M2S_HIP_CHECK(hipMemsetAsync(keys2, 0xff, points2 * 8, st));
-    hipLaunchKernelGGL(k_jfa_splat, dim3((mesh.n_tris + 255) / 256), dim3(256), 0, st, mesh, g2, nullptr, keys2);
-    hipLaunchKernelGGL(k_jfa_load, dim3(nb2), dim3(256), 0, st, mesh, keys2, points2, ca);
-    const uint32_t maxdim2 = max(g2.n[0], max(g2.n[1], g2.n[2]));
-    int step2 = 1;
-    while ((uint32_t)step2 * 2 < maxdim2) step2 *= 2;
-    float4 *src2 = ca, *dst2 = cb;
-    for (; step2 >= 1; step2 /= 2) {
-      launch_jfa_pass(st, g2, src2, dst2, step2, nullptr);
-      float4* t = src2; src2 = dst2; dst2 = t;
-    }
-    hipLaunchKernelGGL(k_jfa_refine, dim3(nb1), dim3(256), 0, st, mesh, g1, g2, keys, (const float4*)src2, la);
-    launch_jfa_pass(st, g1, la, lb, 1, nullptr);
-    launch_jfa_pass(st, g1, lb, la, 1, ids);
-  } else {
-    hipLaunchKernelGGL(k_jfa_load, dim3(nb1), dim3(256), 0, st, mesh, keys, points1, la);
+  // (Round 6, measured and not kept: the flood's long steps on a lattice of half the resolution + a refinement pass — the seeds get worse by
+  // a few hundredths of a cell far from the surface, where a packet's candidate set grows with the square root of exactly that: the
+  // headline walk 6.44 -> 7.00 ms with every step but the last two at half resolution, 6.76 -> 7.16 with only the steps >= 16 there;
+  // profiles/r06_seed_coarse_*.txt.  A bound from the lanes' FINAL minima would take 1.5 % of the node tests, 12 % of the pre-tests and
+  // 18 % of the exact evaluations: profiles/r06_stats2_headline.txt.)
+  {
     const uint32_t maxdim = max(g1.n[0], max(g1.n[1], g1.n[2]));
+    hipLaunchKernelGGL(k_jfa_load, dim3(nb1), dim3(256), 0, st, mesh, keys, points1, la);
     int step = 1;
     while ((uint32_t)step * 2 < maxdim) step *= 2;
     float4 *src = la, *dst = lb;

@@ -33,7 +33,6 @@ const Entry TABLE[] = {
     M2S_KNOB("M2S_CUT_MIN_PACKETS", K_U32, cut_min_packets),
     M2S_KNOB("M2S_QUERY_CUT_MIN", K_U32, query_cut_min),
     M2S_KNOB("M2S_QUERY_LAUNCH_TIGHT", K_INT, query_launch_tight),
-    M2S_KNOB("M2S_SEED_COARSE", K_INT, seed_coarse),
     M2S_KNOB("M2S_CUT_NEAR", K_F32, cut_near),
     M2S_KNOB("M2S_CUT_FAR", K_F32, cut_far),
     M2S_KNOB("M2S_CUT_WAVE_CAP", K_U32, cut_wave_cap),

@@ -26,7 +26,6 @@ struct Tuning {
   uint32_t cut_min_packets = 100000;// M2S_CUT_MIN_PACKETS   grid: cut lists from this many packets on
   uint32_t query_cut_min = 20000;   // M2S_QUERY_CUT_MIN     queries: cut lists from this many packets on
   int query_launch_tight = 0;       // M2S_QUERY_LAUNCH_TIGHT  test hook: forces the consecutive-packet fallback of the query packets
-  int seed_coarse = -1;             // M2S_SEED_COARSE  grid seeds: -1 automatic (lattices of 2^19 brick centres or more flood at half resolution, then refine), 0 never, 1 always
   // ---- cut lists
   float cut_near = 2.0f;            // M2S_CUT_NEAR     emission radius of a list entry, in brick radii (next to the surface)
   float cut_far = 1.0f / 32.0f;     // M2S_CUT_FAR      ... and as a fraction of the distance (far from it)

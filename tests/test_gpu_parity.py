@@ -51,8 +51,7 @@ def cut_lists_mode(request):
     forced = {}
     if mode == "cut lists on every grid":
         # M2S_BRUTE_MAX=0: no brute-force shortcut for tiny problems (the default mode takes it): the walks must see them
-        forced = {"M2S_CUT_MIN_PACKETS": 8, "M2S_QUERY_CUT_MIN": 1, "M2S_LANE_WALK": 0, "M2S_BRUTE_MAX": 0, "M2S_SPLIT": 0, "M2S_TREELETS": 0,   # (and a tree without the treelet pass)
-                  "M2S_SEED_COARSE": 1}                                   # (and seeds flooded at half resolution, as the large grids' are)
+        forced = {"M2S_CUT_MIN_PACKETS": 8, "M2S_QUERY_CUT_MIN": 1, "M2S_LANE_WALK": 0, "M2S_BRUTE_MAX": 0, "M2S_SPLIT": 0, "M2S_TREELETS": 0}   # (and a tree without the treelet pass)
     elif mode == "lane walks":
         forced = {"M2S_LANE_WALK": 1, "M2S_BRUTE_MAX": 0, "M2S_LEAF_MAX": 3}
     elif mode == "split walks":
