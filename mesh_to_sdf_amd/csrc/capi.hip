@@ -356,6 +356,9 @@ static int stats_end(hipStream_t stream, const unsigned long long* d_stats) {
   if (h[104])
     fprintf(stderr, "[m2s stats]   k_cut: %llu waves (4 x 4 x 4 bricks each), node visits per wave %.1f (longest %llu), of them on nodes larger than the wave's block %.1f (%.1f %%), larger than 4 x the block %.1f (%.1f %%)\n",
             h[104], (double)h[105] / h[104], h[108], (double)h[106] / h[104], 100.0 * h[106] / (h[105] ? h[105] : 1), (double)h[107] / h[104], 100.0 * h[107] / (h[105] ? h[105] : 1));
+  if (h[112])
+    fprintf(stderr, "[m2s stats]   k_cut coarse level: %llu waves (4 x 4 x 4 blocks x one of 8 subtrees each), node visits per wave %.1f (longest %llu), on nodes larger than a block %.1f, larger than 4 x a block %.1f\n",
+            h[112], (double)h[113] / h[112], h[116], (double)h[114] / h[112], (double)h[115] / h[112]);
   // grid path: by distance of the packet's first voxel to its seed triangle, in cells: [0,1) [1,2) [2,4) ... [64,inf)
   for (int bk = 0; bk < 8; ++bk) {
     const unsigned long long* q = h + 8 + 8 * bk;

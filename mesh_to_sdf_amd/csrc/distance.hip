@@ -1720,14 +1720,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(M2S_LANE_WA
 // the Morton order) per wave; centre and radius from `centres` (k_qpacket_bounds), the seed from the lattice cell of the
 // centre (as k_packet<false> does), `nbx` = the number of wave slots the packet walk was launched with.
 constexpr uint32_t NB_CUT = (uint32_t)sizeof(NodeExt);
-template <bool GRID>
+// Two levels (round 6; grids only).  Of a fine wave's node visits on 512^3 x blob-100k 44 % fall on nodes larger than the wave's own block
+// of 4 x 4 x 4 bricks (16 % on nodes larger than four blocks; 1024^3 x sheet-100k: 61 % / 29 %; counted, profiles/r06_kcut_visits.txt),
+// and its 63 neighbours inside a 64^3-voxel region repeat them with the same outcome.  LEVEL 1 walks that top ONCE per region: lane =
+// a block of 4 x 4 x 4 bricks (the same tests with the block's radius; witness triangle = the seed of the brick at the block's centre —
+// any triangle bounds the final minimum from above), one wave per 4 x 4 x 4 blocks AND per one of CUTC_S subtrees of the tree's top
+// (a single wave per region would be a chain of ~300 dependent visits on a launch of a few hundred waves: as long as what it saves),
+// and leaves CUTC_S sub-lists of <= CUTC_MAX ranges per block.  LEVEL 2 is the fine walk started from its block's ranges instead of
+// the root.  A subtree the coarse level drops holds nothing a voxel of the block can need, whatever the fine level's own seeds say,
+// so the fine lists can only get shorter; the packets' results cannot change (parity suite, soaks).
+constexpr uint32_t CUTC_S_LOG = 3, CUTC_S = 1u << CUTC_S_LOG, CUTC_WORDS = 8, CUTC_MAX = CUTC_WORDS - 1;   // 64 words = 256 B per block
+static_assert(CUTC_S * CUTC_WORDS == 64, "a fine wave fetches its block's coarse record with one load, lane = word");
+template <bool GRID, int LEVEL = 0>
 __global__ __launch_bounds__(64) void k_cut(DeviceMesh mesh, GridParams g, const uint32_t* __restrict__ seeds, uint32_t seed_shift,
                                             uint32_t seed_ny, uint32_t seed_nz, uint32_t nbx, uint32_t nby, uint32_t nbz,
                                             uint32_t* __restrict__ lists, float emit_near, float emit_far, uint32_t budget, uint32_t wave_cap,
                                             const float4* __restrict__ centres, const uint32_t* __restrict__ table,
-                                            const GridParams* __restrict__ seed_lattice) {
+                                            const GridParams* __restrict__ seed_lattice, const uint32_t* __restrict__ coarse = nullptr) {
+  static_assert(GRID || LEVEL == 0, "the two-level form is the grid's");
+  // LEVEL 1: the "bricks" of this launch are blocks of 4 x 4 x 4 packet bricks (nbx, nby, nbz count blocks), eight waves per 4 x 4 x 4 of them
+  constexpr uint32_t UL = LEVEL == 1 ? 2u : 0u;               // log2 packet bricks per lane unit and axis
+  constexpr uint32_t NMAX = LEVEL == 1 ? CUTC_MAX : CUT_MAX;  // ranges per list
+  constexpr uint32_t OUT_WORDS = LEVEL == 1 ? CUTC_WORDS : CUT_WORDS;
   const uint32_t nsy = (nby + 3u) >> 2, nsz = (nbz + 3u) >> 2;
-  const uint32_t sb = blockIdx.x;                            // 4 x 4 x 4 bricks
+  const uint32_t sb = LEVEL == 1 ? blockIdx.x >> CUTC_S_LOG : blockIdx.x;   // 4 x 4 x 4 units
+  const uint32_t sub = LEVEL == 1 ? blockIdx.x & (CUTC_S - 1u) : 0u;        // LEVEL 1: which subtree of the top
   const uint32_t sz = sb % nsz, sy = (sb / nsz) % nsy, sx = sb / (nsz * nsy);
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t bk[3] = {4u * sx + (lane >> 4), 4u * sy + ((lane >> 2) & 3u), 4u * sz + (lane & 3u)};
@@ -1735,12 +1752,13 @@ __global__ __launch_bounds__(64) void k_cut(DeviceMesh mesh, GridParams g, const
   bool in_grid = bk[0] < nbx && bk[1] < nby && bk[2] < nbz;
   float r = 0.0f, qq[3];
   if (GRID) {
-    // first cell of the brick in the grid (a brick never straddles two chunks of an interleaved slab: capi.hip checks)
-    const uint32_t cell0[3] = {slab_x(g, bk[0] << g.bl[0]), bk[1] << g.bl[1], bk[2] << g.bl[2]};
+    // first cell of the unit in the grid (a brick never straddles two chunks of an interleaved slab: capi.hip checks; a block
+    // does not either where the coarse level is used: prepare_grid_walk)
+    const uint32_t cell0[3] = {slab_x(g, bk[0] << (g.bl[0] + UL)), bk[1] << (g.bl[1] + UL), bk[2] << (g.bl[2] + UL)};
     for (int k = 0; k < 3; ++k) {
-      const float hb = 0.5f * (float)((1u << g.bl[k]) - 1u) * fabsf(g.size[k]);   // half extent between voxel centres
+      const float hb = 0.5f * (float)((1u << (g.bl[k] + UL)) - 1u) * fabsf(g.size[k]);   // half extent between voxel centres
       r = __builtin_fmaf(hb, hb, r);
-      qq[k] = g.first[k] + ((float)cell0[k] + 0.5f * (float)((1u << g.bl[k]) - 1u)) * g.size[k];
+      qq[k] = g.first[k] + ((float)cell0[k] + 0.5f * (float)((1u << (g.bl[k] + UL)) - 1u)) * g.size[k];
     }
     r = sqrtf(r) * 1.0001f;
   } else {
@@ -1753,12 +1771,17 @@ __global__ __launch_bounds__(64) void k_cut(DeviceMesh mesh, GridParams g, const
   const f3 q = mk3(qq[0], qq[1], qq[2]);
   const float scale = fmaxf(mesh_scale(mesh), fmaxf(fabsf(q.x), fmaxf(fabsf(q.y), fabsf(q.z))) + r);
   const float abs_margin = 6.4e-5f * scale + 4.0e-5f;        // the packet walk's own slack is <= 4e-6 * scale + 2.5e-6
-  float R2 = -1.0f, R = 0.0f, D = 0.0f;                      // brick outside the grid: never keeps anything
+  float R2 = -1.0f, R = 0.0f, D = 0.0f;                      // unit outside the grid: never keeps anything
   f3 e = mk3(0.0f, 0.0f, 0.0f);
   float grad_c0 = __builtin_inff(), grad_c1 = 0.0f;          // gradient test: drop if L * (1 - 1e-4) - grad_c0 > grad_c1 * |n - e|
   if (in_grid) {
-    const uint32_t sidx = GRID ? ((bk[0] >> seed_shift) * seed_ny + (bk[1] >> seed_shift)) * seed_nz + (bk[2] >> seed_shift)
-                               : query_lattice_cell(*seed_lattice, q.x, q.y, q.z);
+    uint32_t sidx;
+    if (!GRID) sidx = query_lattice_cell(*seed_lattice, q.x, q.y, q.z);
+    else if (LEVEL == 1) {                                    // the brick at the block's centre (seed lattice: one point per brick)
+      const uint32_t lx = bricks_along(g.xe - g.xb, g.bl[0]);
+      const uint32_t b0 = min((bk[0] << 2) + 2u, lx - 1u), b1 = min((bk[1] << 2) + 2u, seed_ny - 1u), b2 = min((bk[2] << 2) + 2u, seed_nz - 1u);
+      sidx = (b0 * seed_ny + b1) * seed_nz + b2;
+    } else sidx = ((bk[0] >> seed_shift) * seed_ny + (bk[1] >> seed_shift)) * seed_nz + (bk[2] >> seed_shift);
     const uint32_t slot = min(seeds[sidx], mesh.n_tris - 1);
     const TriRec& t = mesh.tris[slot];
     const f3 a = mk3(t.ax, t.ay, t.az), bq = mk3(t.bx, t.by, t.bz), c = mk3(t.cx, t.cy, t.cz);
@@ -1781,20 +1804,56 @@ __global__ __launch_bounds__(64) void k_cut(DeviceMesh mesh, GridParams g, const
   const float emit_radius = fmaxf(emit_near * r, R * emit_far);
 
   constexpr uint32_t NB = (uint32_t)sizeof(NodeExt);
-  const uint32_t end = mesh.n_nodes * NB;
-  uint32_t* out = lists + ((size_t)(in_grid ? (GRID ? (bk[0] * nby + bk[1]) * nbz + bk[2] : pk) : 0u)) * CUT_WORDS;
+  const uint32_t tree_end = mesh.n_nodes * NB;
+  uint32_t* out = lists + ((size_t)(in_grid ? (GRID ? (bk[0] * nby + bk[1]) * nbz + bk[2] : pk) : 0u)) * (LEVEL == 1 ? CUTC_S * CUTC_WORDS : OUT_WORDS)
+                  + sub * CUTC_WORDS;
   const uint32_t cut_S = cut_start_bits(mesh.n_nodes);
   auto cut_word = [cut_S](uint32_t start, uint32_t stop) {   // byte offsets -> list word (see CUT_WORDS)
     return (start / NB_CUT) | (cut_encode_len((stop - start) / NB_CUT, 27u - cut_S) << cut_S);
   };
   uint32_t n = 0, last_start = 0, last_end = 0, resume = 0, opened = 0;   // per lane
-  uint32_t off = 0, steps = 0;                                // wave-uniform
+  uint32_t off = 0, end = tree_end, steps = 0;                // wave-uniform
+  if (LEVEL == 1) {
+    // this wave's subtree: CUTC_S_LOG levels down from the root, left or right by the bits of `sub`.  A leaf met on the way belongs to
+    // the wave whose remaining bits are zero; the others have nothing to walk.
+    for (uint32_t lv = 0; lv < CUTC_S_LOG && off < end; ++lv) {
+      const NodeExt* nr = reinterpret_cast<const NodeExt*>(reinterpret_cast<const char*>(mesh.ext) + off);
+      const uint32_t rest = sub & ((1u << (CUTC_S_LOG - lv)) - 1u);
+      if (__builtin_amdgcn_readfirstlane(nr->tri) >= 0) { if (rest != 0u) end = off; break; }
+      const uint32_t left = off + NB;
+      const uint32_t right = __builtin_amdgcn_readfirstlane(reinterpret_cast<const NodeExt*>(reinterpret_cast<const char*>(mesh.ext) + left)->skip);
+      const uint32_t skip = __builtin_amdgcn_readfirstlane(nr->skip);
+      if ((sub >> (CUTC_S_LOG - 1u - lv)) & 1u) { off = right; end = skip; } else { off = left; end = right; }
+    }
+  }
+  // LEVEL 2: the block's coarse record, lane = word; ranges are taken from it one by one
+  uint32_t cw = 0, c_sub = 0, c_k = 0, c_cnt = 0;
+  if (LEVEL == 2) {
+    cw = coarse[(size_t)sb * (CUTC_S * CUTC_WORDS) + lane];
+    off = end = 0;
+    c_cnt = (uint32_t)__builtin_amdgcn_readlane((int)cw, 0);
+  }
 #ifdef M2S_STATS_BUILD
   // M2S_STATS: where a wave's node visits go — on nodes larger than the wave's own block of 4 x 4 x 4 bricks (what a coarser level
   // of lists could decide once for several waves) or below
-  uint32_t st_visits = 0, st_above1 = 0, st_above4 = 0, st_pruned_above1 = 0;
-  const float st_block = 4.0f * __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, r)));
+  uint32_t st_visits = 0, st_above1 = 0, st_above4 = 0;
+  const float st_block = (LEVEL == 1 ? 1.0f : 4.0f) * __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, r)));
 #endif
+  for (;;) {
+    if (LEVEL == 2) {
+      while (c_k >= c_cnt) {                                  // next non-empty sub-list
+        if (++c_sub >= CUTC_S) break;
+        c_k = 0;
+        c_cnt = (uint32_t)__builtin_amdgcn_readlane((int)cw, (int)(c_sub * CUTC_WORDS));
+      }
+      if (c_sub >= CUTC_S) break;
+      const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)cw, (int)(c_sub * CUTC_WORDS + 1u + c_k));
+      ++c_k;
+      const uint32_t first = w & ((1u << cut_S) - 1u);
+      const uint32_t len = ((w >> cut_S) & ((1u << (27u - cut_S)) - 1u)) << (w >> 27);
+      off = max(first * NB, off);                             // (a rounded-up range may reach into the next one: never walk back)
+      end = min(first + len, mesh.n_nodes) * NB;
+    }
   while (off < end) {
     off = __builtin_amdgcn_readfirstlane(off);
     ++steps;
@@ -1841,11 +1900,11 @@ __global__ __launch_bounds__(64) void k_cut(DeviceMesh mesh, GridParams g, const
     // Where many triangles are (nearly) equidistant — towards the medial axis, e.g. deep inside a round body — the brick-level
     // test keeps a large part of the tree however far it descends: a brick that has already opened `budget` nodes emits what
     // it meets next as it is and leaves the rest to the packet's per-voxel tests (which are 200 times sharper there).
-    // (a saturated list — CUT_MAX ranges — only grows its last range over every gap from here on: nothing finer can be said)
-    const bool emit = keep & (nr.tri >= 0 || fmaxf(nr.R, nr.half) <= emit_radius || opened >= budget || n == CUT_MAX || steps >= wave_cap);
+    // (a saturated list — NMAX ranges — only grows its last range over every gap from here on: nothing finer can be said)
+    const bool emit = keep & (nr.tri >= 0 || fmaxf(nr.R, nr.half) <= emit_radius || opened >= budget || n == NMAX || steps >= wave_cap);
     if (emit) {
-      // keep this subtree: [off, skip).  Adjacent subtrees merge; past CUT_MAX ranges the last one grows over the gap
-      if (n > 0 && (last_end == off || n == CUT_MAX)) last_end = nr.skip;
+      // keep this subtree: [off, skip).  Adjacent subtrees merge; past NMAX ranges the last one grows over the gap
+      if (n > 0 && (last_end == off || n == NMAX)) last_end = nr.skip;
       else {
         if (n > 0) out[n] = cut_word(last_start, last_end);
         ++n; last_start = off; last_end = nr.skip;
@@ -1855,18 +1914,25 @@ __global__ __launch_bounds__(64) void k_cut(DeviceMesh mesh, GridParams g, const
     if (active & (emit | !keep)) resume = nr.skip;            // done with this subtree either way
     off = (__ballot(keep & !emit) != 0ull) ? off + NB : nr.skip;   // some brick still has to look inside
   }
+    if (LEVEL != 2) break;
+  }
 #ifdef M2S_STATS_BUILD
   if (mesh.stats != nullptr && lane == 0u) {
-    atomicAdd(&mesh.stats[104], 1ull);
-    atomicAdd(&mesh.stats[105], (unsigned long long)st_visits);
-    atomicAdd(&mesh.stats[106], (unsigned long long)st_above1);
-    atomicAdd(&mesh.stats[107], (unsigned long long)st_above4);
-    atomicMax(&mesh.stats[108], (unsigned long long)st_visits);
+    unsigned long long* sc = mesh.stats + (LEVEL == 1 ? 112 : 104);
+    atomicAdd(&sc[0], 1ull);
+    atomicAdd(&sc[1], (unsigned long long)st_visits);
+    atomicAdd(&sc[2], (unsigned long long)st_above1);
+    atomicAdd(&sc[3], (unsigned long long)st_above4);
+    atomicMax(&sc[4], (unsigned long long)st_visits);
   }
-  (void)st_pruned_above1;
 #endif
   if (!in_grid) return;
-  if (n == 0) { n = 1; last_start = 0; last_end = end; }    // cannot happen with finite input; never walk nothing
+  if (LEVEL == 1) {                                           // an empty sub-list is fine: the other subtrees hold what the block needs
+    if (n > 0) out[n] = cut_word(last_start, last_end);
+    out[0] = n;
+    return;
+  }
+  if (n == 0) { n = 1; last_start = 0; last_end = tree_end; }    // cannot happen with finite input; never walk nothing
   out[n] = cut_word(last_start, last_end);
   out[0] = n;
 }
@@ -2405,9 +2471,9 @@ bool grid_is_tiny(const GridParams& g, size_t n_tris, int algorithm) {
 size_t grid_distance_workspace_bytes(const GridParams& g, size_t n_tris) {
   const size_t bricks = (size_t)host_brick_count(g);
   if ((double)(g.xe - g.xb) * g.n[1] * g.n[2] <= 4194304.0)   // room for k_brute_split's per-voxel words
-    return bricks * 44 + bricks + 16384 + cut_blocks(g, 0) * CUT_WORDS * 4 + bricks * 64 * 8 + 4096 + split_workspace_bytes(g, n_tris, bricks);
+    return bricks * 44 + bricks + 16384 + cut_blocks(g, 0) * CUT_WORDS * 4 + cut_blocks(g, 2) * CUTC_S * CUTC_WORDS * 4 + 512 + bricks * 64 * 8 + 4096 + split_workspace_bytes(g, n_tris, bricks);
   const size_t trail_counters = (size_t)bricks_along(g.xe - g.xb, g.bl[0]) * (bricks_along(g.n[1], g.bl[1]) + 1) * 4;   // M2S_PEER_TRAIL progress
-  return bricks * 44 + bricks + 16384 + cut_blocks(g, 0) * CUT_WORDS * 4 + trail_counters + 1024 + split_workspace_bytes(g, n_tris, bricks);   // seeds + cut lists (one per brick) + split walk
+  return bricks * 44 + bricks + 16384 + cut_blocks(g, 0) * CUT_WORDS * 4 + cut_blocks(g, 2) * CUTC_S * CUTC_WORDS * 4 + 512 + trail_counters + 1024 + split_workspace_bytes(g, n_tris, bricks);   // seeds + cut lists (one per brick) + split walk
 }
 
 __global__ __launch_bounds__(256) void k_seed_remap(uint32_t* __restrict__ ids, size_t n, const uint32_t* __restrict__ slot_of, uint32_t n_tris) {
@@ -2552,9 +2618,26 @@ int prepare_grid_walk(Arena& ws, hipStream_t st, const DeviceMesh& mesh, const G
     const size_t bricks = (size_t)nbx * nby * nbz;
     uint32_t* lists = ws.take<uint32_t>(bricks * CUT_WORDS);
     if (!lists) { set_error("internal: cut-list workspace too small"); return M2S_ERR_HIP_INTERNAL; }
-    const size_t waves = (size_t)bricks_along(nbx, 2) * bricks_along(nby, 2) * bricks_along(nbz, 2);
-    hipLaunchKernelGGL(k_cut<true>, dim3((unsigned)waves), dim3(64), 0, st, mesh, g, seed1, sh1, s1ny, s1nz, nbx, nby, nbz, lists, emit_near, emit_far, budget, wave_cap,
-                       (const float4*)nullptr, (const uint32_t*)nullptr, (const GridParams*)nullptr);
+    const uint32_t cbx = bricks_along(nbx, 2), cby = bricks_along(nby, 2), cbz = bricks_along(nbz, 2);   // blocks of 4 x 4 x 4 bricks = fine waves
+    const size_t waves = (size_t)cbx * cby * cbz;
+    // two levels (k_cut LEVEL 1 + 2; M2S_CUT_COARSE: -1 automatic, 0 never, 1 always): the coarse launch is waves / 8 waves of its own — worth it
+    // from ~16 000 fine waves on (a 64-layer slab of 512^3, 4 096 waves: 0.20 -> ?; the tests force it on small grids).  A block must lie
+    // inside one chunk of an interleaved slab.
+    const int cc = tuning().cut_coarse;
+    const bool blocks_ok = sh1 == 0u && (g.chunk_log >= 31u || g.chunk_log >= g.bl[0] + 2u);
+    const bool two_level = blocks_ok && (cc > 0 || (cc < 0 && waves >= tuning().cut_coarse_min_waves));
+    if (two_level) {
+      uint32_t* coarse = ws.take<uint32_t>(waves * CUTC_S * CUTC_WORDS);
+      if (!coarse) { set_error("internal: cut-list workspace too small"); return M2S_ERR_HIP_INTERNAL; }
+      const size_t groups = (size_t)bricks_along(cbx, 2) * bricks_along(cby, 2) * bricks_along(cbz, 2);
+      const uint32_t coarse_cap = tuning().cut_coarse_cap ? tuning().cut_coarse_cap : wave_cap;
+      hipLaunchKernelGGL((k_cut<true, 1>), dim3((unsigned)(groups * CUTC_S)), dim3(64), 0, st, mesh, g, seed1, sh1, s1ny, s1nz, cbx, cby, cbz, coarse, 1.0f, emit_far, budget,
+                         coarse_cap, (const float4*)nullptr, (const uint32_t*)nullptr, (const GridParams*)nullptr, (const uint32_t*)nullptr);
+      hipLaunchKernelGGL((k_cut<true, 2>), dim3((unsigned)waves), dim3(64), 0, st, mesh, g, seed1, sh1, s1ny, s1nz, nbx, nby, nbz, lists, emit_near, emit_far, budget, wave_cap,
+                         (const float4*)nullptr, (const uint32_t*)nullptr, (const GridParams*)nullptr, (const uint32_t*)coarse);
+    } else
+    hipLaunchKernelGGL((k_cut<true, 0>), dim3((unsigned)waves), dim3(64), 0, st, mesh, g, seed1, sh1, s1ny, s1nz, nbx, nby, nbz, lists, emit_near, emit_far, budget, wave_cap,
+                       (const float4*)nullptr, (const uint32_t*)nullptr, (const GridParams*)nullptr, (const uint32_t*)nullptr);
     cut = {lists, 0, nby, nbz, 0, nullptr};
   }
   plan->seeds = seed1; plan->seed_shift = sh1; plan->seed_ny = s1ny; plan->seed_nz = s1nz;
@@ -2974,7 +3057,7 @@ int launch_query_walk(Arena& ws, hipStream_t st, const DeviceMesh& mesh, const f
     uint32_t depth = 1;
     while ((1ull << depth) < (unsigned long long)mesh.n_tris + 1ull) ++depth;
     const uint32_t wave_cap = tuning().cut_wave_cap ? tuning().cut_wave_cap : std::max(120u, 20u * depth);
-    hipLaunchKernelGGL(k_cut<false>, dim3((launched + 63) / 64), dim3(64), 0, st, mesh, g, seeds, 0u, 0u, 0u, launched, 1u, 1u, lists,
+    hipLaunchKernelGGL((k_cut<false, 0>), dim3((launched + 63) / 64), dim3(64), 0, st, mesh, g, seeds, 0u, 0u, 0u, launched, 1u, 1u, lists,
                        emit_near, emit_far, 100000u, wave_cap, (const float4*)plan.centres, table, d_lat);
     cut = {lists, 0, 0, 0, 0, plan.centres};
   }
@@ -3022,8 +3105,10 @@ void warm_distance(hipStream_t st) {
       (const void*)k_split_round<MODE_NORMAL_FOLD>,
       (const void*)k_split_finish<MODE_UNSIGNED, SIGN_GRID_PLANE>,
       (const void*)k_split_finish<MODE_NORMAL_FOLD, SIGN_NONE>,
-      (const void*)k_cut<true>,
-      (const void*)k_cut<false>,
+      (const void*)k_cut<true, 0>,
+      (const void*)k_cut<true, 1>,
+      (const void*)k_cut<true, 2>,
+      (const void*)k_cut<false, 0>,
       (const void*)k_lane<MODE_UNSIGNED, SIGN_GRID_PLANE>,
       (const void*)k_lane_q<MODE_UNSIGNED, SIGN_RAYS3>,
       (const void*)k_jfa_splat,

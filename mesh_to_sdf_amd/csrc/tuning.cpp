@@ -35,6 +35,9 @@ const Entry TABLE[] = {
     M2S_KNOB("M2S_QUERY_LAUNCH_TIGHT", K_INT, query_launch_tight),
     M2S_KNOB("M2S_CUT_NEAR", K_F32, cut_near),
     M2S_KNOB("M2S_CUT_FAR", K_F32, cut_far),
+    M2S_KNOB("M2S_CUT_COARSE", K_INT, cut_coarse),
+    M2S_KNOB("M2S_CUT_COARSE_MIN_WAVES", K_U32, cut_coarse_min_waves),
+    M2S_KNOB("M2S_CUT_COARSE_CAP", K_U32, cut_coarse_cap),
     M2S_KNOB("M2S_CUT_WAVE_CAP", K_U32, cut_wave_cap),
     M2S_KNOB("M2S_SPLIT", K_INT, split),
     M2S_KNOB("M2S_SPLIT_BUDGET", K_U32, split_budget),

@@ -121,7 +121,7 @@ def test_interleaved_calls_fuzz(case):
     if case % 4 == 2:
         hi[0] = lo[0] + (hi[0] - lo[0]) * 8   # anisotropic: long cells along x, so packet bricks thin along x
     g = Grid.from_bounding_box(lo, hi, counts)
-    with _lib.knobs(M2S_CUT_MIN_PACKETS=8):
+    with _lib.knobs(M2S_CUT_MIN_PACKETS=8, M2S_CUT_COARSE=case % 2):   # odd cases: two-level cut lists (blocks inside the chunks of an interleaved slab)
         dv, di = torch.as_tensor(v, device="cuda:0"), torch.as_tensor(idx.astype(np.int64), device="cuda:0")
         for sign in (SignMethod.Raycast, SignMethod.Normal):
             want = generate_grid_sdf(dv, Topology.TriangleList(di), g, sign)

@@ -51,7 +51,8 @@ def cut_lists_mode(request):
     forced = {}
     if mode == "cut lists on every grid":
         # M2S_BRUTE_MAX=0: no brute-force shortcut for tiny problems (the default mode takes it): the walks must see them
-        forced = {"M2S_CUT_MIN_PACKETS": 8, "M2S_QUERY_CUT_MIN": 1, "M2S_LANE_WALK": 0, "M2S_BRUTE_MAX": 0, "M2S_SPLIT": 0, "M2S_TREELETS": 0}   # (and a tree without the treelet pass)
+        forced = {"M2S_CUT_MIN_PACKETS": 8, "M2S_QUERY_CUT_MIN": 1, "M2S_LANE_WALK": 0, "M2S_BRUTE_MAX": 0, "M2S_SPLIT": 0, "M2S_TREELETS": 0,   # (and a tree without the treelet pass)
+                  "M2S_CUT_COARSE": 1}                                    # (and the lists made in two levels, as the large grids' are)
     elif mode == "lane walks":
         forced = {"M2S_LANE_WALK": 1, "M2S_BRUTE_MAX": 0, "M2S_LEAF_MAX": 3}
     elif mode == "split walks":
