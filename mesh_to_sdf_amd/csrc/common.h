@@ -272,6 +272,8 @@ struct GridWalkPlan {
   SplitCtl split;                  // packet walk only
   bool split_forced = false;       // M2S_SPLIT=2: the flags start raised (tests)
   int defer = 0;                   // packet walk: 1 exact evaluations queued and run densely, 2 + direct where most lanes are reached (distance.hip DeferQueue)
+  const uint2* group_top = nullptr;   // packet groups (k_packet_group): the tree's top subtrees (k_tree_top); nullptr: one wave per packet
+  uint32_t group_waves = 0;           // ... waves per packet (2, 4, 8 or 16)
   uint32_t* brute_acc = nullptr;   // tiny problems (grid_is_tiny): per-voxel minima of k_brute_split; no seeds, no lists, no tree
 };
 bool grid_is_tiny(const GridParams& g, size_t n_tris, int algorithm);

@@ -1075,6 +1075,99 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
   else if (store) out[out_index] = result;
 }
 
+// ---- packet groups: several waves per packet (round 6) ------------------------------------------------------------------------
+// A launch shallower than the chip (64^3 ... 128^3 over 100 k triangles: 4 096 ... 32 768 packets on 8 192 wave slots, triangles much finer
+// than the bricks) lasts as long as its slowest packet's chain of dependent loads — 0.58 - 0.64 ms whatever the grid (round 5) — while
+// most wave slots idle.  Here a packet is a workgroup of GROUP_WAVES = 2 or 4 waves: every wave evaluates the packet's seed, then walks its share
+// of the tree — the subtrees w, w + GROUP_WAVES, ... of the TOP_SUBTREES subtrees TOP_LOG levels below the root (k_tree_top; neighbours
+// in Morton order go to different waves, so the part of the mesh next to the brick is dealt out evenly) — with its own queues but ONE
+// set of per-voxel minima in LDS: the queued evaluations fold into them with atomic minima (as they always did) and every wave refreshes
+// its bounds from them after each batch, so a wave prunes with what the others have found.  A minimum is a minimum: the same bits as
+// one wave walking everything (parity suite in this form too).  Grid calls without cut lists and without the split walk, leaf work fully
+// queued (DEFER = 3).  Walk, one wave / group (profiles/r06_groups.txt): blob-100k 32^3 1.22 -> 0.46 ms, 48^3 0.87 -> 0.42, 64^3 0.66 -> 0.50, 80^3 0.56 ->
+// 0.49, 96^3 0.62 -> 0.55; blob-11k 32^3 0.30 -> 0.12, 64^3 0.23 -> 0.14.  More waves do not keep helping — every wave starts from the seed's bound
+// alone and learns what the others found only batch by batch, so the group's total work grows: 16 waves at 32^3 0.56 ms, 8 at 64^3 0.59 — and
+// from ~110^3 on (four rounds of the chip's wave slots) one wave per packet is faster again.
+constexpr uint32_t GROUP_MAX_WAVES = 4, TOP_LOG = 8, TOP_SUBTREES = 1u << TOP_LOG;   // 2 or 4 waves per packet, chosen by the launch (blockDim.x / 64)
+__global__ __launch_bounds__(TOP_SUBTREES) void k_tree_top(DeviceMesh mesh, uint2* __restrict__ top) {
+  constexpr uint32_t NB = (uint32_t)sizeof(NodeExt);
+  const uint32_t sub = threadIdx.x;
+  uint32_t off = 0, end = mesh.n_nodes * NB;
+  for (uint32_t lv = 0; lv < TOP_LOG && off < end; ++lv) {
+    const NodeExt* nr = reinterpret_cast<const NodeExt*>(reinterpret_cast<const char*>(mesh.ext) + off);
+    const uint32_t rest = sub & ((1u << (TOP_LOG - lv)) - 1u);
+    if (nr->tri >= 0) { if (rest != 0u) end = off; break; }      // a leaf on the way belongs to the subtree whose remaining bits are zero
+    const uint32_t skip = nr->skip, left = off + NB;
+    const uint32_t right = reinterpret_cast<const NodeExt*>(reinterpret_cast<const char*>(mesh.ext) + left)->skip;
+    if ((sub >> (TOP_LOG - 1u - lv)) & 1u) { off = right; end = skip; } else { off = left; end = right; }
+  }
+  top[sub] = make_uint2(off, end);
+}
+template <int MODE, int SIGN>
+__global__ __launch_bounds__(64 * GROUP_MAX_WAVES) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_packet_group(
+    DeviceMesh mesh, GridParams g, const uint32_t* __restrict__ plane, float* __restrict__ out, int* __restrict__ err, uint32_t n_packets,
+    const uint32_t* __restrict__ seed_in, uint32_t seed_shift, uint32_t seed_ny, uint32_t seed_nz, uint32_t bx_off, const uint2* __restrict__ top, PeerOut peers) {
+  static_assert(MODE == MODE_UNSIGNED || MODE == MODE_NORMAL_FOLD, "grid modes");
+  const int lane = threadIdx.x & 63;
+  const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const uint32_t packet = (uint32_t)__builtin_amdgcn_readfirstlane((int)xcd_remap(blockIdx.x));
+  if (packet >= n_packets) return;
+  const GridBrick vox = grid_lane_voxel(g, packet, lane);
+  if (!vox.brick_in_grid) return;        // padding of the super-brick order (the same for every wave of the group)
+  const f3 p = grid_point(g, vox);
+  const size_t out_index = ((size_t)vox.x * g.n[1] + vox.y) * g.n[2] + vox.z - (size_t)g.out_off;
+
+  extern __shared__ unsigned long long group_lds[];   // blockDim.x / 64 x 256 ring words, then DeferLayout<MODE>::SLOT_WORDS slot words
+  const uint32_t GROUP_WAVES = blockDim.x >> 6;
+  uint32_t* const lds = reinterpret_cast<uint32_t*>(group_lds);
+  DeferQueue dq = {lds + wave * 256u, lds + GROUP_WAVES * 256u, 0u, 0u, lds + wave * 256u + 128u, 0u, 0u};   // own rings, shared minima
+  if (wave == 0u) {
+    dq.slot[lane] = 0x7f800000u;
+    if (MODE == MODE_NORMAL_FOLD) { dq.slot[64 + lane] = 0x7f800000u; dq.slot[128 + lane] = 0u; }
+  }
+  Best<MODE> best;
+  if (mesh.n_nodes) {
+    const float scale = fmaxf(mesh_scale(mesh), fmaxf(fabsf(p.x), fmaxf(fabsf(p.y), fabsf(p.z))));
+    const float slack = 4.0e-6f * scale + (MODE == MODE_NORMAL_FOLD ? 2.5e-6f : 0.0f);
+    uint32_t slot = 0;
+    if (seed_in != nullptr) {
+      const uint32_t sidx = (((vox.bx + bx_off) >> seed_shift) * seed_ny + (vox.by >> seed_shift)) * seed_nz + (vox.bz >> seed_shift);
+      slot = __builtin_amdgcn_readfirstlane(min(seed_in[sidx], mesh.n_tris - 1));
+    }
+    eval_triangle<MODE>(best, p, record_at(mesh.tris, slot));
+    float thr = prune_bound(best.d2, slack);
+    __syncthreads();                     // the shared minima are initialised
+    WalkStats st;
+    SplitState sp;
+    for (uint32_t k = wave; k < TOP_SUBTREES; k += GROUP_WAVES) {
+      const uint2 r = top[k];            // wave-uniform
+      uint32_t off = (uint32_t)__builtin_amdgcn_readfirstlane((int)r.x);
+      const uint32_t end = (uint32_t)__builtin_amdgcn_readfirstlane((int)r.y);
+      if (off >= end) continue;
+      walk_span<MODE, false, false, false, false, 3>(mesh, p, slack, best, thr, off, end, st, sp, nullptr, &dq);
+    }
+    defer_drain<MODE>(mesh, p, slack, dq, best);
+    // this wave's minima (the seed's among them) join the group's
+    atomicMin(&dq.slot[lane], __float_as_uint(best.d2));
+    if (MODE == MODE_NORMAL_FOLD) {
+      atomicMin(&dq.slot[64 + lane], __float_as_uint(best.d2pos));
+      if (best.nan) dq.slot[128 + lane] = 1u;
+    }
+    __syncthreads();
+    if (wave != 0u) return;
+    best.d2 = __uint_as_float(dq.slot[lane]);
+    if (MODE == MODE_NORMAL_FOLD) { best.d2pos = __uint_as_float(dq.slot[64 + lane]); best.nan = dq.slot[128 + lane] != 0u; }
+  } else if (wave != 0u) return;
+
+  bool negate = false;
+  if (MODE == MODE_UNSIGNED && SIGN == SIGN_GRID_PLANE) {
+    const size_t w = ((size_t)vox.x * g.n[1] + vox.y) * g.nzw + (vox.z >> 5);
+    negate = (plane[w] >> (vox.z & 31u)) & 1u;                       // grid.rs:630-636
+  }
+  if (MODE == MODE_NORMAL_FOLD && best.nan) atomicOr(err, ERRF_NAN);
+  store_grid_result(out, out_index, finish<MODE>(best, negate), vox.in_range, g, vox, peers, lane);
+}
+
 // One follow-up round of the split walk (grid path): a fixed set of single-wave workgroups strides the round's list.  An item is either
 // a CONTINUATION — a suspended packet: the rest of its range `range` from record `first` on, and the ranges behind it (round 1) — or a
 // subtree [first, end) that a suspended walk did not enter.  The wave rebuilds the packet's 64 points, starts from the slot's current
@@ -2471,9 +2564,9 @@ bool grid_is_tiny(const GridParams& g, size_t n_tris, int algorithm) {
 size_t grid_distance_workspace_bytes(const GridParams& g, size_t n_tris) {
   const size_t bricks = (size_t)host_brick_count(g);
   if ((double)(g.xe - g.xb) * g.n[1] * g.n[2] <= 4194304.0)   // room for k_brute_split's per-voxel words
-    return bricks * 44 + bricks + 16384 + cut_blocks(g, 0) * CUT_WORDS * 4 + cut_blocks(g, 2) * CUTC_S * CUTC_WORDS * 4 + 512 + bricks * 64 * 8 + 4096 + split_workspace_bytes(g, n_tris, bricks);
+    return bricks * 44 + bricks + 16384 + cut_blocks(g, 0) * CUT_WORDS * 4 + cut_blocks(g, 2) * CUTC_S * CUTC_WORDS * 4 + 512 + TOP_SUBTREES * 8 + 256 + bricks * 64 * 8 + 4096 + split_workspace_bytes(g, n_tris, bricks);
   const size_t trail_counters = (size_t)bricks_along(g.xe - g.xb, g.bl[0]) * (bricks_along(g.n[1], g.bl[1]) + 1) * 4;   // M2S_PEER_TRAIL progress
-  return bricks * 44 + bricks + 16384 + cut_blocks(g, 0) * CUT_WORDS * 4 + cut_blocks(g, 2) * CUTC_S * CUTC_WORDS * 4 + 512 + trail_counters + 1024 + split_workspace_bytes(g, n_tris, bricks);   // seeds + cut lists (one per brick) + split walk
+  return bricks * 44 + bricks + 16384 + cut_blocks(g, 0) * CUT_WORDS * 4 + cut_blocks(g, 2) * CUTC_S * CUTC_WORDS * 4 + 512 + TOP_SUBTREES * 8 + 256 + trail_counters + 1024 + split_workspace_bytes(g, n_tris, bricks);   // seeds + cut lists (one per brick) + split walk
 }
 
 __global__ __launch_bounds__(256) void k_seed_remap(uint32_t* __restrict__ ids, size_t n, const uint32_t* __restrict__ slot_of, uint32_t n_tris) {
@@ -2640,6 +2733,26 @@ int prepare_grid_walk(Arena& ws, hipStream_t st, const DeviceMesh& mesh, const G
                        (const float4*)nullptr, (const uint32_t*)nullptr, (const GridParams*)nullptr, (const uint32_t*)nullptr);
     cut = {lists, 0, nby, nbz, 0, nullptr};
   }
+  // packet groups (k_packet_group; M2S_GROUP: -1 automatic, 0 never, 1 always): launches of at most M2S_GROUP_MAX_PACKETS packets without
+  // cut lists where the bricks meet several triangles each (the chains are long there: 64^3 ... 128^3 over 100 k triangles)
+  {
+    const int gk = tn.group;
+    const bool can = !brute && !lane_walk && cut.lists == nullptr && mesh.n_nodes != 0 && mesh.stats == nullptr && tn.split <= 0 && tn.defer < 0 && g.chunk_log >= 31u;
+    const bool want = gk > 0 || (gk < 0 && (double)mesh.n_tris >= tn.group_min_ratio * real_bricks);
+    if (can && want) {
+      // as many waves per packet (a power of two, four at most) as keep the launch within M2S_GROUP_TARGET_WAVES waves
+      uint32_t w = 1;
+      while (w < GROUP_MAX_WAVES && (double)(2u * w) * real_bricks <= (double)tn.group_target_waves) w *= 2;
+      if (gk > 0 && w < 2u) w = GROUP_MAX_WAVES;                      // forced (tests)
+      if (w >= 2u) {
+        uint2* top = ws.take<uint2>(TOP_SUBTREES);
+        if (!top) { set_error("internal: workspace too small"); return M2S_ERR_HIP_INTERNAL; }
+        hipLaunchKernelGGL(k_tree_top, dim3(1), dim3(TOP_SUBTREES), 0, st, mesh, top);
+        plan->group_top = top;
+        plan->group_waves = w;
+      }
+    }
+  }
   plan->seeds = seed1; plan->seed_shift = sh1; plan->seed_ny = s1ny; plan->seed_nz = s1nz;
   plan->cut_lists = cut.lists; plan->cut_log = cut.log; plan->cut_ny = cut.ny; plan->cut_nz = cut.nz;
   plan->lane_walk = lane_walk;
@@ -2649,7 +2762,7 @@ int prepare_grid_walk(Arena& ws, hipStream_t st, const DeviceMesh& mesh, const G
   // blob-100k in 96^3 ... 192^3 1.79 -> 1.07, 1.57 -> 1.28, 1.81 -> 1.63 ms, in 256^3 2.25 -> 2.34 (a wash), the 64-layer slabs of
   // 512^3 1.21 -> 1.26 (a loss: no tail to speak of, three more launches); blob-1M in 256^3 12.8 -> 9.5 ms, its slowest 8-GPU slab of
   // 512^3 5.05 -> 4.05, its fastest 3.14 -> 3.16.  Automatic: split_auto above (>= 300 000 triangles, >= 5 per packet brick of the WHOLE grid, >= 10 240 bricks).
-  if (!lane_walk && split_possible && (tn.split > 0 || split_auto)) {
+  if (!lane_walk && split_possible && plan->group_top == nullptr && (tn.split > 0 || split_auto)) {
     SplitCtl sc;
     sc.cap_slots = split_cap_slots(packets);
     sc.cap_items = std::max(sc.cap_slots, std::min(sc.cap_slots * SPLIT_ITEMS_PER_SLOT, 1u << 20));
@@ -2749,6 +2862,23 @@ int launch_grid_walk(hipStream_t st, const DeviceMesh& mesh, const GridParams& g
       hipLaunchKernelGGL((k_lane<MODE_UNSIGNED, SIGN_NONE>), dim3(blocks), dim3(256), 0, st, mesh, g, nullptr, d_out, d_err, packets, seed1, sh1, s1ny, s1nz, bx_off, pz);
     else
       hipLaunchKernelGGL((k_lane<MODE_NORMAL_FOLD, SIGN_NONE>), dim3(blocks), dim3(256), 0, st, mesh, g, nullptr, d_out, d_err, packets, seed1, sh1, s1ny, s1nz, bx_off, pz);
+    M2S_HIP_CHECK(hipGetLastError());
+    return 0;
+  }
+  if (plan.group_top != nullptr && !brute) {
+    const uint32_t per = 8u << XCD_RUN_LOG;
+    const uint32_t grid_blocks = ((packets + per - 1) / per) * per;        // as launch_packet: whole runs per XCD (xcd_remap)
+    const uint32_t gw = plan.group_waves;
+    const size_t lds_u = ((size_t)gw * 256u + DeferLayout<MODE_UNSIGNED>::SLOT_WORDS) * 4u, lds_n = ((size_t)gw * 256u + DeferLayout<MODE_NORMAL_FOLD>::SLOT_WORDS) * 4u;
+    if (mode == MODE_UNSIGNED && d_inside_plane)
+      hipLaunchKernelGGL((k_packet_group<MODE_UNSIGNED, SIGN_GRID_PLANE>), dim3(grid_blocks), dim3(64 * gw), lds_u, st, mesh, g, d_inside_plane, d_out, d_err, packets,
+                         seed1, sh1, s1ny, s1nz, bx_off, plan.group_top, pz);
+    else if (mode == MODE_UNSIGNED)
+      hipLaunchKernelGGL((k_packet_group<MODE_UNSIGNED, SIGN_NONE>), dim3(grid_blocks), dim3(64 * gw), lds_u, st, mesh, g, (const uint32_t*)nullptr, d_out, d_err, packets,
+                         seed1, sh1, s1ny, s1nz, bx_off, plan.group_top, pz);
+    else
+      hipLaunchKernelGGL((k_packet_group<MODE_NORMAL_FOLD, SIGN_NONE>), dim3(grid_blocks), dim3(64 * gw), lds_n, st, mesh, g, (const uint32_t*)nullptr, d_out, d_err, packets,
+                         seed1, sh1, s1ny, s1nz, bx_off, plan.group_top, pz);
     M2S_HIP_CHECK(hipGetLastError());
     return 0;
   }

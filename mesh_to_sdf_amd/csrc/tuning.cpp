@@ -33,6 +33,9 @@ const Entry TABLE[] = {
     M2S_KNOB("M2S_CUT_MIN_PACKETS", K_U32, cut_min_packets),
     M2S_KNOB("M2S_QUERY_CUT_MIN", K_U32, query_cut_min),
     M2S_KNOB("M2S_QUERY_LAUNCH_TIGHT", K_INT, query_launch_tight),
+    M2S_KNOB("M2S_GROUP", K_INT, group),
+    M2S_KNOB("M2S_GROUP_TARGET_WAVES", K_U32, group_target_waves),
+    M2S_KNOB("M2S_GROUP_MIN_RATIO", K_F64, group_min_ratio),
     M2S_KNOB("M2S_CUT_NEAR", K_F32, cut_near),
     M2S_KNOB("M2S_CUT_FAR", K_F32, cut_far),
     M2S_KNOB("M2S_CUT_COARSE", K_INT, cut_coarse),

@@ -26,6 +26,9 @@ struct Tuning {
   uint32_t cut_min_packets = 100000;// M2S_CUT_MIN_PACKETS   grid: cut lists from this many packets on
   uint32_t query_cut_min = 20000;   // M2S_QUERY_CUT_MIN     queries: cut lists from this many packets on
   int query_launch_tight = 0;       // M2S_QUERY_LAUNCH_TIGHT  test hook: forces the consecutive-packet fallback of the query packets
+  int group = -1;                   // M2S_GROUP        packets as workgroups of 2 or 4 waves (launches shallower than the chip): -1 automatic, 0 never, 1 always (where the walk form allows it; four waves)
+  uint32_t group_target_waves = 32768; // M2S_GROUP_TARGET_WAVES  ... as many waves per packet (2 or 4) as keep the launch within this many waves
+  double group_min_ratio = 1.0;     // M2S_GROUP_MIN_RATIO     ... and from this many triangles per packet brick on
   // ---- cut lists
   float cut_near = 2.0f;            // M2S_CUT_NEAR     emission radius of a list entry, in brick radii (next to the surface)
   float cut_far = 1.0f / 32.0f;     // M2S_CUT_FAR      ... and as a fraction of the distance (far from it)

@@ -21,7 +21,8 @@ F = np.float32
 TOL = 1e-5  # north_star tolerance (absolute, f32 distances); signs must match exactly
 
 
-@pytest.fixture(autouse=True, params=["default", "cut lists on every grid", "lane walks", "split walks", "direct evaluations", "queued evaluations", "queued + direct evaluations"])
+@pytest.fixture(autouse=True, params=["default", "cut lists on every grid", "lane walks", "split walks", "direct evaluations", "queued evaluations", "queued + direct evaluations",
+                                      "packet groups"])
 def cut_lists_mode(request):
     """The cut lists (k_cut) are used from 100 000 packets per launch upwards and the packet walk of generic queries from a
     few million queries; the second run of every test lowers the thresholds and forces the packet walks, so that the nasty
@@ -45,6 +46,8 @@ def cut_lists_mode(request):
         pytest.skip("the lane walk is not meant for this size")
     if mode in ("direct evaluations", "queued evaluations", "queued + direct evaluations") and big and "512" not in request.node.name:
         pytest.skip("the evaluation forms differ per packet, not per size: the small inputs and one large grid cover them")
+    if mode == "packet groups" and big and "256" not in request.node.name:
+        pytest.skip("four waves per packet are for launches shallower than the chip; 256^3 stands for the large ones")
     if mode == "split walks" and big:
         pytest.skip("a budget of 24 work units is for small inputs (test_split_walk_* covers the large ones with realistic budgets)")
     # the library reads its knobs from the environment once; afterwards they are switched through m2s_tuning_set (_lib.set_knob)
@@ -64,6 +67,9 @@ def cut_lists_mode(request):
         forced = {"M2S_DEFER": 1, "M2S_LANE_WALK": 0, "M2S_BRUTE_MAX": 0, "M2S_LEAF_MAX": 4}
     elif mode == "queued + direct evaluations":
         forced = {"M2S_DEFER": 2, "M2S_LANE_WALK": 0, "M2S_BRUTE_MAX": 0}
+    elif mode == "packet groups":
+        # every packet a workgroup of four waves that share their minima in LDS (k_packet_group; automatic for shallow launches over fine meshes)
+        forced = {"M2S_GROUP": 1, "M2S_LANE_WALK": 0, "M2S_BRUTE_MAX": 0, "M2S_CUT_MIN_PACKETS": 4000000000}
     with _lib.knobs(**forced):
         yield
 
