@@ -738,6 +738,11 @@ __device__ __forceinline__ void defer_drain(const DeviceMesh& mesh, f3 p, float 
   while (dq.n != 0u) defer_flush<MODE>(mesh, p, dq, best);
 }
 
+// (Round 6, measured and not kept — two cursors per wave, so that two record loads are in flight and two node tests issue back to back.  First
+// form: idle cursors take the next range of the list or the rest of the other cursor's range; ~100 scalar instructions of bookkeeping per
+// iteration; headline walk 7.1 -> 12.6 ms.  Second form: two ranges in lockstep while both last, the same instruction count per node plus ~6
+// scalar instructions; 6.47 -> 6.86 ms, 512^3 x sheet-100k Normal 13.3 -> 14.1.  The record loads hit the scalar cache: what a wave waits for
+// is its own instruction stream, and at eight waves per SIMD a wave's time follows its instruction count.  profiles/r06_two_cursors_*.)
 // The pre-order records [off, end) of the oriented-bound tree for the 64 points of a wave: position wave-uniform (SGPR), node
 // records and pre-test planes through scalar loads, a subtree left when no lane's bound reaches it.  BUDGET: the walk may stop
 // early (sp.suspended, off = the first record not yet looked at).  EMIT: a suspended walk — surviving subtrees of em.min_bytes ..

@@ -17,6 +17,11 @@ MODES = {"default": {}, "packet + cut lists": {"M2S_CUT_MIN_PACKETS": 8, "M2S_QU
          "packet, queued evaluations, leaves of 2": {"M2S_LANE_WALK": 0, "M2S_BRUTE_MAX": 0, "M2S_DEFER": 1, "M2S_LEAF_MAX": 2},
          "packet, leaves of 16": {"M2S_LANE_WALK": 0, "M2S_BRUTE_MAX": 0, "M2S_LEAF_MAX": 16},
          "packet + cut lists, queued pre-tests and evaluations": {"M2S_CUT_MIN_PACKETS": 8, "M2S_QUERY_CUT_MIN": 1, "M2S_LANE_WALK": 0, "M2S_BRUTE_MAX": 0, "M2S_SPLIT": 0, "M2S_DEFER": 3},
+         # round 6: cut lists made in two levels (k_cut LEVEL 1 + 2), packets as groups of four waves that share their minima in LDS
+         "packet + two-level cut lists": {"M2S_CUT_MIN_PACKETS": 8, "M2S_CUT_COARSE": 1, "M2S_LANE_WALK": 0, "M2S_BRUTE_MAX": 0, "M2S_SPLIT": 0},
+         "packet + two-level cut lists + split": {"M2S_CUT_MIN_PACKETS": 8, "M2S_CUT_COARSE": 1, "M2S_LANE_WALK": 0, "M2S_BRUTE_MAX": 0, "M2S_SPLIT": 2, "M2S_SPLIT_BUDGET": 60},
+         "packet groups": {"M2S_GROUP": 1, "M2S_LANE_WALK": 0, "M2S_BRUTE_MAX": 0, "M2S_CUT_MIN_PACKETS": 4000000000},
+         "packet groups, leaves of 2": {"M2S_GROUP": 1, "M2S_LANE_WALK": 0, "M2S_BRUTE_MAX": 0, "M2S_CUT_MIN_PACKETS": 4000000000, "M2S_LEAF_MAX": 2},
          "packet + cut lists + split, queued + direct evaluations": {"M2S_CUT_MIN_PACKETS": 8, "M2S_QUERY_CUT_MIN": 1, "M2S_LANE_WALK": 0, "M2S_BRUTE_MAX": 0, "M2S_SPLIT": 2,
                                                                      "M2S_SPLIT_BUDGET": 60, "M2S_DEFER": 2}}
 
