@@ -96,17 +96,14 @@ __host__ __device__ __forceinline__ uint32_t bricks_along(uint32_t cells, uint32
   return (cells + (1u << log2_extent) - 1u) >> log2_extent;
 }
 __host__ __device__ __forceinline__ uint32_t super_brick_xlog(uint32_t nbx, uint32_t xl_cap = 0) {
-  // the largest xl in 1 .. min(3, xl_cap - 1) whose padding is at most nbx / 8, else 0.  Straight-line: every packet computes it in its
-  // prologue, and the compiler turned the loop over xl (trip count from xl_cap) into an eight-wide "vectorised" scalar monster of ~100
-  // SALU + 26 VALU instructions per packet (round 6, found in the -S listing).
-  const uint32_t top = xl_cap ? xl_cap - 1u : 3u;
-  uint32_t r = 0;
-#pragma unroll
-  for (uint32_t xl = 1; xl <= 3u; ++xl) {
+  // (the compiler also emits an eight-wide "vectorised" form of this loop for trip counts >= 16, which never runs: xl starts at 3 or below.
+  // A straight-line rewrite — round 6 — executed the same handful of scalar instructions and moved the packet walk's code by 1 400 bytes:
+  // 6.44 -> 6.48 ms on the headline, same box, three runs each.  Left as it was.)
+  for (uint32_t xl = xl_cap ? xl_cap - 1u : 3u; xl > 0; --xl) {
     const uint32_t padded = ((nbx + (1u << xl) - 1u) >> xl) << xl;
-    if (xl <= top && (padded - nbx) * 8u <= nbx) r = xl;
+    if ((padded - nbx) * 8u <= nbx) return xl;
   }
-  return r;
+  return 0;
 }
 __device__ __forceinline__ uint32_t div_magic(uint32_t n, uint32_t d, uint32_t magic) {
   return magic ? __umulhi(n, magic) : n / d;   // common.h set_super_brick_magic
@@ -2718,9 +2715,11 @@ int prepare_grid_walk(Arena& ws, hipStream_t st, const DeviceMesh& mesh, const G
     if (!lists) { set_error("internal: cut-list workspace too small"); return M2S_ERR_HIP_INTERNAL; }
     const uint32_t cbx = bricks_along(nbx, 2), cby = bricks_along(nby, 2), cbz = bricks_along(nbz, 2);   // blocks of 4 x 4 x 4 bricks = fine waves
     const size_t waves = (size_t)cbx * cby * cbz;
-    // two levels (k_cut LEVEL 1 + 2; M2S_CUT_COARSE: -1 automatic, 0 never, 1 always): the coarse launch is waves / 8 waves of its own — worth it
-    // from ~16 000 fine waves on (a 64-layer slab of 512^3, 4 096 waves: 0.20 -> ?; the tests force it on small grids).  A block must lie
-    // inside one chunk of an interleaved slab.
+    // two levels (k_cut LEVEL 1 + 2; M2S_CUT_COARSE: -1 automatic, 0 never, 1 always).  The coarse launch is waves / 8 waves of its own whose longest
+    // chain (the subtree next to its region, up to the visit cap) is ~0.14 ms whatever the grid: 1024^3 (262 144 fine waves) seed + cut 5.98 -> 4.9 ms and
+    // the call 83.2 -> 81.9 ms (sheet-100k, Normal) / 40.8 -> 39.9 (blob-100k); 512^3 (32 768) 0.72 -> 0.67 + 0.14 ms with a walk 0.08 ms shorter — a wash;
+    // a 64-layer slab of 512^3 (4 096) 0.20 -> 0.34 ms.  Automatic from M2S_CUT_COARSE_MIN_WAVES = 40 000 fine waves on (profiles/r06_cut_coarse.txt; the
+    // tests force it on small grids).  A block must lie inside one chunk of an interleaved slab.
     const int cc = tuning().cut_coarse;
     const bool blocks_ok = sh1 == 0u && (g.chunk_log >= 31u || g.chunk_log >= g.bl[0] + 2u);
     const bool two_level = blocks_ok && (cc > 0 || (cc < 0 && waves >= tuning().cut_coarse_min_waves));

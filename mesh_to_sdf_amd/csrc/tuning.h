@@ -33,7 +33,7 @@ struct Tuning {
   float cut_near = 2.0f;            // M2S_CUT_NEAR     emission radius of a list entry, in brick radii (next to the surface)
   float cut_far = 1.0f / 32.0f;     // M2S_CUT_FAR      ... and as a fraction of the distance (far from it)
   int cut_coarse = -1;              // M2S_CUT_COARSE   grid cut lists in two levels (a coarse pass per 4 x 4 x 4 bricks first): -1 automatic (from M2S_CUT_COARSE_MIN_WAVES fine waves on), 0 never, 1 always
-  uint32_t cut_coarse_min_waves = 16384;   // M2S_CUT_COARSE_MIN_WAVES   fine k_cut waves (blocks of 4 x 4 x 4 bricks) from which the automatic choice takes two levels
+  uint32_t cut_coarse_min_waves = 40000;   // M2S_CUT_COARSE_MIN_WAVES   fine k_cut waves (blocks of 4 x 4 x 4 bricks) from which the automatic choice takes two levels (512^3: 32 768 waves, a wash; 1024^3: 262 144, - 1.5 %)
   uint32_t cut_coarse_cap = 0;      // M2S_CUT_COARSE_CAP   node visits after which a coarse-level wave emits what it meets; 0: as M2S_CUT_WAVE_CAP
   uint32_t cut_wave_cap = 0;        // M2S_CUT_WAVE_CAP node visits after which a k_cut wave emits what it meets; 0: max(120, 20 x tree depth)
   // ---- heavy packets (distance.hip "split walk")

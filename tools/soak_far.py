@@ -12,7 +12,10 @@ FORMS = {"all pairs": {"M2S_BRUTE_MAX": 1e30}, "default": {"M2S_BRUTE_MAX": 0},
          "packets, queued, leaves of 2": {"M2S_BRUTE_MAX": 0, "M2S_LANE_WALK": 0, "M2S_DEFER": 3, "M2S_LEAF_MAX": 2},
          "packets, wave-wide, cut lists": {"M2S_BRUTE_MAX": 0, "M2S_LANE_WALK": 0, "M2S_DEFER": 0, "M2S_CUT_MIN_PACKETS": 8, "M2S_QUERY_CUT_MIN": 1},
          "packets, mixed, leaves of 16": {"M2S_BRUTE_MAX": 0, "M2S_LANE_WALK": 0, "M2S_DEFER": 2, "M2S_LEAF_MAX": 16},
-         "lane walk": {"M2S_BRUTE_MAX": 0, "M2S_LANE_WALK": 1, "M2S_LEAF_MAX": 2}}
+         "lane walk": {"M2S_BRUTE_MAX": 0, "M2S_LANE_WALK": 1, "M2S_LEAF_MAX": 2},
+         # round 6: cut lists in two levels; packets as groups of four waves
+         "packets, two-level cut lists": {"M2S_BRUTE_MAX": 0, "M2S_LANE_WALK": 0, "M2S_CUT_MIN_PACKETS": 8, "M2S_CUT_COARSE": 1, "M2S_SPLIT": 0},
+         "packet groups": {"M2S_BRUTE_MAX": 0, "M2S_LANE_WALK": 0, "M2S_GROUP": 1, "M2S_CUT_MIN_PACKETS": 4000000000}}
 
 
 def main():
