@@ -1707,6 +1707,77 @@ __global__ __launch_bounds__(256) void k_jfa_pass32(GridParams g, const float4* 
   out[i] = bc;
   if (ids_out) ids_out[i] = best;
 }
+// Lattices of at most JFA_SMALL_MAX points (a 64^3 grid: 16^3 brick centres): the whole flood — clear, splat, load, every pass — in ONE
+// workgroup with the lattice in LDS.  Seven to nine launches of 2 - 4 us kernels cost the host ~45 us to enqueue, during which the caller's
+// stream sat idle behind the build's sort (suzanne, 968 triangles, 64^3: hierarchy started 55 us after the sort had ended; timeline in
+// profiles/r06_small_calls.txt).  Same candidates, same tie rule as k_jfa_splat / k_jfa_pass32: the same seeds.
+constexpr uint32_t JFA_SMALL_MAX = 4096, JFA_SMALL_THREADS = 1024;
+__global__ __launch_bounds__(JFA_SMALL_THREADS) void k_jfa_small(DeviceMesh mesh, GridParams g, uint32_t* __restrict__ ids_out) {
+  __shared__ float4 lat_a[JFA_SMALL_MAX], lat_b[JFA_SMALL_MAX];
+  unsigned long long* const keys = reinterpret_cast<unsigned long long*>(lat_b);   // the splat's keys live in the second buffer until the load
+  const uint32_t n0 = g.n[0], n1 = g.n[1], n2 = g.n[2], n = n0 * n1 * n2, tid = threadIdx.x;
+  for (uint32_t i = tid; i < n; i += JFA_SMALL_THREADS) keys[i] = ~0ull;
+  __syncthreads();
+  for (uint32_t t = tid; t < mesh.n_tris; t += JFA_SMALL_THREADS) {          // k_jfa_splat
+    const float4 c = mesh.cen[t];
+    const float cc[3] = {c.x, c.y, c.z};
+    uint32_t cell[3];
+    bool ok = true;
+    for (int k = 0; k < 3; ++k) {
+      float f = (cc[k] - g.first[k]) / g.size[k] + 0.5f;
+      if (!(f == f)) { ok = false; break; }                                  // NaN centroid: not a useful seed
+      if (k == 0) { cell[0] = lattice_x_from_real(g, f); continue; }
+      f = fminf(fmaxf(f, 0.0f), (float)(g.n[k] - 1));
+      cell[k] = min((uint32_t)f, g.n[k] - 1);
+    }
+    if (!ok) continue;
+    const f3 p = lattice_point(g, cell[0], cell[1], cell[2]);
+    const float ex = p.x - c.x, ey = p.y - c.y, ez = p.z - c.z;
+    const float d2 = __builtin_fmaf(ex, ex, __builtin_fmaf(ey, ey, ez * ez));
+    if (!(d2 == d2)) continue;
+    atomicMin(&keys[(cell[0] * n1 + cell[1]) * n2 + cell[2]], ((unsigned long long)__float_as_uint(d2) << 32) | t);
+  }
+  __syncthreads();
+  for (uint32_t i = tid; i < n; i += JFA_SMALL_THREADS) {                    // k_jfa_load
+    const uint32_t id = (uint32_t)(keys[i] & 0xffffffffull);
+    float4 c = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (id != 0xffffffffu) c = mesh.cen[id];
+    c.w = __uint_as_float(id);
+    lat_a[i] = c;
+  }
+  __syncthreads();
+  const uint32_t maxdim = max(n0, max(n1, n2));
+  uint32_t step = 1;
+  while (step * 2u < maxdim) step *= 2u;
+  float4* in = lat_a;
+  float4* out = lat_b;
+  for (bool last = false;; ) {                                                // steps ... 2, 1, then one more unit pass (launch_grid_seeds)
+    for (uint32_t i = tid; i < n; i += JFA_SMALL_THREADS) {                  // k_jfa_pass32
+      const uint32_t z = i % n2, xy = i / n2, y = xy % n1, x = xy / n1;
+      const f3 p = lattice_point(g, x, y, z);
+      const bool okx[3] = {x >= step, true, x + step < n0}, oky[3] = {y >= step, true, y + step < n1}, okz[3] = {z >= step, true, z + step < n2};
+      const int sx = (int)(step * n1 * n2), sy = (int)(step * n2), sz = (int)step;
+      unsigned long long key = 0x7f800000ffffffffull;
+      float4 bc = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0xffffffffu));
+      for (int a = 0; a < 3; ++a)
+        for (int k = 0; k < 9; ++k) {
+          if (!(okx[a] && oky[k / 3] && okz[k % 3])) continue;
+          const float4 c = in[(uint32_t)((int)i + (a - 1) * sx + (k / 3 - 1) * sy + (k % 3 - 1) * sz)];
+          const uint32_t cand = __float_as_uint(c.w);
+          const float ex = p.x - c.x, ey = p.y - c.y, ez = p.z - c.z;
+          const float d = __builtin_fmaf(ex, ex, __builtin_fmaf(ey, ey, ez * ez));
+          const unsigned long long kk = ((unsigned long long)__float_as_uint(d) << 32) | cand;
+          if (cand != 0xffffffffu && kk < key) { key = kk; bc = c; }
+        }
+      out[i] = bc;
+      if (last) ids_out[i] = (uint32_t)key;
+    }
+    __syncthreads();
+    float4* t = in; in = out; out = t;
+    if (last) break;
+    if (step == 1u) last = true; else step >>= 1;
+  }
+}
 // One flooding pass over the lattice g.
 static void launch_jfa_pass(hipStream_t st, const GridParams& g, const float4* in, float4* out, int step, uint32_t* ids) {
   const size_t total = (size_t)g.n[0] * g.n[1] * g.n[2];
@@ -2603,6 +2674,15 @@ int launch_grid_seeds(Arena& ws, hipStream_t st, const float4* cen, uint32_t n_t
   unsigned long long* keys = ws.take<unsigned long long>(points1);
   if (!ids || !la || !lb || !keys) { set_error("internal: seed workspace too small"); return M2S_ERR_HIP_INTERNAL; }
   const unsigned nb1 = (unsigned)((points1 + 255) / 256);
+  if (points1 <= JFA_SMALL_MAX) {                               // the whole flood in one workgroup
+    hipLaunchKernelGGL(k_jfa_small, dim3(1), dim3(JFA_SMALL_THREADS), 0, st, mesh, g1, ids);
+    out->ids = ids;
+    out->ny = g1.n[1];
+    out->nz = g1.n[2];
+    out->points = points1;
+    out->shift = seed_shift;
+    return 0;
+  }
   M2S_HIP_CHECK(hipMemsetAsync(keys, 0xff, points1 * 8, st));
   hipLaunchKernelGGL(k_jfa_splat, dim3((mesh.n_tris + 255) / 256), dim3(256), 0, st, mesh, g1, nullptr, keys);
   // (Round 6, measured and not kept: the flood's long steps on a lattice of half the resolution + a refinement pass — the seeds get worse by

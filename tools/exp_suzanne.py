@@ -1,8 +1,9 @@
 import os, sys
-sys.path.insert(0, os.getcwd())
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 import numpy as np, torch
 from mesh_to_sdf_amd import Grid, M2STimings, SignMethod, Topology, generate_grid_sdf, meshes
-d = np.load("tests/golden/suzanne.npz")
+d = np.load(os.path.join(ROOT, "tests/golden/suzanne.npz"))
 v, idx = d["vertices"].astype(np.float32), d["indices"].astype(np.uint32)
 lo, hi = meshes.extended_bbox(v, 0.1)
 dv, di = torch.as_tensor(v, device="cuda"), torch.as_tensor(idx.astype(np.int64), device="cuda").to(torch.int32)
