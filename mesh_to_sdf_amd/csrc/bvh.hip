@@ -21,7 +21,6 @@
 #include <functional>
 #include <vector>
 
-#include <rocprim/rocprim.hpp>
 
 #include "../../include/m2s.h"
 #include "common.h"
@@ -1112,7 +1111,7 @@ inline unsigned cdiv(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }
 size_t bvh_workspace_bytes(size_t n_tris) {
   const size_t n = n_tris ? n_tris : 1;
   size_t sort_tmp = 0;
-  (void)rocprim::radix_sort_pairs(nullptr, sort_tmp, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr,
+  (void)sort_pairs_u64(nullptr, sort_tmp, (const uint64_t*)nullptr, (uint64_t*)nullptr, (const uint32_t*)nullptr,
                             (uint32_t*)nullptr, n, 0, 64, (hipStream_t)0);
   size_t b = AUX_WORDS * 4 + 256;
   b += n * 48 + 256 + n * sizeof(TriRec) * 2 + n * 16 + 256 + n * 16 + 256 + n * 16 + 256 + n * 4 + 256 + n * sizeof(TriPlanes) + 256 + n * sizeof(Box) * 3 + n * (8 + 4) * 2 + sort_tmp;
@@ -1170,7 +1169,7 @@ int build_device_mesh(Arena& ws, hipStream_t st, const float* d_verts, size_t n_
   int* scene = ws.take<int>(8 + 6 * ((n_tris + 255) / 256));
   uint32_t* aux = ws.take<uint32_t>(AUX_WORDS);   // [0]: k_hierarchy's finished segment-tree blocks
   size_t sort_tmp = 0;
-  (void)rocprim::radix_sort_pairs(nullptr, sort_tmp, keys, keys2, vals, order, n_tris, 0, 64, st);
+  (void)sort_pairs_u64(nullptr, sort_tmp, keys, keys2, vals, order, n_tris, 0, 64, st);
   void* tmp = ws.take<char>(sort_tmp ? sort_tmp : 1);
   const uint32_t sort_w = sort_tile_size(n_tris);
   SortBufs sb;
@@ -1218,7 +1217,7 @@ int build_device_mesh(Arena& ws, hipStream_t st, const float* d_verts, size_t n_
   else if (sort_w == 2048u) launch_sample_sort<2048>(st, boxes, (uint32_t)n_tris, scene, (uint32_t)cdiv(n_tris, B), sb, keys2, order, d_err);
   else {
     hipLaunchKernelGGL(k_morton_keys, dim3(key_tiles(n_tris)), dim3(KEY_THREADS), 0, st, boxes, (uint32_t)n_tris, scene, (uint32_t)cdiv(n_tris, B), keys, vals, key_tile_pairs(n_tris));
-    M2S_HIP_CHECK(rocprim::radix_sort_pairs(tmp, sort_tmp, keys, keys2, vals, order, n_tris, 0, 64, st));
+    M2S_HIP_CHECK(sort_pairs_u64(tmp, sort_tmp, keys, keys2, vals, order, n_tris, 0, 64, st));
   }
   if (after_setup) {
     // phase 1: `st` now holds ~100 us of work (keys, sort) — the time the host needs to enqueue the side work (the seed

@@ -1307,6 +1307,8 @@ int m2s_warmup(int device, size_t workspace_bytes, size_t host_ring_bytes) {
   warm_distance(c.stream);
   warm_serde(c.stream);
   warm_client(c.stream);
+  warm_sortlib(c.stream);                                        // (the rocPRIM sorts of large meshes and of the query path: units of their own,
+  warm_sortlib_query(c.stream);                                  // which a grid call over a mesh of <= 229 376 triangles never loads)
   M2S_HIP_CHECK(hipGetLastError());
   M2S_HIP_CHECK(hipStreamSynchronize(c.stream));
   return M2S_OK;

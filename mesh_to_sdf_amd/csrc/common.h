@@ -214,6 +214,12 @@ struct Arena {
   }
 };
 
+// sortlib.hip: the rocPRIM calls (their device code lives in that translation unit alone; tmp == nullptr: the size query)
+hipError_t sort_pairs_u64(void* tmp, size_t& bytes, const uint64_t* keys_in, uint64_t* keys_out, const uint32_t* vals_in, uint32_t* vals_out, size_t n,
+                          unsigned begin_bit, unsigned end_bit, hipStream_t st);
+hipError_t sort_pairs_u32(void* tmp, size_t& bytes, const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* vals_in, uint32_t* vals_out, size_t n,
+                          unsigned begin_bit, unsigned end_bit, hipStream_t st);
+hipError_t select_flagged_indices(void* tmp, size_t& bytes, const uint8_t* flags, uint32_t* out, uint32_t* count, size_t n, hipStream_t st);
 // ---- host launchers implemented in the .hip files ------------------------------------------
 // one empty kernel per translation unit (m2s_warmup)
 void warm_bvh(hipStream_t st);
@@ -221,6 +227,8 @@ void warm_sign(hipStream_t st);
 void warm_distance(hipStream_t st);
 void warm_serde(hipStream_t st);
 void warm_client(hipStream_t st);
+void warm_sortlib(hipStream_t st);
+void warm_sortlib_query(hipStream_t st);
 // bvh.hip: flatten topology, build triangle records + LBVH in pre-order layout.
 size_t bvh_workspace_bytes(size_t n_tris);
 // `after_setup` (optional) is called twice with the input-order centroid array and triangle records: with phase 0 once the kernels that fill

@@ -21,8 +21,6 @@
 #include <cstdlib>
 #include <cstring>
 
-#include <rocprim/rocprim.hpp>
-
 #include "common.h"
 #include "geo.hip.h"
 #include "tuning.h"
@@ -3101,10 +3099,10 @@ int launch_query_brute_split(Arena& ws, hipStream_t st, const DeviceMesh& mesh, 
 
 size_t query_workspace_bytes(size_t n_q) {
   size_t n = n_q ? n_q : 1, tmp = 0;
-  (void)rocprim::radix_sort_pairs(nullptr, tmp, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr,
+  (void)sort_pairs_u32(nullptr, tmp, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr,
                             n, 0, 30, (hipStream_t)0);
   size_t sel = 0;
-  (void)rocprim::select(nullptr, sel, rocprim::counting_iterator<uint32_t>(0), (uint8_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, n, (hipStream_t)0);
+  (void)select_flagged_indices(nullptr, sel, (const uint8_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, n, (hipStream_t)0);
   return n * (8 + 8 + 4 + 4 + 16 + 1 + 4) + n * 16 + 256 + (n / 32 + 64) * (16 + 4 * CUT_WORDS) + tmp + sel + 21 * 256 + (size_t)64 * 64 * 64 * 44 + 8192 + 24 * 1024 + 256;
 }
 
@@ -3127,7 +3125,7 @@ int prepare_query_walk(Arena& ws, hipStream_t st, const float* d_queries, size_t
   uint32_t* perm = ws.take<uint32_t>(n_q);
   float4* sorted = ws.take<float4>(n_q);
   size_t tmp_bytes = 0;
-  (void)rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys, keys2, vals, perm, n_q, 0, QKEY_BITS, st);
+  (void)sort_pairs_u32(nullptr, tmp_bytes, keys, keys2, vals, perm, n_q, 0, QKEY_BITS, st);
   void* tmp = ws.take<char>(tmp_bytes ? tmp_bytes : 1);
   if (!qb || !keys || !keys2 || !vals || !perm || !sorted || !tmp) {
     set_error("internal: query workspace too small");
@@ -3150,7 +3148,7 @@ int prepare_query_walk(Arena& ws, hipStream_t st, const float* d_queries, size_t
   }
   if (after_lattice) M2S_HIP_CHECK(hipEventRecord(after_lattice, st));
   hipLaunchKernelGGL(k_qkeys, dim3(nb), dim3(B), 0, st, d_queries, nq, qb, keys, vals, drop);
-  M2S_HIP_CHECK(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, keys2, vals, perm, n_q, drop, QKEY_BITS, st));
+  M2S_HIP_CHECK(sort_pairs_u32(tmp, tmp_bytes, keys, keys2, vals, perm, n_q, drop, QKEY_BITS, st));
   // Sparse query sets take the lane walk (k_lane_q).  Measured crossover, uniform queries in the extended box (lane / packet walk,
   // RtreeBvh): blob-100k 100 k queries 1.36 / 3.65 ms, 1 M 2.70 / 3.45, 3 M 5.00 / 4.38, 10 M 12.3 / 6.7 (crossover ~2 M);
   // blob-1M 1 M 6.3 / 12.8 ms, 10 M 26.4 / 22.4 (~7 M).  Below it the packet walk lasts as long as its worst packet's chain of
@@ -3169,11 +3167,11 @@ int prepare_query_walk(Arena& ws, hipStream_t st, const float* d_queries, size_t
     uint8_t* head = ws.take<uint8_t>(n_q);
     uint32_t* tb = ws.take<uint32_t>(n_q + 2);               // [0] count, [1] mode, then one start per head (at most n_q)
     size_t sel_bytes = 0;
-    (void)rocprim::select(nullptr, sel_bytes, rocprim::counting_iterator<uint32_t>(0), head, tb + 2, tb, n_q, st);
+    (void)select_flagged_indices(nullptr, sel_bytes, head, tb + 2, tb, n_q, st);
     void* sel_tmp = ws.take<char>(sel_bytes ? sel_bytes : 1);
     if (!head || !tb || !sel_tmp) { set_error("internal: query workspace too small"); return M2S_ERR_HIP_INTERNAL; }
     hipLaunchKernelGGL(k_qcells, dim3(nb), dim3(B), 0, st, keys2, nq, head);
-    M2S_HIP_CHECK(rocprim::select(sel_tmp, sel_bytes, rocprim::counting_iterator<uint32_t>(0), head, tb + 2, tb, n_q, st));
+    M2S_HIP_CHECK(select_flagged_indices(sel_tmp, sel_bytes, head, tb + 2, tb, n_q, st));
     hipLaunchKernelGGL(k_qtable_mode, dim3(1), dim3(1), 0, st, tb, nq, launched);
     table = tb;
   }

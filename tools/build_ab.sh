@@ -8,7 +8,7 @@ mkdir -p ../ab
 BASE="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-slp-vectorize -Wall -Wno-unused-function -Wno-bitwise-instead-of-logical"
 /opt/rocm/bin/hipcc $BASE $FLAGS -c $UNIT -o ../ab/${UNIT%.hip}_$TAG.o
 OBJS=""
-for o in bvh sign distance serde client gltf tuning capi capi_io multi; do
+for o in bvh sign distance sortlib sortlib_query serde client gltf tuning capi capi_io multi; do
   if [ "$o.hip" == "$UNIT" ]; then OBJS="$OBJS ../ab/${o}_$TAG.o"; else OBJS="$OBJS $o.o"; fi
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../ab/libm2s_$TAG.so $OBJS -ldl
