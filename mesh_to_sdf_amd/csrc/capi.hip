@@ -1033,7 +1033,7 @@ int m2s_generate_grid_sdf(const float* vertices, size_t n_vertices, const void* 
   st->early_planes = false;
   // tiny problems (cells x triangles small): all voxels against all triangles, no tree (distance.hip k_brute_split)
   const bool stats = tuning().stats != 0;
-  const bool tiny = grid_is_tiny(g, n_tris, c.algorithm) && !stats;
+  const bool tiny = grid_is_tiny(g, n_tris, c.algorithm, sign_method == M2S_SIGN_RAYCAST) && !stats;
   const bool beside = !tiny && c.algorithm == 0 && !stats && grid_walk_wants_seeds(g, n_tris, c.algorithm);
   const std::function<int(const float4*, const TriRec*, int)> seeds_beside_build = [&](const float4* cen_raw, const TriRec* raw, int phase) -> int {
     if (!side_stream_wanted(c.sync)) return 0;               // no side stream for this call: seeds as part of the walk's preparation

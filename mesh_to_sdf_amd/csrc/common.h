@@ -284,7 +284,7 @@ struct GridWalkPlan {
   uint32_t group_waves = 0;           // ... waves per packet (2, 4, 8 or 16)
   uint32_t* brute_acc = nullptr;   // tiny problems (grid_is_tiny): per-voxel minima of k_brute_split; no seeds, no lists, no tree
 };
-bool grid_is_tiny(const GridParams& g, size_t n_tris, int algorithm);
+bool grid_is_tiny(const GridParams& g, size_t n_tris, int algorithm, bool raycast);   // raycast: the call's sign rule (the limits differ)
 // Seed lattice of a slab: one triangle id per packet brick (ids index the centroid array it was computed from).
 struct SeedLattice {
   uint32_t* ids = nullptr;

@@ -2626,9 +2626,15 @@ static size_t split_workspace_bytes(const GridParams& g, size_t n_tris, size_t p
   const size_t rounds = std::min(tuning().split_rounds, SPLIT_MAX_ROUNDS);
   return 256 + SPLIT_CNT_WORDS * 4 + cap * 4 + 256 + cap * 128 * 4 + 256 + rounds * items * 16 + 256;
 }
-bool grid_is_tiny(const GridParams& g, size_t n_tris, int algorithm) {
+// Round 6 (packet groups, one-workgroup seed flood: the walks of small problems got faster), whole one-shot calls, brute / build + walk
+// (tools/exp_tiny.py, profiles/r06_tiny.txt): suzanne (968 triangles) 16^3 Raycast 0.120 / 0.125 ms, 24^3 0.151 / 0.127, Normal 24^3 0.097 / 0.132, 32^3
+// 0.136 / 0.128; blob-11k 12^3 Raycast 0.190 / 0.276, 16^3 0.323 / 0.232, Normal 16^3 0.204 / 0.231, 20^3 0.347 / 0.252; blob-100k 8^3 0.40 / 1.17,
+// 12^3 Raycast 1.05 / 0.94, Normal 0.66 / 0.93.  Brute force costs 0.08 ms + pairs / 1.9e11 per s with the Raycast planes (0.06 + pairs / 3e11 for
+// Normal), the walk 0.12 ms + 1e-5 ms per triangle: the limits below are where they cross (rounds 2 - 5: 1e8 + 3 000 per triangle for both).
+bool grid_is_tiny(const GridParams& g, size_t n_tris, int algorithm, bool raycast) {
   if (algorithm != 0 || n_tris == 0 || g.xe <= g.xb || g.n[1] == 0 || g.n[2] == 0 || g.chunk_log < 31u) return false;
-  const double limit = tuning().brute_max >= 0.0 ? tuning().brute_max : 1.0e8 + 3.0e3 * (double)n_tris;
+  const double automatic = raycast ? 7.6e6 + 1.9e3 * (double)n_tris : 1.8e7 + 3.0e3 * (double)n_tris;
+  const double limit = tuning().brute_max >= 0.0 ? tuning().brute_max : automatic;
   const double cells = (double)(g.xe - g.xb) * g.n[1] * g.n[2];
   return cells <= 4194304.0 && cells * (double)n_tris <= limit;
 }
@@ -2717,7 +2723,9 @@ int prepare_grid_walk(Arena& ws, hipStream_t st, const DeviceMesh& mesh, const G
   *plan = GridWalkPlan{};
   if (g.xe <= g.xb || g.n[1] == 0 || g.n[2] == 0) return 0;
   const uint32_t packets = host_brick_count(g);
-  if (grid_is_tiny(g, mesh.n_tris, algorithm)) {
+  // a one-shot call that found its problem tiny built the triangle records only (no tree: n_nodes == 0); a resident mesh decides here, by the
+  // smaller (Raycast) limit: it has its tree already
+  if ((mesh.n_nodes == 0 && mesh.n_tris != 0 && algorithm == 0) || grid_is_tiny(g, mesh.n_tris, algorithm, true)) {
     plan->brute_acc = ws.take<uint32_t>((size_t)packets * 64 * 2);
     if (!plan->brute_acc) { set_error("internal: brute-force workspace too small"); return M2S_ERR_HIP_INTERNAL; }
     return 0;
