@@ -2827,7 +2827,8 @@ int prepare_grid_walk(Arena& ws, hipStream_t st, const DeviceMesh& mesh, const G
   // cut lists where the bricks meet several triangles each (the chains are long there: 64^3 ... 128^3 over 100 k triangles)
   {
     const int gk = tn.group;
-    const bool can = !brute && !lane_walk && cut.lists == nullptr && mesh.n_nodes != 0 && mesh.stats == nullptr && tn.split <= 0 && tn.defer < 0 && g.chunk_log >= 31u;
+    // (not where the split walk is the automatic choice — large meshes in launches deeper than the chip: blob-1M 96^3 Raycast 1.88 ms split, 2.48 in groups)
+    const bool can = !brute && !lane_walk && cut.lists == nullptr && mesh.n_nodes != 0 && mesh.stats == nullptr && tn.split <= 0 && !split_auto && tn.defer < 0 && g.chunk_log >= 31u;
     const bool want = gk > 0 || (gk < 0 && (double)mesh.n_tris >= tn.group_min_ratio * real_bricks);
     if (can && want) {
       // as many waves per packet (a power of two, four at most) as keep the launch within M2S_GROUP_TARGET_WAVES waves
