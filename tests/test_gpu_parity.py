@@ -671,7 +671,12 @@ def test_full_size_config5_sheet100k_1024_normal():
         a = s3[x0 : x0 + 128].abs()
         dz = max(dz, float((a[:, :, 1:] - a[:, :, :-1]).abs().max()))
     assert dz <= cs + 2e-6
-    del sdf, s3
+    # the single 1024^3 call makes its cut lists in two levels (262 144 fine k_cut waves; a 128-layer slab's 32 768 stay below the automatic
+    # threshold): it must reproduce the slabs — which have just met the oracle on every lane of a packet — bit for bit
+    del s3
+    whole = generate_grid_sdf(dv, Topology.TriangleList(di), g, SignMethod.Normal)
+    assert torch.equal(whole.view(torch.int32), sdf.view(torch.int32)), "1024^3 in one call (two-level cut lists) differs from its slabs"
+    del sdf, whole
 
 
 @pytest.mark.parametrize("sign", [SignMethod.Raycast, SignMethod.Normal])
